@@ -1,0 +1,169 @@
+// api.hip -- the extern "C" boundary declared in include/gsrast.h.
+#include "gsr_common.h"
+
+thread_local int gsr_tls_hip_error = 0;
+
+// stage launchers (preprocess.hip, binning.hip, render.hip)
+int gsr_launch_preprocess(const GsrView&, const GsrGaussians&, GsrGeom&, hipStream_t);
+int gsr_launch_preprocess_bwd(const GsrView&, const GsrGaussians&, const GsrGeom&, const GsrGrads&, hipStream_t);
+int gsr_launch_scan(GsrGeom&, int32_t P, uint64_t* n_pairs_dev, hipStream_t);
+int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t n, GsrBinning&, hipStream_t, GsrProfile*);
+int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, GsrImages&, hipStream_t);
+int gsr_launch_render_bwd(const GsrView&, const GsrGeom&, const GsrBinning&, const GsrImages&, const GsrImageGrads&,
+                          GsrGrads&, hipStream_t);
+
+namespace {
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_view(const GsrView* v) {
+  if (!v) return GSR_EINVAL;
+  if (v->P < 0 || v->image_height <= 0 || v->image_width <= 0) return GSR_EINVAL;
+  if (v->sh_degree < 0 || v->sh_degree > 3) return GSR_EINVAL;
+  if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos) return GSR_EINVAL;
+  if (!(v->tanfovx > 0.f) || !(v->tanfovy > 0.f)) return GSR_EINVAL;
+  return GSR_OK;
+}
+
+int check_gaussians(const GsrView* v, const GsrGaussians* g) {
+  if (!g) return GSR_EINVAL;
+  if (v->P == 0) return GSR_OK;
+  if (!g->means3D || !g->opacities) return GSR_EINVAL;
+  if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return GSR_EINVAL;
+  const bool sr = g->scales != nullptr && g->rotations != nullptr;
+  const bool any_sr = g->scales != nullptr || g->rotations != nullptr;
+  if (g->cov3D_precomp ? any_sr : !sr) return GSR_EINVAL;
+  if (g->shs) {
+    const int nb = (v->sh_degree + 1) * (v->sh_degree + 1);
+    if (v->sh_stride < nb || v->sh_stride > 64) return GSR_EINVAL;
+    if (!aligned16(g->shs)) return GSR_EINVAL;
+  }
+  if (g->rotations && !aligned16(g->rotations)) return GSR_EINVAL;
+  return GSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gsr_version(void) { return GSR_VERSION; }
+
+int gsr_last_hip_error(void) { return gsr_tls_hip_error; }
+
+const char* gsr_strerror(int code) {
+  switch (code) {
+    case GSR_OK: return "ok";
+    case GSR_EINVAL: return "invalid argument (shape, null pointer, alignment or unsupported SH degree)";
+    case GSR_ECAPACITY: return "tile-pair count does not fit 32-bit list positions";
+    case GSR_EHIP: return hipGetErrorString((hipError_t)gsr_tls_hip_error);
+    case GSR_ESCRATCH: return "sort scratch buffer too small";
+    default: return "unknown gsrast error";
+  }
+}
+
+GsrProfile* gsr_profile_create(void) { return new GsrProfile(); }
+
+void gsr_profile_destroy(GsrProfile* p) {
+  if (!p) return;
+  for (int i = 0; i < p->created; ++i) {
+    (void)hipEventDestroy(p->ev[i][0]);
+    (void)hipEventDestroy(p->ev[i][1]);
+  }
+  delete p;
+}
+
+int gsr_profile_collect(GsrProfile* p, double* ms, int64_t* counts) {
+  if (!p || !ms || !counts) return GSR_EINVAL;
+  for (int i = 0; i < p->n; ++i) {
+    GSR_HIP(hipEventSynchronize(p->ev[i][1]));
+    float t = 0.f;
+    GSR_HIP(hipEventElapsedTime(&t, p->ev[i][0], p->ev[i][1]));
+    ms[p->stage[i]] += (double)t;
+    counts[p->stage[i]] += 1;
+  }
+  p->n = 0;
+  return GSR_OK;
+}
+
+int gsr_forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geom, uint64_t* n_pairs_host, void* stream_,
+                        GsrProfile* prof) {
+  int rc = check_view(v);
+  if (rc) return rc;
+  rc = check_gaussians(v, g);
+  if (rc) return rc;
+  if (!geom || !n_pairs_host) return GSR_EINVAL;
+  *n_pairs_host = 0;
+  if (v->P == 0) return GSR_OK;
+  if (!geom->splat || !geom->radii || !geom->tiles_touched || !geom->block_offsets) return GSR_EINVAL;
+  if (!aligned16(geom->splat)) return GSR_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  {
+    GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS);
+    rc = gsr_launch_preprocess(*v, *g, *geom, stream);
+    if (rc) return rc;
+  }
+  // the device-side u64 total lives right after the u32 offsets (block_offsets has nb+1 entries + 2 spare)
+  const uint32_t nb = gsr_num_blocks(v->P);
+  uint64_t* n_dev = reinterpret_cast<uint64_t*>(geom->block_offsets + ((nb + 1 + 1) & ~1u));
+  {
+    GsrStageTimer t(prof, stream, GSR_STAGE_SCAN);
+    rc = gsr_launch_scan(*geom, v->P, n_dev, stream);
+    if (rc) return rc;
+  }
+  GSR_HIP(hipMemcpyAsync(n_pairs_host, n_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  GSR_HIP(hipStreamSynchronize(stream));
+  if (*n_pairs_host >= (1ull << 32)) return GSR_ECAPACITY;
+  return GSR_OK;
+}
+
+int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, GsrBinning* b, GsrImages* img,
+                       void* stream_, GsrProfile* prof) {
+  int rc = check_view(v);
+  if (rc) return rc;
+  if (!geom || !b || !img) return GSR_EINVAL;
+  if (!b->ranges || !img->color || !img->depth_alpha || !img->final_T || !img->n_contrib) return GSR_EINVAL;
+  if (n_pairs && (!b->point_list || !geom->splat)) return GSR_EINVAL;
+  if (n_pairs >= (1ull << 32)) return GSR_ECAPACITY;
+  hipStream_t stream = (hipStream_t)stream_;
+  rc = gsr_launch_binning(*v, *geom, n_pairs, *b, stream, prof);
+  if (rc) return rc;
+  {
+    GsrStageTimer t(prof, stream, GSR_STAGE_RENDER_FWD);
+    rc = gsr_launch_render_fwd(*v, *geom, *b, *img, stream);
+    if (rc) return rc;
+  }
+  return GSR_OK;
+}
+
+int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, const GsrBinning* b,
+                 const GsrImages* img, const GsrImageGrads* ig, GsrGrads* out, void* stream_, GsrProfile* prof) {
+  int rc = check_view(v);
+  if (rc) return rc;
+  rc = check_gaussians(v, g);
+  if (rc) return rc;
+  if (!geom || !b || !img || !ig || !out) return GSR_EINVAL;
+  if (v->P == 0) return GSR_OK;
+  if (!ig->dL_dcolor || !ig->dL_ddepth_alpha || !img->final_T || !img->n_contrib || !b->ranges) return GSR_EINVAL;
+  if (!out->partials || !aligned16(out->partials)) return GSR_EINVAL;
+  if (!out->dL_dmeans3D || !out->dL_dmeans2D || !out->dL_dopacities) return GSR_EINVAL;
+  if (out->dL_dshs && (!g->shs || !aligned16(out->dL_dshs))) return GSR_EINVAL;
+  if (out->dL_dcolors && !g->colors_precomp) return GSR_EINVAL;
+  if ((out->dL_dscales || out->dL_drotations) && g->cov3D_precomp) return GSR_EINVAL;
+  if (out->dL_dcov3D && !g->cov3D_precomp) return GSR_EINVAL;
+  if (out->dL_drotations && !aligned16(out->dL_drotations)) return GSR_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  GSR_HIP(hipMemsetAsync(out->partials, 0, (size_t)v->P * 12 * sizeof(float), stream));
+  {
+    GsrStageTimer t(prof, stream, GSR_STAGE_RENDER_BWD);
+    rc = gsr_launch_render_bwd(*v, *geom, *b, *img, *ig, *out, stream);
+    if (rc) return rc;
+  }
+  {
+    GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
+    rc = gsr_launch_preprocess_bwd(*v, *g, *geom, *out, stream);
+    if (rc) return rc;
+  }
+  return GSR_OK;
+}
+
+}  // extern "C"

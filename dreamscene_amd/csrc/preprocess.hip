@@ -1,0 +1,586 @@
+// preprocess.hip -- K1 (per-Gaussian EWA projection + SH colour) and K8 (its backward), gfx950.
+//
+// Replaces the preprocess stage of the rasterizer DreamScene imports (scene_gaussian.py:11-12); the math
+// follows SEMANTICS.md / SURVEY.md Appendix A.1, A.3 and the Python statements the reference does hold:
+// cov3D gs_renderer.py:124-172, SH utils/sh_utils.py:25-102, projection utils/graphics_utils.py:29-36.
+//
+// Both kernels are HBM-streaming (44 + 12K bytes in per Gaussian for K1; 276 in / 248 out for K8 at K=16).
+// One thread per Gaussian; the [P,K,3] SH block of a wave (64*3K contiguous floats) is moved with fully
+// coalesced 16-byte loads/stores and transposed through LDS (odd row stride => conflict-free per-lane rows)
+// instead of 64 lanes each walking its own 12K-byte row.
+//
+// This translation unit is built with -ffp-contract=off: every fp32 operator that feeds an integer artefact
+// (depth bits, radius, tile rectangle) rounds exactly once, in the order written -- the same order as
+// oracle/gsr_oracle.c -- which is what makes radii / tile counts / sort keys bit-exact against the oracle.
+#include "gsr_common.h"
+
+namespace {
+
+struct ViewConst {
+  float V[16];
+  float PV[16];
+  float cam[3];
+};
+
+__device__ __forceinline__ void load_view(const GsrView& v, ViewConst& c) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { c.V[i] = v.viewmatrix[i]; c.PV[i] = v.projmatrix[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c.cam[i] = v.campos[i];
+}
+
+__device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  R[0] = 1.0f - 2.0f * (y * y + z * z);
+  R[1] = 2.0f * (x * y - r * z);
+  R[2] = 2.0f * (x * z + r * y);
+  R[3] = 2.0f * (x * y + r * z);
+  R[4] = 1.0f - 2.0f * (x * x + z * z);
+  R[5] = 2.0f * (y * z - r * x);
+  R[6] = 2.0f * (x * z - r * y);
+  R[7] = 2.0f * (y * z + r * x);
+  R[8] = 1.0f - 2.0f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void cov3d_from(const float s0, const float s1, const float s2, const float R[9],
+                                           float c6[6]) {
+  float L[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    L[3 * i + 0] = R[3 * i + 0] * s0;
+    L[3 * i + 1] = R[3 * i + 1] * s1;
+    L[3 * i + 2] = R[3 * i + 2] * s2;
+  }
+#define GSR_SIG(i, j) ((L[3 * i] * L[3 * j] + L[3 * i + 1] * L[3 * j + 1]) + L[3 * i + 2] * L[3 * j + 2])
+  c6[0] = GSR_SIG(0, 0); c6[1] = GSR_SIG(0, 1); c6[2] = GSR_SIG(0, 2);
+  c6[3] = GSR_SIG(1, 1); c6[4] = GSR_SIG(1, 2); c6[5] = GSR_SIG(2, 2);
+#undef GSR_SIG
+}
+
+// The EWA chain shared by K1 and K8 (identical operator order => identical values in both).
+struct Ewa {
+  float tx, ty, tz, txc, tyc, J00, J02, J11, J12;
+  float M0[3], M1[3], U0[3], U1[3];
+  float ca, cb, cc, det;
+  bool clx, cly;
+};
+
+__device__ __forceinline__ void ewa_forward(const ViewConst& vc, float px, float py, float pz, const float c6[6],
+                                            float fx, float fy, float limx, float limy, Ewa& e) {
+  const float* V = vc.V;
+  e.tx = ((V[0] * px + V[4] * py) + V[8] * pz) + V[12];
+  e.ty = ((V[1] * px + V[5] * py) + V[9] * pz) + V[13];
+  e.tz = ((V[2] * px + V[6] * py) + V[10] * pz) + V[14];
+  const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+  const float txz = e.tx / e.tz, tyz = e.ty / e.tz;
+  e.clx = (txz < -limx) || (txz > limx);
+  e.cly = (tyz < -limy) || (tyz > limy);
+  e.txc = fminf(limx, fmaxf(-limx, txz)) * e.tz;
+  e.tyc = fminf(limy, fmaxf(-limy, tyz)) * e.tz;
+  e.J00 = fx / e.tz;
+  e.J02 = -(fx * e.txc) / (e.tz * e.tz);
+  e.J11 = fy / e.tz;
+  e.J12 = -(fy * e.tyc) / (e.tz * e.tz);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    e.M0[r] = e.J00 * V[4 * r + 0] + e.J02 * V[4 * r + 2];
+    e.M1[r] = e.J11 * V[4 * r + 1] + e.J12 * V[4 * r + 2];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    e.U0[j] = (e.M0[0] * S[j] + e.M0[1] * S[3 + j]) + e.M0[2] * S[6 + j];
+    e.U1[j] = (e.M1[0] * S[j] + e.M1[1] * S[3 + j]) + e.M1[2] * S[6 + j];
+  }
+  e.ca = ((e.U0[0] * e.M0[0] + e.U0[1] * e.M0[1]) + e.U0[2] * e.M0[2]) + GSR_LOWPASS;
+  e.cb = (e.U0[0] * e.M1[0] + e.U0[1] * e.M1[1]) + e.U0[2] * e.M1[2];
+  e.cc = ((e.U1[0] * e.M1[0] + e.U1[1] * e.M1[1]) + e.U1[2] * e.M1[2]) + GSR_LOWPASS;
+  e.det = e.ca * e.cc - e.cb * e.cb;
+}
+
+__device__ __forceinline__ void sh_basis(int D, float x, float y, float z, float b[16]) {
+  b[0] = GSR_SH_C0;
+  if (D > 0) {
+    b[1] = -GSR_SH_C1 * y; b[2] = GSR_SH_C1 * z; b[3] = -GSR_SH_C1 * x;
+    if (D > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      b[4] = GSR_SH_C2_0 * xy; b[5] = GSR_SH_C2_1 * yz; b[6] = GSR_SH_C2_2 * (2.0f * zz - xx - yy);
+      b[7] = GSR_SH_C2_3 * xz; b[8] = GSR_SH_C2_4 * (xx - yy);
+      if (D > 2) {
+        b[9] = GSR_SH_C3_0 * y * (3.0f * xx - yy);
+        b[10] = GSR_SH_C3_1 * xy * z;
+        b[11] = GSR_SH_C3_2 * y * (4.0f * zz - xx - yy);
+        b[12] = GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+        b[13] = GSR_SH_C3_4 * x * (4.0f * zz - xx - yy);
+        b[14] = GSR_SH_C3_5 * z * (xx - yy);
+        b[15] = GSR_SH_C3_6 * x * (xx - 3.0f * yy);
+      }
+    }
+  }
+}
+
+// Row stride (in floats) of one Gaussian's SH block inside the LDS transpose buffer: odd => the 64 lanes of a
+// wave reading "their" row element k hit 64 different banks pairs (ds_read_b32, 32-lane groups).
+__host__ __device__ __forceinline__ int sh_lds_stride(int K) { return (3 * K) | 1; }
+
+// Coalesced global -> LDS load of the wave's SH block. `vis` = ballot of lanes whose Gaussian needs its row.
+__device__ __forceinline__ void stage_sh_in(const float* __restrict__ shs, int64_t wave_first, int n_valid, int K,
+                                            unsigned long long vis, float* lds_wave) {
+  const int F = 3 * K;
+  const int stride = sh_lds_stride(K);
+  const int total = n_valid * F;                                   // floats in the wave's block
+  const float* src = shs + wave_first * (int64_t)F;
+  const int lane = gsr_lane();
+  for (int q = lane * 4; q < total; q += 64 * 4) {
+    const int g0 = q / F, g1 = (q + 3) / F;
+    const bool need = ((vis >> g0) & 1ull) || ((g1 < 64) && ((vis >> g1) & 1ull));
+    if (!need) continue;
+    float4 v;
+    if (q + 3 < total) {
+      v = *reinterpret_cast<const float4*>(src + q);
+    } else {
+      v.x = src[q];
+      v.y = (q + 1 < total) ? src[q + 1] : 0.f;
+      v.z = (q + 2 < total) ? src[q + 2] : 0.f;
+      v.w = 0.f;
+    }
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = q + k;
+      if (f < total) {
+        const int g = f / F, o = f - g * F;
+        lds_wave[g * stride + o] = e[k];
+      }
+    }
+  }
+}
+
+// LDS -> global coalesced store of the wave's [n_valid, 3K] block.
+__device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64_t wave_first, int n_valid, int K,
+                                             const float* lds_wave) {
+  const int F = 3 * K;
+  const int stride = sh_lds_stride(K);
+  const int total = n_valid * F;
+  float* dst = dst_base + wave_first * (int64_t)F;
+  const int lane = gsr_lane();
+  for (int q = lane * 4; q < total; q += 64 * 4) {
+    float e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = q + k;
+      const int g = f / F, o = f - g * F;
+      e[k] = (f < total) ? lds_wave[g * stride + o] : 0.f;
+    }
+    if (q + 3 < total) {
+      *reinterpret_cast<float4*>(dst + q) = make_float4(e[0], e[1], e[2], e[3]);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (q + k < total) dst[q + k] = e[k];
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------- K1
+__global__ void __launch_bounds__(256)
+k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, int32_t* __restrict__ radii,
+             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ uint32_t wave_tiles[4];
+  const int P = v.P, W = v.image_width, H = v.image_height, K = v.sh_stride;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
+  const int n_valid = (int)min((int64_t)64, max((int64_t)0, (int64_t)P - wave_first));
+  const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+  const float fx = (float)W / (2.0f * v.tanfovx), fy = (float)H / (2.0f * v.tanfovy);
+  const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
+
+  ViewConst vc;
+  load_view(v, vc);
+
+  bool vis = false;
+  float px = 0, py = 0, pz = 0;
+  float q0x = 0, q0y = 0, ca_ = 0, cb_ = 0, cc_ = 0, depth = 0, opac = 0;
+  int32_t radius = 0;
+  uint32_t ntiles = 0;
+  if (i < P) {
+    px = g.means3D[3 * i]; py = g.means3D[3 * i + 1]; pz = g.means3D[3 * i + 2];
+    const float tzq = ((vc.V[2] * px + vc.V[6] * py) + vc.V[10] * pz) + vc.V[14];
+    if (tzq > GSR_NEAR_Z) {
+      const float* PV = vc.PV;
+      const float hx = ((PV[0] * px + PV[4] * py) + PV[8] * pz) + PV[12];
+      const float hy = ((PV[1] * px + PV[5] * py) + PV[9] * pz) + PV[13];
+      const float hw = ((PV[3] * px + PV[7] * py) + PV[11] * pz) + PV[15];
+      const float pw = 1.0f / (hw + 0.0000001f);
+      const float ndcx = hx * pw, ndcy = hy * pw;
+      float c6[6];
+      if (g.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = g.cov3D_precomp[6 * i + k];
+      } else {
+        const float mod = v.scale_modifier;
+        const float s0 = mod * g.scales[3 * i], s1 = mod * g.scales[3 * i + 1], s2 = mod * g.scales[3 * i + 2];
+        const float4 q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
+        float R[9];
+        quat_to_R(q, R);
+        cov3d_from(s0, s1, s2, R, c6);
+      }
+      Ewa e;
+      ewa_forward(vc, px, py, pz, c6, fx, fy, limx, limy, e);
+      if ((fabsf(e.det) > 0.0f) && (fabsf(e.det) < INFINITY)) {
+        const float inv = 1.0f / e.det;
+        const float mid = 0.5f * (e.ca + e.cc);
+        const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - e.det));
+        radius = gsr_f2i_sat(ceilf(3.0f * sqrtf(lam)));
+        const float pxl = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
+        const float pyl = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+        const float rf = (float)radius;
+        const int32_t x0 = min(gx, max(0, gsr_f2i_sat((pxl - rf) * 0.0625f)));
+        const int32_t y0 = min(gy, max(0, gsr_f2i_sat((pyl - rf) * 0.0625f)));
+        const int32_t x1 = min(gx, max(0, gsr_f2i_sat(((pxl + rf) + 15.0f) * 0.0625f)));
+        const int32_t y1 = min(gy, max(0, gsr_f2i_sat(((pyl + rf) + 15.0f) * 0.0625f)));
+        ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
+        if (ntiles != 0) {
+          vis = true;
+          q0x = pxl; q0y = pyl;
+          ca_ = e.cc * inv; cb_ = -e.cb * inv; cc_ = e.ca * inv;
+          depth = e.tz;
+          opac = g.opacities[i];
+        } else {
+          radius = 0;
+        }
+      } else {
+        radius = 0;
+      }
+    }
+  }
+
+  // ---- colour
+  float rgb[3] = {0.f, 0.f, 0.f};
+  if (g.shs) {
+    const unsigned long long vmask = __ballot(vis);
+    float* lw = lds + wave * (64 * sh_lds_stride(K));
+    if (vmask) stage_sh_in(g.shs, wave_first, n_valid, K, vmask, lw);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (vis) {
+      float dx = px - vc.cam[0], dy = py - vc.cam[1], dz = pz - vc.cam[2];
+      const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+      dx = dx / len; dy = dy / len; dz = dz / len;
+      float b[16];
+      sh_basis(v.sh_degree, dx, dy, dz, b);
+      const int nb = (v.sh_degree + 1) * (v.sh_degree + 1);
+      const float* sh = lw + lane * sh_lds_stride(K);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float acc = b[0] * sh[c];
+        for (int k = 1; k < nb; ++k) acc = acc + b[k] * sh[3 * k + c];
+        acc = acc + 0.5f;
+        rgb[c] = fmaxf(acc, 0.0f);
+      }
+    }
+  } else if (vis) {
+    rgb[0] = g.colors_precomp[3 * i]; rgb[1] = g.colors_precomp[3 * i + 1]; rgb[2] = g.colors_precomp[3 * i + 2];
+  }
+
+  if (i < P) {
+    radii[i] = radius;
+    tiles_touched[i] = ntiles;
+    if (vis) {
+      float4* o = reinterpret_cast<float4*>(splat + 12 * i);
+      o[0] = make_float4(q0x, q0y, ca_, cb_);
+      o[1] = make_float4(cc_, opac, depth, rgb[0]);
+      o[2] = make_float4(rgb[1], rgb[2], 0.f, 0.f);
+    }
+  }
+
+  // ---- per-block tile count (feeds the scan)
+  uint32_t s = ntiles;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
+  if (lane == 0) wave_tiles[wave] = s;
+  __syncthreads();
+  if (tid == 0) block_sums[blockIdx.x] = (wave_tiles[0] + wave_tiles[1]) + (wave_tiles[2] + wave_tiles[3]);
+}
+
+// --------------------------------------------------------------------------------------------------------- K8
+// partials [P,12]: (dL/dndc_x, dL/dndc_y, dL/dconic a,b,c, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
+__global__ void __launch_bounds__(256)
+k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restrict__ radii,
+                 const float* __restrict__ partials, const GsrGrads out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float cam_red[4][32];
+  const int P = v.P, W = v.image_width, H = v.image_height, K = v.sh_stride, D = v.sh_degree;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
+  const int n_valid = (int)min((int64_t)64, max((int64_t)0, (int64_t)P - wave_first));
+  const float fx = (float)W / (2.0f * v.tanfovx), fy = (float)H / (2.0f * v.tanfovy);
+  const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
+  const float mod = v.scale_modifier;
+  const bool want_cam = (out.dL_dview != nullptr) || (out.dL_dproj != nullptr) || (out.dL_dcampos != nullptr);
+
+  ViewConst vc;
+  load_view(v, vc);
+  const float* V = vc.V;
+  const float* PV = vc.PV;
+
+  const bool vis = (i < P) && (radii[i] > 0);
+  float px = 0, py = 0, pz = 0;
+  float4 pa = make_float4(0, 0, 0, 0), pb = pa, pc = pa;
+  if (vis) {
+    px = g.means3D[3 * i]; py = g.means3D[3 * i + 1]; pz = g.means3D[3 * i + 2];
+    const float4* pp = reinterpret_cast<const float4*>(partials + 12 * i);
+    pa = pp[0]; pb = pp[1]; pc = pp[2];
+  }
+  const float gndx = pa.x, gndy = pa.y, gca = pa.z, gcb = pa.w, gcc = pb.x, gop = pb.y;
+  const float grgb[3] = {pb.z, pb.w, pc.x};
+  const float gdep = pc.y;
+
+  float dp[3] = {0.f, 0.f, 0.f};
+  float dview[12];   // rows 0..3 x cols 0..2 of dL/dviewmatrix
+  float dproj[12];   // rows 0..3 x cols {0,1,3} of dL/dprojmatrix
+  float dcam[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) { dview[k] = 0.f; dproj[k] = 0.f; }
+
+  // ---- (1) colour -> SH coefficients, view direction
+  if (g.shs) {
+    const unsigned long long vmask = __ballot(vis);
+    const int stride = sh_lds_stride(K);
+    float* lw = lds + wave * (64 * stride);
+    if (vmask) stage_sh_in(g.shs, wave_first, n_valid, K, vmask, lw);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float* sh = lw + lane * stride;
+    if (vis) {
+      const float vx = px - vc.cam[0], vy = py - vc.cam[1], vz = pz - vc.cam[2];
+      const float len = sqrtf((vx * vx + vy * vy) + vz * vz);
+      const float x = vx / len, y = vy / len, z = vz / len;
+      float b[16];
+      sh_basis(D, x, y, z, b);
+      const int nb = (D + 1) * (D + 1);
+      float gch[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float acc = b[0] * sh[c];
+        for (int k = 1; k < nb; ++k) acc = acc + b[k] * sh[3 * k + c];
+        acc = acc + 0.5f;
+        gch[c] = (acc < 0.0f) ? 0.0f : grgb[c];           // same clamp decision as K1 (same operator order)
+      }
+      float s[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s[k] = 0.f;
+      for (int k = 0; k < nb; ++k) {
+        s[k] = (sh[3 * k] * gch[0] + sh[3 * k + 1] * gch[1]) + sh[3 * k + 2] * gch[2];
+        sh[3 * k] = b[k] * gch[0]; sh[3 * k + 1] = b[k] * gch[1]; sh[3 * k + 2] = b[k] * gch[2];
+      }
+      for (int k = 3 * nb; k < 3 * K; ++k) sh[k] = 0.f;
+      float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+      if (D > 0) {
+        ddy += -GSR_SH_C1 * s[1]; ddz += GSR_SH_C1 * s[2]; ddx += -GSR_SH_C1 * s[3];
+        if (D > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          ddx += GSR_SH_C2_0 * y * s[4] + GSR_SH_C2_2 * (-2.0f * x) * s[6] + GSR_SH_C2_3 * z * s[7] + GSR_SH_C2_4 * 2.0f * x * s[8];
+          ddy += GSR_SH_C2_0 * x * s[4] + GSR_SH_C2_1 * z * s[5] + GSR_SH_C2_2 * (-2.0f * y) * s[6] + GSR_SH_C2_4 * (-2.0f * y) * s[8];
+          ddz += GSR_SH_C2_1 * y * s[5] + GSR_SH_C2_2 * 4.0f * z * s[6] + GSR_SH_C2_3 * x * s[7];
+          if (D > 2) {
+            ddx += GSR_SH_C3_0 * 6.0f * xy * s[9] + GSR_SH_C3_1 * yz * s[10] + GSR_SH_C3_2 * (-2.0f * xy) * s[11] +
+                   GSR_SH_C3_3 * (-6.0f * xz) * s[12] + GSR_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy) * s[13] +
+                   GSR_SH_C3_5 * 2.0f * xz * s[14] + GSR_SH_C3_6 * 3.0f * (xx - yy) * s[15];
+            ddy += GSR_SH_C3_0 * 3.0f * (xx - yy) * s[9] + GSR_SH_C3_1 * xz * s[10] +
+                   GSR_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy) * s[11] + GSR_SH_C3_3 * (-6.0f * yz) * s[12] +
+                   GSR_SH_C3_4 * (-2.0f * xy) * s[13] + GSR_SH_C3_5 * (-2.0f * yz) * s[14] + GSR_SH_C3_6 * (-6.0f * xy) * s[15];
+            ddz += GSR_SH_C3_1 * xy * s[10] + GSR_SH_C3_2 * 8.0f * yz * s[11] +
+                   GSR_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy) * s[12] + GSR_SH_C3_4 * 8.0f * xz * s[13] +
+                   GSR_SH_C3_5 * (xx - yy) * s[14];
+          }
+        }
+      }
+      const float dot = (x * ddx + y * ddy) + z * ddz;
+      const float dvx = (ddx - x * dot) / len, dvy = (ddy - y * dot) / len, dvz = (ddz - z * dot) / len;
+      dp[0] += dvx; dp[1] += dvy; dp[2] += dvz;
+      dcam[0] = -dvx; dcam[1] = -dvy; dcam[2] = -dvz;
+    } else if (lane < n_valid) {
+      for (int k = 0; k < 3 * K; ++k) sh[k] = 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (out.dL_dshs) stage_sh_out(out.dL_dshs, wave_first, n_valid, K, lw);
+  }
+
+  float dscale[3] = {0.f, 0.f, 0.f};
+  float drot[4] = {0.f, 0.f, 0.f, 0.f};
+  float dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (vis) {
+    float c6[6];
+    float R[9];
+    float s3[3] = {0.f, 0.f, 0.f};
+    float4 q = make_float4(1, 0, 0, 0);
+    if (g.cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c6[k] = g.cov3D_precomp[6 * i + k];
+    } else {
+      s3[0] = mod * g.scales[3 * i]; s3[1] = mod * g.scales[3 * i + 1]; s3[2] = mod * g.scales[3 * i + 2];
+      q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
+      quat_to_R(q, R);
+      cov3d_from(s3[0], s3[1], s3[2], R, c6);
+    }
+    Ewa e;
+    ewa_forward(vc, px, py, pz, c6, fx, fy, limx, limy, e);
+
+    // (2) conic -> cov2D (lineage denominator det^2 + 1e-7)
+    const float d2i = 1.0f / (e.det * e.det + 0.0000001f);
+    const float ca = e.ca, cb = e.cb, cc = e.cc;
+    const float dca = d2i * ((-cc * cc * gca + cb * cc * gcb) - cb * cb * gcc);
+    const float dcc = d2i * ((-cb * cb * gca + cb * ca * gcb) - ca * ca * gcc);
+    const float dcb = d2i * ((2.0f * cb * cc * gca - (e.det + 2.0f * cb * cb) * gcb) + 2.0f * cb * ca * gcc);
+    // (3) cov2D = M Sigma M^T
+    const float h = 0.5f * dcb;
+    float dS[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        dS[3 * r + c] = (e.M0[r] * (dca * e.M0[c] + h * e.M1[c])) + (e.M1[r] * (h * e.M0[c] + dcc * e.M1[c]));
+    float dM0[3], dM1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dM0[j] = 2.0f * (dca * e.U0[j] + h * e.U1[j]);
+      dM1[j] = 2.0f * (h * e.U0[j] + dcc * e.U1[j]);
+    }
+    const float dJ00 = (dM0[0] * V[0] + dM0[1] * V[4]) + dM0[2] * V[8];
+    const float dJ02 = (dM0[0] * V[2] + dM0[1] * V[6]) + dM0[2] * V[10];
+    const float dJ11 = (dM1[0] * V[1] + dM1[1] * V[5]) + dM1[2] * V[9];
+    const float dJ12 = (dM1[0] * V[2] + dM1[1] * V[6]) + dM1[2] * V[10];
+    const float tzi = 1.0f / e.tz, tz2 = tzi * tzi, tz3 = tz2 * tzi;
+    float dt[3];
+    dt[0] = e.clx ? 0.0f : (-fx * tz2 * dJ02);
+    dt[1] = e.cly ? 0.0f : (-fy * tz2 * dJ12);
+    dt[2] = ((-fx * tz2 * dJ00 - fy * tz2 * dJ11) + (2.0f * fx * e.txc) * tz3 * dJ02) + (2.0f * fy * e.tyc) * tz3 * dJ12;
+    dt[2] += gdep;                                                               // (5) depth
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dp[r] += (V[4 * r] * dt[0] + V[4 * r + 1] * dt[1]) + V[4 * r + 2] * dt[2];
+    // (4) ndc -> p
+    const float hx = ((PV[0] * px + PV[4] * py) + PV[8] * pz) + PV[12];
+    const float hy = ((PV[1] * px + PV[5] * py) + PV[9] * pz) + PV[13];
+    const float hw = ((PV[3] * px + PV[7] * py) + PV[11] * pz) + PV[15];
+    const float pw = 1.0f / (hw + 0.0000001f);
+    const float dh[3] = {pw * gndx, pw * gndy, -(pw * pw) * (hx * gndx + hy * gndy)};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dp[r] += (PV[4 * r] * dh[0] + PV[4 * r + 1] * dh[1]) + PV[4 * r + 3] * dh[2];
+
+    if (want_cam) {
+      const float p4[4] = {px, py, pz, 1.0f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dview[3 * r + c] = p4[r] * dt[c];
+        dproj[3 * r + 0] = p4[r] * dh[0];
+        dproj[3 * r + 1] = p4[r] * dh[1];
+        dproj[3 * r + 2] = p4[r] * dh[2];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        dview[3 * r + 0] += e.J00 * dM0[r];
+        dview[3 * r + 1] += e.J11 * dM1[r];
+        dview[3 * r + 2] += e.J02 * dM0[r] + e.J12 * dM1[r];
+      }
+    }
+
+    // (6) Sigma -> its parameters
+    if (g.cov3D_precomp) {
+      dc6[0] = dS[0]; dc6[1] = dS[1] + dS[3]; dc6[2] = dS[2] + dS[6];
+      dc6[3] = dS[4]; dc6[4] = dS[5] + dS[7]; dc6[5] = dS[8];
+    } else {
+      float L[9], dL[9], dR[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) L[3 * a + b2] = R[3 * a + b2] * s3[b2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) {
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc += (dS[3 * a + k] + dS[3 * k + a]) * L[3 * k + b2];
+          dL[3 * a + b2] = acc;
+        }
+#pragma unroll
+      for (int b2 = 0; b2 < 3; ++b2) {
+        const float ds = (dL[b2] * R[b2] + dL[3 + b2] * R[3 + b2]) + dL[6 + b2] * R[6 + b2];
+        dscale[b2] = mod * ds;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) dR[3 * a + b2] = dL[3 * a + b2] * s3[b2];
+      const float r = q.x, x = q.y, y = q.z, z = q.w;
+      drot[0] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+      drot[1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
+      drot[2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
+      drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    }
+  }
+
+  if (i < P) {
+    out.dL_dmeans3D[3 * i] = dp[0]; out.dL_dmeans3D[3 * i + 1] = dp[1]; out.dL_dmeans3D[3 * i + 2] = dp[2];
+    out.dL_dmeans2D[3 * i] = gndx; out.dL_dmeans2D[3 * i + 1] = gndy; out.dL_dmeans2D[3 * i + 2] = 0.f;
+    out.dL_dopacities[i] = gop;
+    if (out.dL_dcolors) { out.dL_dcolors[3 * i] = grgb[0]; out.dL_dcolors[3 * i + 1] = grgb[1]; out.dL_dcolors[3 * i + 2] = grgb[2]; }
+    if (out.dL_dscales) { out.dL_dscales[3 * i] = dscale[0]; out.dL_dscales[3 * i + 1] = dscale[1]; out.dL_dscales[3 * i + 2] = dscale[2]; }
+    if (out.dL_drotations) *reinterpret_cast<float4*>(out.dL_drotations + 4 * i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    if (out.dL_dcov3D) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) out.dL_dcov3D[6 * i + k] = dc6[k];
+    }
+  }
+
+  // ---- camera gradients: block reduction, one atomic per value per block
+  if (want_cam) {
+    float vals[27];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { vals[k] = dview[k]; vals[12 + k] = dproj[k]; }
+    vals[24] = dcam[0]; vals[25] = dcam[1]; vals[26] = dcam[2];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const float s = gsr_wave_sum_to_lane63(vals[k]);
+      if (lane == 63) cam_red[wave][k] = s;
+    }
+    __syncthreads();
+    if (tid < 27) {
+      const float s = (cam_red[0][tid] + cam_red[1][tid]) + (cam_red[2][tid] + cam_red[3][tid]);
+      if (tid < 12) {
+        if (out.dL_dview) unsafeAtomicAdd(out.dL_dview + 4 * (tid / 3) + (tid % 3), s);
+      } else if (tid < 24) {
+        const int k = tid - 12, r = k / 3, c = k % 3;
+        if (out.dL_dproj) unsafeAtomicAdd(out.dL_dproj + 4 * r + (c == 2 ? 3 : c), s);
+      } else {
+        if (out.dL_dcampos) unsafeAtomicAdd(out.dL_dcampos + (tid - 24), s);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+size_t gsr_preprocess_lds_bytes(int K) { return (size_t)4 * 64 * sh_lds_stride(K) * sizeof(float); }
+
+int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom, hipStream_t stream) {
+  const uint32_t nb = gsr_num_blocks(v.P);
+  const size_t lds = g.shs ? gsr_preprocess_lds_bytes(v.sh_stride) : 0;
+  hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(256), lds, stream, v, g, geom.splat, geom.radii,
+                     geom.tiles_touched, geom.block_offsets /* per-block sums, scanned in place next */);
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const GsrGeom& geom, const GsrGrads& out,
+                              hipStream_t stream) {
+  const uint32_t nb = gsr_num_blocks(v.P);
+  const size_t lds = g.shs ? gsr_preprocess_lds_bytes(v.sh_stride) : 0;
+  hipLaunchKernelGGL(k_preprocess_bwd, dim3(nb), dim3(256), lds, stream, v, g, geom.radii, out.partials, out);
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}

@@ -1,0 +1,235 @@
+"""Host-side mirror of the reference's rasterizer interface, bound to the HIP library through the C ABI.
+
+Same names, argument meaning and error behaviour as the package DreamScene imports
+(`from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer`,
+scene_gaussian.py:11-12):
+  * GaussianRasterizationSettings -- the 12 keyword fields of scene_gaussian.py:951-964 (with `score_flag`,
+    without upstream's `debug`);
+  * GaussianRasterizer(raster_settings=...)(means3D=, means2D=, shs=, colors_precomp=, opacities=, scales=,
+    rotations=, cov3D_precomp=) -> (image [3,H,W], radii [P] int32, depth_alpha [2,H,W]), with a leading
+    important_score [P] when raster_settings.score_flag (scene_gaussian.py:637, 1012);
+  * gradients flow through image AND depth_alpha (scene_gaussian.py:1023-1032) to means3D, means2D (the dummy
+    screen-space tensor, gs_renderer.py:1061-1065), opacities, shs / colors_precomp, scales, rotations /
+    cov3D_precomp.
+PyTorch is used for device memory, streams and autograd plumbing only; all arithmetic is in libgsrast.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _lib as L
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    score_flag: bool = False
+
+
+# important_score weight (the fork's exact definition is unpinned, SEMANTICS.md): 0 = opacity per contributing
+# (pixel, splat) pair [default, the LightGaussian global-significance hit term], 1 = alpha*T.
+SCORE_MODE = 0
+# optional GsrProfile handle (bench.py sets it to collect per-kernel HIP-event timings)
+PROFILE: Optional[L.Profile] = None
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _prep(t: Optional[torch.Tensor], name: str, dev: torch.device) -> Optional[torch.Tensor]:
+    """fp32, contiguous, on `dev`, 16-byte aligned base (what the ABI requires)."""
+    if t is None:
+        return None
+    if t.device != dev:
+        raise ValueError(f"{name} is on {t.device}, expected {dev}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _view_struct(s: GaussianRasterizationSettings, P: int, K: int, bg, vm, pm, cp) -> L.GsrView:
+    v = L.GsrView()
+    v.P, v.sh_stride, v.sh_degree = P, K, int(s.sh_degree)
+    v.image_height, v.image_width = int(s.image_height), int(s.image_width)
+    v.tanfovx, v.tanfovy, v.scale_modifier = float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier)
+    v.prefiltered, v.score_mode = int(bool(s.prefiltered)), int(SCORE_MODE)
+    v.bg, v.viewmatrix, v.projmatrix, v.campos = bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr()
+    return v
+
+
+class _State:
+    """Everything the backward needs; tensors are kept alive here (the C side owns nothing)."""
+    __slots__ = ("view", "gauss", "geom", "binning", "images", "keep", "P", "K", "N", "dev", "cam_grads")
+
+
+def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
+                          rotations, cov3D_precomp, want_keys: bool = False):
+    """Forward through the C ABI. Returns (outputs dict, _State). Used by the autograd Function and by tests."""
+    lib = L.load()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise L.GsrError("the HIP rasterizer needs tensors on a cuda (ROCm) device; there is no CPU fallback")
+    P = int(means3D.shape[0])
+    H, W = int(s.image_height), int(s.image_width)
+    means3D = _prep(means3D, "means3D", dev)
+    opacities = _prep(opacities, "opacities", dev)
+    shs, colors_precomp = _prep(shs, "shs", dev), _prep(colors_precomp, "colors_precomp", dev)
+    scales, rotations = _prep(scales, "scales", dev), _prep(rotations, "rotations", dev)
+    cov3D_precomp = _prep(cov3D_precomp, "cov3D_precomp", dev)
+    bg = _prep(s.bg.reshape(-1), "bg", dev)
+    vm = _prep(s.viewmatrix.reshape(-1), "viewmatrix", dev)
+    pm = _prep(s.projmatrix.reshape(-1), "projmatrix", dev)
+    cp = _prep(s.campos.reshape(-1), "campos", dev)
+    K = int(shs.shape[1]) if shs is not None else 0
+    if shs is not None and (shs.dim() != 3 or shs.shape[0] != P or shs.shape[2] != 3):
+        raise ValueError(f"shs must be [P,K,3], got {tuple(shs.shape)}")
+
+    st = _State()
+    st.P, st.K, st.dev = P, K, dev
+    st.view = _view_struct(s, P, K, bg, vm, pm, cp)
+    g = L.GsrGaussians()
+    g.means3D, g.opacities, g.shs, g.colors_precomp = _ptr(means3D), _ptr(opacities), _ptr(shs), _ptr(colors_precomp)
+    g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp)
+    st.gauss = g
+
+    i32, u8 = torch.int32, torch.uint8
+    nb = lib.gsr_num_blocks(P)
+    tiles = lib.gsr_num_tiles(H, W)
+    splat = torch.empty((max(P, 1), 12), dtype=torch.float32, device=dev)
+    radii = torch.empty(max(P, 1), dtype=i32, device=dev)
+    tiles_touched = torch.empty(max(P, 1), dtype=i32, device=dev)
+    block_offsets = torch.empty(nb + 4, dtype=i32, device=dev)
+    geom = L.GsrGeom()
+    geom.splat, geom.radii, geom.tiles_touched, geom.block_offsets = (splat.data_ptr(), radii.data_ptr(),
+                                                                      tiles_touched.data_ptr(), block_offsets.data_ptr())
+    st.geom = geom
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    prof = PROFILE.handle if PROFILE is not None else None
+    n_pairs = C.c_uint64(0)
+    with torch.cuda.device(dev):
+        L.check(lib.gsr_forward_project(C.byref(st.view), C.byref(g), C.byref(geom), C.byref(n_pairs), stream, prof),
+                "gsr_forward_project")
+        N = int(n_pairs.value)
+        st.N = N
+        point_list = torch.empty(max(N, 1), dtype=i32, device=dev)
+        ranges = torch.empty((tiles, 2), dtype=i32, device=dev)
+        scratch_bytes = int(lib.gsr_sort_scratch_bytes(N, tiles))
+        scratch = torch.empty(scratch_bytes, dtype=u8, device=dev)
+        keys_sorted = torch.empty(max(N, 1), dtype=torch.int64, device=dev) if want_keys else None
+        b = L.GsrBinning()
+        b.point_list, b.ranges, b.keys_sorted = point_list.data_ptr(), ranges.data_ptr(), _ptr(keys_sorted)
+        b.scratch, b.scratch_bytes = scratch.data_ptr(), scratch_bytes
+        st.binning = b
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        depth_alpha = torch.empty((2, H, W), dtype=torch.float32, device=dev)
+        final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
+        n_contrib = torch.empty((H, W), dtype=i32, device=dev)
+        score = torch.zeros(P, dtype=torch.float32, device=dev) if s.score_flag else None
+        im = L.GsrImages()
+        im.color, im.depth_alpha, im.final_T, im.n_contrib = (color.data_ptr(), depth_alpha.data_ptr(),
+                                                              final_T.data_ptr(), n_contrib.data_ptr())
+        im.important_score = _ptr(score)
+        st.images = im
+        L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), N, C.byref(b), C.byref(im), stream, prof),
+                "gsr_forward_render")
+    # sort scratch is dead after the forward; everything else is kept for backward
+    b.scratch, b.scratch_bytes = None, 0
+    st.keep = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, bg, vm, pm, cp, splat, radii,
+               tiles_touched, block_offsets, point_list, ranges, final_T, n_contrib)
+    out = dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, splat=splat[:P],
+               tiles_touched=tiles_touched[:P], point_list=point_list[:N], ranges=ranges, final_T=final_T,
+               n_contrib=n_contrib, keys_sorted=None if keys_sorted is None else keys_sorted[:N], N=N)
+    return out, st
+
+
+def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool = False) -> dict:
+    lib = L.load()
+    dev, P, K = st.dev, st.P, st.K
+    dL_dcolor = _prep(dL_dcolor, "dL_dcolor", dev)
+    dL_ddepth_alpha = _prep(dL_ddepth_alpha, "dL_ddepth_alpha", dev)
+    g = st.gauss
+    f32 = torch.float32
+    new = lambda *shape: torch.empty(shape, dtype=f32, device=dev)
+    o = dict(dL_dmeans3D=new(P, 3), dL_dmeans2D=new(P, 3), dL_dopacities=new(P, 1),
+             dL_dshs=new(P, K, 3) if g.shs else None, dL_dcolors=new(P, 3) if g.colors_precomp else None,
+             dL_dscales=new(P, 3) if g.scales else None, dL_drotations=new(P, 4) if g.rotations else None,
+             dL_dcov3D=new(P, 6) if g.cov3D_precomp else None,
+             dL_dview=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
+             dL_dproj=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
+             dL_dcampos=torch.zeros(3, dtype=f32, device=dev) if cam_grads else None)
+    partials = new(max(P, 1), 12)
+    gr = L.GsrGrads()
+    for k, t in o.items():
+        setattr(gr, k, _ptr(t))
+    gr.partials = partials.data_ptr()
+    ig = L.GsrImageGrads()
+    ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    prof = PROFILE.handle if PROFILE is not None else None
+    with torch.cuda.device(dev):
+        L.check(lib.gsr_backward(C.byref(st.view), C.byref(g), C.byref(st.geom), C.byref(st.binning),
+                                 C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
+    o["partials"] = partials
+    return o
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
+        out, st = rasterize_forward_raw(settings, means3D, opacities, shs, colors_precomp, scales, rotations,
+                                        cov3D_precomp)
+        ctx.st = st
+        ctx.opac_shape = opacities.shape
+        ctx.mark_non_differentiable(out["radii"])
+        if settings.score_flag:
+            ctx.mark_non_differentiable(out["score"])
+            return out["score"], out["color"], out["radii"], out["depth_alpha"]
+        return out["color"], out["radii"], out["depth_alpha"]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        st = ctx.st
+        if len(grads) == 4:
+            _, g_color, _, g_da = grads
+        else:
+            g_color, _, g_da = grads
+        H, W = st.view.image_height, st.view.image_width
+        if g_color is None:
+            g_color = torch.zeros((3, H, W), dtype=torch.float32, device=st.dev)
+        if g_da is None:
+            g_da = torch.zeros((2, H, W), dtype=torch.float32, device=st.dev)
+        o = rasterize_backward_raw(st, g_color, g_da)
+        return (o["dL_dmeans3D"], o["dL_dmeans2D"], o["dL_dshs"], o["dL_dcolors"],
+                o["dL_dopacities"].reshape(ctx.opac_shape), o["dL_dscales"], o["dL_drotations"], o["dL_dcov3D"], None)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                         cov3D_precomp, self.raster_settings)

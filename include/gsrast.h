@@ -1,0 +1,164 @@
+/* gsrast.h -- C ABI of libgsrast.so, the MI355X-native differentiable 3D Gaussian splatting rasterizer.
+ *
+ * This is the boundary a binding of the reference would target. The reference (DreamScene) reaches its
+ * rasterizer through the Python package `diff_gaussian_rasterization` (scene_gaussian.py:11-12), whose
+ * native half is `diff_gaussian_rasterization._C` (un-vendored CUDA, README.md:47-51). The entry points below
+ * replace that native half one for one:
+ *
+ *   gsr_forward_project + gsr_forward_render   <->  _C.rasterize_gaussians            (the forward the
+ *        autograd.Function behind GaussianRasterizer.forward calls; call sites scene_gaussian.py:637-646,
+ *        861-870, 1012-1021; outputs image / radii / depth_alpha [/ important_score], :637, :1012)
+ *   gsr_backward                               <->  _C.rasterize_gaussians_backward   (invoked by
+ *        loss.backward(), training/object_trainer.py:382, training/scene_trainer.py:881)
+ *   GsrView                                    <->  GaussianRasterizationSettings     (12 fields,
+ *        scene_gaussian.py:951-964)
+ *
+ * Rules of the boundary:
+ *   - plain C: POD structs of raw DEVICE pointers and sizes, no torch / C++ types;
+ *   - the caller owns every buffer (inputs, outputs, state saved for backward, scratch); the library
+ *     allocates nothing that outlives a call and keeps no mutable global state: re-entrant, any thread;
+ *   - all work is enqueued on the caller's stream (a hipStream_t passed as void*); the only host
+ *     synchronisation is inside gsr_forward_project (it returns the data-dependent pair count N);
+ *   - every entry point returns 0 or a negative GSR_E* code, never throws; gsr_strerror() explains;
+ *   - fp32 contiguous tensors only; layouts are those of the reference call sites, quoted per field.
+ */
+#ifndef GSRAST_H
+#define GSRAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_VERSION 1
+#define GSR_TILE 16 /* 16x16 pixel tiles */
+
+enum {
+  GSR_OK = 0,
+  GSR_EINVAL = -1,    /* bad shape / null pointer / unsupported SH degree            */
+  GSR_ECAPACITY = -2, /* pair count N does not fit the 32-bit list positions         */
+  GSR_EHIP = -3,      /* a HIP call failed; gsr_last_hip_error() has the hipError_t  */
+  GSR_ESCRATCH = -4   /* scratch buffer too small for this (P, N)                    */
+};
+
+/* Per-view configuration == GaussianRasterizationSettings (scene_gaussian.py:951-964). The four tensors
+ * stay on the device exactly as RCamera holds them (utils/cam_utils.py:196-210): row-vector convention,
+ * i.e. viewmatrix is the TRANSPOSED world-to-camera matrix, projmatrix = viewmatrix @ projection^T. */
+typedef struct GsrView {
+  int32_t P;            /* number of Gaussians                                                        */
+  int32_t sh_stride;    /* K: SH coefficients stored per Gaussian = (max_sh_degree+1)^2; 0 if no SHs   */
+  int32_t sh_degree;    /* D: active degree 0..3 (raster_settings.sh_degree)                           */
+  int32_t image_height, image_width;
+  float tanfovx, tanfovy, scale_modifier;
+  int32_t prefiltered;  /* accepted for API parity; no effect (frustum test always runs)               */
+  int32_t score_mode;   /* important_score weight: 0 = opacity per contributing (pixel,splat), 1 = alpha*T */
+  const float* bg;         /* device f32[3]  */
+  const float* viewmatrix; /* device f32[16] */
+  const float* projmatrix; /* device f32[16] */
+  const float* campos;     /* device f32[3]  */
+} GsrView;
+
+/* Inputs of GaussianRasterizer.forward (scene_gaussian.py:1012-1021). Exactly one of shs / colors_precomp and
+ * exactly one of (scales, rotations) / cov3D_precomp is non-NULL. */
+typedef struct GsrGaussians {
+  const float* means3D;        /* [P,3]                                            */
+  const float* opacities;      /* [P] (the reference passes [P,1])                  */
+  const float* shs;            /* [P,K,3] coefficient-major (gs_renderer.py:480-484) */
+  const float* colors_precomp; /* [P,3]                                            */
+  const float* scales;         /* [P,3] post-activation                            */
+  const float* rotations;      /* [P,4] (w,x,y,z), already normalised              */
+  const float* cov3D_precomp;  /* [P,6] [xx,xy,xz,yy,yz,zz] (gs_renderer.py:79-88)  */
+} GsrGaussians;
+
+/* Projected per-Gaussian state: written by gsr_forward_project, read by render and backward (save it).
+ * splat holds 12 floats per Gaussian as three float4 rows q0,q1,q2 (row-major [P][12]):
+ *   q0 = (x_pix, y_pix, conic_a, conic_b)   q1 = (conic_c, opacity, view_depth, r)   q2 = (g, b, 0, 0)
+ * Rows of culled Gaussians (radii == 0) are left unwritten. */
+typedef struct GsrGeom {
+  float* splat;            /* [P,12], 16-byte aligned */
+  int32_t* radii;          /* [P]  screen radius in pixels, 0 = culled (output `radii`)            */
+  uint32_t* tiles_touched; /* [P]  number of 16x16 tiles overlapped                               */
+  uint32_t* block_offsets; /* [gsr_num_blocks(P)+4], 8-byte aligned: exclusive scan of the per-256-Gaussian tile
+                              counts, entry [nb] = N (low 32 bits); the tail holds the 64-bit N on the device */
+} GsrGeom;
+
+/* Tile binning. point_list / ranges are saved for backward; the rest is scratch for the forward only. */
+typedef struct GsrBinning {
+  uint32_t* point_list; /* [N] Gaussian index per (tile, depth)-sorted pair                         */
+  uint32_t* ranges;     /* [tiles,2] (start,end) into point_list; (0,0) for an empty tile            */
+  uint64_t* keys_sorted;/* [N] optional: receives the sorted 64-bit keys (tile<<32 | depth bits); may be NULL */
+  void* scratch;        /* gsr_sort_scratch_bytes(N, tiles) bytes, 256-byte aligned                   */
+  size_t scratch_bytes;
+} GsrBinning;
+
+/* Per-pixel outputs (scene_gaussian.py:1012,1023) and the per-pixel state backward needs. */
+typedef struct GsrImages {
+  float* color;           /* [3,H,W]                                                         */
+  float* depth_alpha;     /* [2,H,W]: plane 0 = sum z_i a_i T_i, plane 1 = sum a_i T_i        */
+  float* final_T;         /* [H,W] transmittance after the last contributor                  */
+  uint32_t* n_contrib;    /* [H,W] 1-based list position of the last contributor             */
+  float* important_score; /* [P] zero-initialised by the caller, or NULL (score_flag False)   */
+} GsrImages;
+
+typedef struct GsrImageGrads {
+  const float* dL_dcolor;       /* [3,H,W] */
+  const float* dL_ddepth_alpha; /* [2,H,W] */
+} GsrImageGrads;
+
+/* Gradients w.r.t. the forward inputs. NULL = not wanted (must be NULL where the input was NULL).
+ * Every non-NULL output is fully overwritten (zeros for culled Gaussians). dL_dview / dL_dproj /
+ * dL_dcampos treat viewmatrix, projmatrix and campos as three independent inputs. */
+typedef struct GsrGrads {
+  float* dL_dmeans3D;   /* [P,3]                                                                     */
+  float* dL_dmeans2D;   /* [P,3] (d/d ndc_x, d/d ndc_y, 0): what lands in viewspace_points.grad     */
+  float* dL_dopacities; /* [P]                                                                       */
+  float* dL_dshs;       /* [P,K,3]                                                                   */
+  float* dL_dcolors;    /* [P,3]                                                                     */
+  float* dL_dscales;    /* [P,3]                                                                     */
+  float* dL_drotations; /* [P,4]                                                                     */
+  float* dL_dcov3D;     /* [P,6]                                                                     */
+  float* dL_dview;      /* [16] or NULL; zero-initialised by the caller                              */
+  float* dL_dproj;      /* [16] or NULL; zero-initialised by the caller                              */
+  float* dL_dcampos;    /* [3]  or NULL; zero-initialised by the caller                              */
+  float* partials;      /* scratch [P,12]: per-Gaussian screen-space gradient accumulators           */
+} GsrGrads;
+
+/* Optional per-stage timing with HIP events on the caller's stream (bench.py uses it for `roofline`). */
+enum {
+  GSR_STAGE_PREPROCESS = 0, GSR_STAGE_SCAN, GSR_STAGE_DUPLICATE, GSR_STAGE_SORT, GSR_STAGE_RANGES,
+  GSR_STAGE_RENDER_FWD, GSR_STAGE_RENDER_BWD, GSR_STAGE_PREPROCESS_BWD, GSR_STAGE_COUNT
+};
+typedef struct GsrProfile GsrProfile;
+GsrProfile* gsr_profile_create(void);
+void gsr_profile_destroy(GsrProfile*);
+/* Synchronises the recorded events and ADDS each stage's elapsed ms into ms[GSR_STAGE_COUNT] and the
+ * number of recordings into counts[]; then clears the recordings. */
+int gsr_profile_collect(GsrProfile*, double* ms, int64_t* counts);
+
+int gsr_version(void);
+const char* gsr_strerror(int code);
+int gsr_last_hip_error(void); /* thread-local hipError_t of the last GSR_EHIP on this thread */
+
+size_t gsr_sort_scratch_bytes(uint64_t n_pairs, uint32_t n_tiles);
+uint32_t gsr_num_tiles(int32_t image_height, int32_t image_width);
+uint32_t gsr_num_blocks(int32_t P); /* entries of GsrGeom.block_offsets minus one */
+
+/* K1 projection (cull, cov3D, EWA cov2D, conic, radius, tile rect, SH colour) + K2 scan of tile counts.
+ * Synchronises `stream` once and stores the pair count N in *n_pairs_host (ordinary host memory). */
+int gsr_forward_project(const GsrView*, const GsrGaussians*, GsrGeom*, uint64_t* n_pairs_host, void* stream,
+                        GsrProfile* prof);
+
+/* K3 key/value emission, K4 stable radix sort, K5 tile ranges, K6 front-to-back compositing. */
+int gsr_forward_render(const GsrView*, const GsrGeom*, uint64_t n_pairs, GsrBinning*, GsrImages*, void* stream,
+                       GsrProfile* prof);
+
+/* K7 reverse traversal of every pixel's blend list + K8 chain rule to the inputs. */
+int gsr_backward(const GsrView*, const GsrGaussians*, const GsrGeom*, const GsrBinning*, const GsrImages*,
+                 const GsrImageGrads*, GsrGrads*, void* stream, GsrProfile* prof);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRAST_H */

@@ -1,0 +1,199 @@
+"""-m gpu: HIP path (through the C ABI) vs the oracles on the same seeded inputs.
+
+Bars (BASELINE.json north_star): bit-exact for tile assignment / sort indices (radii, tiles_touched, N, sorted
+value list, sorted keys, tile ranges); <= 1e-5 (fp32, normalised by max(1, max|ref|)) on RGB / depth / alpha and
+on every gradient."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import err, oracle_view, settings_for, small_scene
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+def _to_dev(g):
+    return {k: torch.tensor(v, device=DEV) for k, v in g.items()}
+
+
+def _run_hip(g, cam, bg, D, score=False, want_keys=True, **over):
+    from dreamscene_amd import rasterizer as R
+    s = settings_for(cam, bg, D, DEV, score_flag=score)
+    t = _to_dev(g)
+    kw = dict(shs=t.get("shs"), colors_precomp=t.get("colors_precomp"), scales=t.get("scales"),
+              rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"))
+    out, st = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], kw["shs"], kw["colors_precomp"], kw["scales"],
+                                      kw["rotations"], kw["cov3D_precomp"], want_keys=want_keys)
+    torch.cuda.synchronize()
+    return out, st
+
+
+def _check_forward(out, f, P):
+    vis = f["radii"] > 0
+    assert np.array_equal(out["radii"].cpu().numpy(), f["radii"]), "radii not bit-exact"
+    assert np.array_equal(out["tiles_touched"].cpu().numpy().view(np.uint32), f["tiles_touched"]), "tiles_touched"
+    assert out["N"] == f["N"], "pair count"
+    assert np.array_equal(out["point_list"].cpu().numpy().view(np.uint32), f["point_list"]), "sorted value list"
+    if out["keys_sorted"] is not None:
+        assert np.array_equal(out["keys_sorted"].cpu().numpy().view(np.uint64), f["keys"]), "sorted keys"
+    assert np.array_equal(out["ranges"].cpu().numpy().view(np.uint32), f["ranges"]), "tile ranges"
+    sp = out["splat"].cpu().numpy()
+    # depth bits and pixel centres feed keys / rects: bit-exact
+    assert np.array_equal(sp[vis, 6].view(np.uint32), f["depth"][vis].view(np.uint32)), "depth bits"
+    assert np.array_equal(sp[vis, 0:2].view(np.uint32), f["xy"][vis].view(np.uint32)), "pixel centres"
+    assert err(sp[vis][:, [2, 3, 4, 5]], f["conic_opacity"][vis]) == 0.0, "conic/opacity"
+    assert err(sp[vis][:, [7, 8, 9]], f["rgb"][vis]) <= 1e-6, "SH colour"
+    e_img = err(out["color"].cpu().numpy(), f["image"])
+    e_da = err(out["depth_alpha"].cpu().numpy(), f["depth_alpha"])
+    scale_d = max(1.0, float(np.abs(f["depth_alpha"]).max()))
+    assert e_img <= TOL, f"image err {e_img}"
+    assert e_da <= TOL * scale_d, f"depth/alpha err {e_da}"
+    assert err(out["final_T"].cpu().numpy(), f["final_T"]) <= TOL
+    nc = out["n_contrib"].cpu().numpy().view(np.uint32)
+    assert (nc != f["n_contrib"]).mean() <= 1e-4, "n_contrib differs on more than 0.01% of pixels"
+
+
+@pytest.mark.parametrize("D,K", [(0, 16), (1, 4), (2, 9), (3, 16)])
+def test_forward_vs_c_oracle(built_lib, c_oracle, D, K):
+    g, cam = small_scene(P=2000, H=128, W=112, K=K, seed=10 + D)
+    bg = np.array([1.0, 0.4, 0.1], np.float32)
+    out, _ = _run_hip(g, cam, bg, D)
+    v = oracle_view(c_oracle, cam, 2000, K, D, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    _check_forward(out, f, 2000)
+
+
+def _grad_check(g, cam, bg, D, c_oracle, colors=False, cov=False, seed=0):
+    from dreamscene_amd import rasterizer as R, synth
+    P = g["means3D"].shape[0]
+    K = g["shs"].shape[1] if "shs" in g else 0
+    H, W = cam.image_height, cam.image_width
+    gi, gda = synth.upstream_grads(H, W, seed)
+    out, st = _run_hip(g, cam, bg, D, want_keys=False)
+    o = R.rasterize_backward_raw(st, torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV), cam_grads=True)
+    torch.cuda.synchronize()
+    v = oracle_view(c_oracle, cam, P, K, D, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g.get("shs"), colors_precomp=g.get("colors_precomp"),
+                         scales=g.get("scales"), rotations=g.get("rotations"), cov3D_precomp=g.get("cov3D_precomp"))
+    b = c_oracle.backward(v, f, gi, gda, g["means3D"], shs=g.get("shs"), scales=g.get("scales"),
+                          rotations=g.get("rotations"), cov3D_precomp=g.get("cov3D_precomp"), cam_grads=True)
+    pairs = [("dL_dmeans3D", "dL_dmeans3D"), ("dL_dmeans2D", "dL_dmeans2D"), ("dL_dopacities", "dL_dopacity"),
+             ("dL_dshs", "dL_dshs"), ("dL_dcolors", "dL_dcolors"), ("dL_dscales", "dL_dscales"),
+             ("dL_drotations", "dL_drotations"), ("dL_dcov3D", "dL_dcov3D"), ("dL_dview", "dL_dview"),
+             ("dL_dproj", "dL_dproj"), ("dL_dcampos", "dL_dcampos")]
+    report = {}
+    for hk, ok in pairs:
+        if o.get(hk) is None or b.get(ok) is None:
+            assert (o.get(hk) is None) == (b.get(ok) is None), hk
+            continue
+        a, r = o[hk].cpu().numpy().reshape(-1), np.asarray(b[ok]).reshape(-1)
+        scale = max(1.0, float(np.abs(r).max()))
+        e = err(a, r)
+        report[hk] = (e, float(np.abs(r).max()))
+        assert e <= TOL * scale, f"{hk}: max abs err {e} (max|ref| {np.abs(r).max()})"
+    return report
+
+
+@pytest.mark.parametrize("D", [0, 3])
+def test_backward_vs_c_oracle(built_lib, c_oracle, D):
+    g, cam = small_scene(P=1500, H=96, W=112, K=16, seed=20 + D)
+    _grad_check(g, cam, np.array([0.2, 0.7, 1.0], np.float32), D, c_oracle)
+
+
+def test_backward_colors_precomp_cov3d(built_lib, c_oracle):
+    g, cam = small_scene(P=800, H=80, W=80, K=16, seed=31)
+    v = oracle_view(c_oracle, cam, 800, 16, 0, np.zeros(3, np.float32))
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    g2 = dict(means3D=g["means3D"], opacities=g["opacities"], cov3D_precomp=f["cov3D"].copy(),
+              colors_precomp=np.random.default_rng(5).uniform(size=(800, 3)).astype(np.float32))
+    # cov3D of culled Gaussians is 0 in the oracle output: recompute them all on the host
+    from oracle import torch_oracle as TO
+    g2["cov3D_precomp"] = TO.cov3d_from_scale_rot(torch.tensor(g["scales"]), 1.0, torch.tensor(g["rotations"])).numpy()
+    _grad_check(g2, cam, np.array([0.0, 0.0, 0.0], np.float32), 0, c_oracle)
+
+
+def test_backward_vs_autograd_fp64(built_lib):
+    """Independent check: HIP gradients vs autograd of the vectorised torch oracle in float64."""
+    from dreamscene_amd import rasterizer as R, synth
+    from oracle import torch_oracle as TO
+    g, cam = small_scene(P=500, H=64, W=80, K=16, seed=41)
+    D, bg = 3, np.array([1.0, 1.0, 1.0], np.float32)
+    H, W = cam.image_height, cam.image_width
+    gi, gda = synth.upstream_grads(H, W, 7)
+    out, st = _run_hip(g, cam, bg, D, want_keys=False)
+    o = R.rasterize_backward_raw(st, torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV), cam_grads=True)
+    dt = torch.float64
+    t = {k: torch.tensor(v, dtype=dt, requires_grad=True) for k, v in g.items()}
+    m2d = torch.zeros(500, 3, dtype=dt, requires_grad=True)
+    vm = torch.tensor(cam.world_view_transform, dtype=dt, requires_grad=True)
+    pm = torch.tensor(cam.full_proj_transform, dtype=dt, requires_grad=True)
+    cp = torch.tensor(cam.camera_center, dtype=dt, requires_grad=True)
+    s = TO.Settings(H, W, cam.tanfovx, cam.tanfovy, torch.tensor(bg, dtype=dt), 1.0, vm, pm, D, cp, False, False)
+    img, radii, da = TO.rasterize(t["means3D"], m2d, t["opacities"], shs=t["shs"], scales=t["scales"],
+                                  rotations=t["rotations"], settings=s)
+    ((img * torch.tensor(gi, dtype=dt)).sum() + (da * torch.tensor(gda, dtype=dt)).sum()).backward()
+    assert err(out["color"].cpu().numpy(), img.detach().numpy()) <= TOL
+    ref = dict(dL_dmeans3D=t["means3D"].grad, dL_dmeans2D=m2d.grad, dL_dopacities=t["opacities"].grad,
+               dL_dshs=t["shs"].grad, dL_dscales=t["scales"].grad, dL_drotations=t["rotations"].grad,
+               dL_dview=vm.grad, dL_dproj=pm.grad, dL_dcampos=cp.grad)
+    for k, r in ref.items():
+        r = r.numpy().reshape(-1)
+        e = err(o[k].cpu().numpy().reshape(-1), r)
+        assert e <= TOL * max(1.0, float(np.abs(r).max())), f"{k}: {e}"
+
+
+def test_autograd_module_and_score(built_lib, c_oracle):
+    """The nn.Module / autograd path the reference calls (scene_gaussian.py:966-1021), incl. score_flag arity."""
+    from dreamscene_amd.rasterizer import GaussianRasterizer
+    g, cam = small_scene(P=700, H=64, W=64, K=16, seed=51)
+    bg = np.array([1.0, 1.0, 1.0], np.float32)
+    t = {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in g.items()}
+    m2d = torch.zeros(700, 3, device=DEV, requires_grad=True) + 0
+    m2d.retain_grad()
+    rast = GaussianRasterizer(raster_settings=settings_for(cam, bg, 3, DEV))
+    img, radii, da = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], colors_precomp=None,
+                          opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+    assert img.shape == (3, 64, 64) and da.shape == (2, 64, 64) and radii.dtype == torch.int32
+    (img.sum() + da.sum()).backward()
+    assert m2d.grad is not None and float(m2d.grad[:, 2].abs().max()) == 0.0
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        assert t[k].grad is not None and torch.isfinite(t[k].grad).all()
+    rast_s = GaussianRasterizer(raster_settings=settings_for(cam, bg, 3, DEV, score_flag=True))
+    with torch.no_grad():
+        sc, img2, radii2, da2 = rast_s(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
+                                       scales=t["scales"], rotations=t["rotations"])
+    assert torch.equal(img2, img.detach())
+    v = oracle_view(c_oracle, cam, 700, 16, 3, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
+                         score=True)
+    ref = f["important_score"]
+    assert err(sc.cpu().numpy(), ref) <= 1e-4 * max(1.0, float(ref.max()))
+    with pytest.raises(Exception):
+        rast(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+
+
+def test_edge_cases(built_lib, c_oracle):
+    """Zero scales (scene_gaussian.py:1008 clamps to 0), behind-camera / off-screen Gaussians, saturating alpha,
+    alpha < 1/255, ragged image size (not a multiple of 16), empty input."""
+    from dreamscene_amd import rasterizer as R
+    g, cam = small_scene(P=900, H=70, W=90, K=16, seed=61)
+    g["scales"][:50] = 0.0
+    g["means3D"][50:100] *= 40.0                 # far off-screen / behind
+    g["means3D"][100:120, :] = cam.camera_center + 0.05   # inside the near plane
+    g["opacities"][120:200] = 1.0                # saturates min(0.99, .)
+    g["opacities"][200:260] = 0.003              # below 1/255 everywhere
+    g["scales"][260:270] *= 50.0                 # huge footprints -> cooperative duplicate path
+    bg = np.array([0.3, 0.6, 0.9], np.float32)
+    out, st = _run_hip(g, cam, bg, 2)
+    v = oracle_view(c_oracle, cam, 900, 16, 2, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    _check_forward(out, f, 900)
+    _grad_check(g, cam, bg, 2, c_oracle)
+    # empty input
+    e = {k: v[:0] for k, v in g.items()}
+    out0, st0 = _run_hip(e, cam, bg, 2, want_keys=False)
+    assert out0["N"] == 0
+    assert err(out0["color"].cpu().numpy(), np.broadcast_to(bg[:, None, None], (3, 70, 90))) == 0.0

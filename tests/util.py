@@ -1,0 +1,43 @@
+"""Shared scene builders / comparison helpers for the parity tests."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from dreamscene_amd import synth
+from dreamscene_amd.camera import Camera
+
+
+def small_scene(P=600, H=96, W=80, K=16, seed=3, scale_mul=6.0, radius=3.0, cam_idx=1, init_opacity=False):
+    g = synth.g_object(P, seed=seed, K=K, init_opacity=init_opacity)
+    g["scales"] = (g["scales"] * scale_mul).astype(np.float32)
+    cam = synth.object_cameras(cam_idx + 1, H, W, radius=radius)[cam_idx]
+    return g, cam
+
+
+def settings_for(cam: Camera, bg, sh_degree, device, score_flag=False, scale_modifier=1.0, cls=None):
+    from dreamscene_amd.rasterizer import GaussianRasterizationSettings
+    cls = cls or GaussianRasterizationSettings
+    t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=device)
+    return cls(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+               bg=t(bg), scale_modifier=scale_modifier, viewmatrix=t(cam.world_view_transform),
+               projmatrix=t(cam.full_proj_transform), sh_degree=sh_degree, campos=t(cam.camera_center),
+               prefiltered=False, score_flag=score_flag)
+
+
+def oracle_view(CO, cam: Camera, P, K, D, bg, scale_modifier=1.0, score_mode=0):
+    return CO.make_view(P, K, D, cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, bg,
+                        cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
+                        scale_modifier=scale_modifier, score_mode=score_mode)
+
+
+def err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max()) if a.size else 0.0
+
+
+def tol_ok(a, ref, atol=1e-5, rtol=1e-5):
+    """|a-ref| <= atol * max(1, max|ref|)  (the 1e-5 fp32 bar of BASELINE.json, scale-normalised)"""
+    a, ref = np.asarray(a, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    scale = max(1.0, float(np.abs(ref).max()) if ref.size else 1.0)
+    return err(a, ref) <= atol * scale
