@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""bench.py -- fwd+bwd views/s of the MI355X-native Gaussian rasterizer on BASELINE.json's metric config.
+
+A "step" = one pass of the hot path over one view per GPU: GaussianRasterizer forward (K1-K6) + backward
+(K7-K8) from fixed upstream gradients on image and depth_alpha, through the same nn.Module / autograd boundary
+the reference calls (scene_gaussian.py:966-1021). With N GPUs every rank renders its own view of the same
+Gaussians and the parameter gradients are summed with one in-place RCCL all-reduce (weak scaling: per-GPU work
+is fixed). Inputs are synthetic (dreamscene_amd/synth.py), resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the dominant kernel
+(HIP events on the launch stream, via the library's GsrProfile) and `cpu_baseline` (scalar C oracle, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def algorithmic_bytes(stage: str, P: int, N: int, HW: int, K: int, D: int) -> float:
+    """Algorithmic HBM bytes of one launch of each stage (DESIGN.md 'bytes per unit')."""
+    S = 12 * (D + 1) ** 2
+    return {
+        "preprocess": P * (44 + S) + P * 48,
+        "scan": P * 4 / 256 * 2,
+        "duplicate": P * 20 + N * 12,
+        "sort": N * 24,                       # lower bound: one read + one write of (u64 key, u32 value)
+        "ranges": N * 8,
+        "render_fwd": N * 44 + HW * 28,
+        "render_bwd": N * 44 + HW * 28 + P * 40,
+        "preprocess_bwd": P * (44 + S + 40) + P * (44 + 12 * K + 12),
+    }[stage]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gaussians", type=int, default=500_000)
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--scene", choices=["object", "indoor"], default="object")
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from dreamscene_amd import _lib, multiview, rasterizer as R, synth
+    from dreamscene_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    _lib.load()   # fail loudly if the HIP library is missing: there is no fallback
+    H = W = args.res
+    if args.scene == "object":
+        K, D = 16, args.sh_degree
+        g = synth.g_object(args.gaussians, seed=0, K=K)
+        cams = synth.object_cameras(8, H, W)
+        workload = f"C3: G-object {args.gaussians} Gaussians (K=16, SH degree {D}), 1 orbit view/GPU @{W}x{H}, fwd+bwd"
+    else:
+        K, D = 4, 1
+        g = synth.g_indoor(seed=0, per_wall=max(1, args.gaussians // 5), K=K)
+        cams = synth.indoor_cameras(8, H, W)
+        workload = f"G-indoor {g['means3D'].shape[0]} Gaussians (K=4, SH degree 1), 1 in-room view/GPU @{W}x{H}, fwd+bwd"
+    P = g["means3D"].shape[0]
+    cam = cams[rank % len(cams)]
+    params = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items()}
+    gi_np, gda_np = synth.upstream_grads(H, W, seed=rank)
+    gi, gda = torch.tensor(gi_np, device=dev), torch.tensor(gda_np, device=dev)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=t([1.0, 1.0, 1.0]),
+        scale_modifier=1.0, viewmatrix=t(cam.world_view_transform), projmatrix=t(cam.full_proj_transform),
+        sh_degree=D, campos=t(cam.camera_center), prefiltered=False, score_flag=False)
+    rast = GaussianRasterizer(raster_settings=settings)
+    arena = multiview.GradArena(P, K, dev)
+    R.GRAD_ARENA = arena
+    leaves = [params[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+
+    def step():
+        means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+        img, radii, da = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
+                              opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"],
+                              cov3D_precomp=None)
+        grads = torch.autograd.grad([img, da], leaves + [means2D], [gi, gda])
+        multiview.allreduce_grads(arena)
+        return img, da, radii, grads
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    prof = None
+    if not args.no_roofline:
+        prof = _lib.Profile()
+        R.PROFILE = prof
+    for _ in range(args.warmup):
+        step()
+    sync()
+    stage_ms = {}
+    dominant = None
+    if prof is not None:
+        if args.warmup == 0:
+            step()
+            sync()
+        res = prof.collect()
+        stage_ms = {s: (ms / c if c else 0.0) for s, (ms, c) in res.items()}
+        dominant = max(stage_ms, key=stage_ms.get)
+        prof.reset()
+        prof.set_stages([dominant])      # timed region records only the dominant kernel's events
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    N_pairs = None
+    roofline = None
+    if prof is not None:
+        res = prof.collect()
+        ms, cnt = res[dominant]
+        R.PROFILE = None
+        # pair count of this rank's view (for the algorithmic byte count)
+        with torch.no_grad():
+            o, _ = R.rasterize_forward_raw(settings, params["means3D"], params["opacities"], params["shs"], None,
+                                           params["scales"], params["rotations"], None)
+        N_pairs = int(o["N"])
+        if cnt:
+            avg_s = ms / cnt * 1e-3
+            ab = algorithmic_bytes(dominant, P, N_pairs, H * W, K, D)
+            achieved = ab / avg_s / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(f"{args.scene}_{P}_{W}", {}).get(dominant)
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes": int(ab),
+                        "stage_us_warmup": {s: round(v * 1e3, 2) for s, v in stage_ms.items()}}
+
+    cpu_baseline = None
+    grad_err = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline, grad_err = cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, out)
+
+    if rank == 0:
+        views = world * args.steps
+        line = {
+            "metric": f"fwd+bwd views/s @{W}x{H}, {P} Gaussians",
+            "value": round(views / elapsed, 3),
+            "unit": "views/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "gaussians": P, "resolution": [H, W], "tile_pairs_N": N_pairs,
+                       "parallelism": f"1 view/GPU x {world}, grads summed by 1 RCCL all-reduce ({arena.nbytes()} B)"
+                       if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "max_grad_err_vs_oracle": grad_err,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out):
+    """Times the scalar C oracle (a CPU port of the same algorithm; the reference has no CPU path)
+    on ONE fwd+bwd view of the same workload, single thread, and reuses that run to report the HIP path's max
+    gradient error at the full benchmark size."""
+    from oracle import c_oracle as CO
+    CO.build()
+    P = g["means3D"].shape[0]
+    v = CO.make_view(P, K, D, H, W, cam.tanfovx, cam.tanfovy, [1.0, 1.0, 1.0], cam.world_view_transform,
+                     cam.full_proj_transform, cam.camera_center)
+    t0 = time.perf_counter()
+    f = CO.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    b = CO.backward(v, f, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    dt = time.perf_counter() - t0
+    img, da, radii, grads = hip_out
+    names = ["dL_dmeans3D", "dL_dshs", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]
+    worst = 0.0
+    for n, gt in zip(names, grads):
+        ref = np.asarray(b[n], dtype=np.float64).reshape(-1)
+        e = float(np.abs(gt.detach().cpu().numpy().astype(np.float64).reshape(-1) - ref).max())
+        worst = max(worst, e / max(1.0, float(np.abs(ref).max())))
+    img_err = float(np.abs(img.detach().cpu().numpy() - f["image"]).max())
+    base = {"value": round(1.0 / dt, 5), "unit": "views/s", "cores": 1, "kind": "port",
+            "sample": f"1 fwd+bwd view of the same workload ({P} Gaussians @{W}x{H}) through oracle/gsr_oracle.c, "
+                      f"single thread, {dt:.1f} s; host has {os.cpu_count()} cores"}
+    return base, {"grads_rel_to_max1": worst, "image_abs": img_err,
+                  "bit_exact_radii": bool(np.array_equal(radii.cpu().numpy(), f["radii"]))}
+
+
+if __name__ == "__main__":
+    main()

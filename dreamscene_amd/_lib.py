@@ -58,6 +58,7 @@ SYMBOLS = [
     ("gsr_num_blocks", C.c_uint32, [C.c_int32]),
     ("gsr_profile_create", C.c_void_p, []),
     ("gsr_profile_destroy", None, [C.c_void_p]),
+    ("gsr_profile_set_stage_mask", None, [C.c_void_p, C.c_uint32]),
     ("gsr_profile_collect", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("gsr_forward_project", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom),
                                       C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
@@ -80,6 +81,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libgsrast.so must share the HIP runtime torch has loaded (its device pointers and streams are
+    # only meaningful inside that runtime instance); dlopen resolves libamdhip64 to the already-loaded copy.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise GsrError(f"{LIB_PATH} is missing: build it with `python -m dreamscene_amd.build` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
@@ -111,6 +115,11 @@ class Profile:
         self.handle = self.lib.gsr_profile_create()
         self.ms = (C.c_double * len(STAGES))()
         self.counts = (C.c_int64 * len(STAGES))()
+
+    def set_stages(self, names=None):
+        """Record only the named stages (None = all)."""
+        mask = 0xFFFFFFFF if names is None else sum(1 << STAGES.index(n) for n in names)
+        self.lib.gsr_profile_set_stage_mask(self.handle, mask)
 
     def collect(self) -> dict:
         check(self.lib.gsr_profile_collect(self.handle, self.ms, self.counts), "gsr_profile_collect")

@@ -72,6 +72,10 @@ void gsr_profile_destroy(GsrProfile* p) {
   delete p;
 }
 
+void gsr_profile_set_stage_mask(GsrProfile* p, uint32_t mask) {
+  if (p) p->mask = mask;
+}
+
 int gsr_profile_collect(GsrProfile* p, double* ms, int64_t* counts) {
   if (!p || !ms || !counts) return GSR_EINVAL;
   for (int i = 0; i < p->n; ++i) {

@@ -132,21 +132,24 @@ k_radix_hist(const uint64_t* __restrict__ keys, uint64_t n, int shift, uint32_t 
   hist[(uint64_t)tid * nblk + blockIdx.x] = h[tid];
 }
 
-// Exclusive scan of hist[256 * nblk] (digit-major), single workgroup.
-__global__ void __launch_bounds__(1024) k_radix_scan(uint32_t* __restrict__ hist, uint32_t total) {
-  __shared__ uint32_t wave_tot[16];
+// Per-digit exclusive scan: workgroup d scans row d of hist[256][nblk] in place and writes the row total to
+// totals[d]. (The 256 totals are scanned by every scatter workgroup on the fly.)
+__global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblk,
+                                                    uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wave_tot[4];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* row = hist + (uint64_t)blockIdx.x * nblk;
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  constexpr uint32_t kPer = 8;
-  for (uint32_t base = 0; base < total; base += 1024 * kPer) {
+  constexpr uint32_t kPer = 4;
+  for (uint32_t base = 0; base < nblk; base += 256 * kPer) {
     uint32_t x[kPer];
     uint32_t s = 0;
     const uint32_t first = base + tid * kPer;
 #pragma unroll
     for (uint32_t k = 0; k < kPer; ++k) {
-      x[k] = (first + k < total) ? hist[first + k] : 0u;
+      x[k] = (first + k < nblk) ? row[first + k] : 0u;
       s += x[k];
     }
     uint32_t inc = s;
@@ -163,23 +166,40 @@ __global__ void __launch_bounds__(1024) k_radix_scan(uint32_t* __restrict__ hist
     uint32_t run = carry + woff + inc - s;
 #pragma unroll
     for (uint32_t k = 0; k < kPer; ++k) {
-      if (first + k < total) hist[first + k] = run;
+      if (first + k < nblk) row[first + k] = run;
       run += x[k];
     }
     __syncthreads();
-    if (tid == 1023) carry_s = carry + woff + inc;
+    if (tid == 255) carry_s = carry + woff + inc;
     __syncthreads();
   }
+  if (tid == 0) totals[blockIdx.x] = carry_s;
 }
 
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                 uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t n, int shift, uint32_t nblk,
-                const uint32_t* __restrict__ hist) {
+                const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
   __shared__ uint32_t wh[4][kRadix];   // running per-wave digit counters, then per-wave global bases
+  __shared__ uint32_t dbase[kRadix];   // exclusive scan of the 256 digit totals
+  __shared__ uint32_t wtot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
+  {
+    const uint32_t x = totals[tid];
+    uint32_t inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wtot[w];
+    dbase[tid] = woff + inc - x;
+  }
   __syncthreads();
   volatile uint32_t* mywh = wh[wave];
   uint64_t key[kSortItems];
@@ -217,7 +237,7 @@ k_radix_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict
   }
   __syncthreads();
   {
-    uint32_t run = hist[(uint64_t)tid * nblk + blockIdx.x];
+    uint32_t run = dbase[tid] + hist[(uint64_t)tid * nblk + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const uint32_t c = wh[w][tid];
@@ -262,7 +282,7 @@ static uint32_t sort_blocks(uint64_t n) { return (uint32_t)((n + kSortTile - 1) 
 extern "C" size_t gsr_sort_scratch_bytes(uint64_t n, uint32_t n_tiles) {
   (void)n_tiles;
   const uint64_t m = n ? n : 1;
-  return 2 * align256(m * 8) + align256(m * 4) + align256((size_t)kRadix * (sort_blocks(m) + 1) * 4) + 1024;
+  return 2 * align256(m * 8) + align256(m * 4) + align256((size_t)kRadix * sort_blocks(m) * 4) + align256(kRadix * 4) + 1024;
 }
 
 int gsr_sort_key_bits(uint32_t n_tiles) {
@@ -284,11 +304,13 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t n, GsrBin
   GSR_HIP(hipMemsetAsync(b.ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), stream));
   if (n == 0) return GSR_OK;
   if (b.scratch_bytes < gsr_sort_scratch_bytes(n, tiles) || !b.scratch) return GSR_ESCRATCH;
+  const uint32_t nblk_ = sort_blocks(n);
   char* base = (char*)b.scratch;
   uint64_t* keys_a = (uint64_t*)base; base += align256(n * 8);
   uint64_t* keys_b = (uint64_t*)base; base += align256(n * 8);
   uint32_t* vals_t = (uint32_t*)base; base += align256(n * 4);
-  uint32_t* hist = (uint32_t*)base;
+  uint32_t* hist = (uint32_t*)base; base += align256((size_t)kRadix * nblk_ * 4);
+  uint32_t* totals = (uint32_t*)base;
 
   const int bits = gsr_sort_key_bits(tiles);
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
@@ -309,8 +331,9 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t n, GsrBin
     for (int p = 0; p < passes; ++p) {
       const int shift = p * kRadixBits;
       hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(kSortThreads), 0, stream, ka, n, shift, nblk, hist);
-      hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, stream, hist, (uint32_t)kRadix * nblk);
-      hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb, n, shift, nblk, hist);
+      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals);
+      hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb, n, shift, nblk, hist,
+                         totals);
       uint64_t* tk = ka; ka = kb; kb = tk;
       uint32_t* tv = va; va = vb; vb = tv;
     }

@@ -30,6 +30,7 @@ struct GsrProfile {
   int stage[kMax];
   int n = 0;
   int created = 0;
+  uint32_t mask = 0xFFFFFFFFu;
 };
 
 // RAII-free stage bracket: records start/stop events on `stream` if profiling is on.
@@ -38,7 +39,7 @@ struct GsrStageTimer {
   hipStream_t s;
   int slot;
   GsrStageTimer(GsrProfile* prof, hipStream_t stream, int stage) : p(prof), s(stream), slot(-1) {
-    if (!p || p->n >= GsrProfile::kMax) return;
+    if (!p || p->n >= GsrProfile::kMax || !((p->mask >> stage) & 1u)) return;
     slot = p->n++;
     if (slot >= p->created) {
       (void)hipEventCreate(&p->ev[slot][0]);

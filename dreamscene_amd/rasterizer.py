@@ -43,6 +43,9 @@ class GaussianRasterizationSettings(NamedTuple):
 SCORE_MODE = 0
 # optional GsrProfile handle (bench.py sets it to collect per-kernel HIP-event timings)
 PROFILE: Optional[L.Profile] = None
+# optional multiview.GradArena: when set, the autograd backward writes the parameter gradients of the view
+# straight into the arena's flat buffer (zero-copy hand-off to the RCCL all-reduce) and returns views of it
+GRAD_ARENA = None
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -158,17 +161,26 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     return out, st
 
 
-def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool = False) -> dict:
+def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool = False, arena=None) -> dict:
     lib = L.load()
     dev, P, K = st.dev, st.P, st.K
     dL_dcolor = _prep(dL_dcolor, "dL_dcolor", dev)
     dL_ddepth_alpha = _prep(dL_ddepth_alpha, "dL_ddepth_alpha", dev)
     g = st.gauss
     f32 = torch.float32
-    new = lambda *shape: torch.empty(shape, dtype=f32, device=dev)
-    o = dict(dL_dmeans3D=new(P, 3), dL_dmeans2D=new(P, 3), dL_dopacities=new(P, 1),
-             dL_dshs=new(P, K, 3) if g.shs else None, dL_dcolors=new(P, 3) if g.colors_precomp else None,
-             dL_dscales=new(P, 3) if g.scales else None, dL_drotations=new(P, 4) if g.rotations else None,
+    av = {}
+    if arena is not None:
+        if arena.P != P or (g.shs and arena.K != K) or arena.flat.device != dev:
+            raise ValueError("GradArena does not match this view's (P, K, device)")
+        av = arena.views
+
+    def new(*shape, name=None):
+        t = av.get(name)
+        return t if t is not None else torch.empty(shape, dtype=f32, device=dev)
+    o = dict(dL_dmeans3D=new(P, 3, name="means3D"), dL_dmeans2D=new(P, 3), dL_dopacities=new(P, 1, name="opacities"),
+             dL_dshs=new(P, K, 3, name="shs") if g.shs else None, dL_dcolors=new(P, 3) if g.colors_precomp else None,
+             dL_dscales=new(P, 3, name="scales") if g.scales else None,
+             dL_drotations=new(P, 4, name="rotations") if g.rotations else None,
              dL_dcov3D=new(P, 6) if g.cov3D_precomp else None,
              dL_dview=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
              dL_dproj=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
@@ -214,7 +226,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_color = torch.zeros((3, H, W), dtype=torch.float32, device=st.dev)
         if g_da is None:
             g_da = torch.zeros((2, H, W), dtype=torch.float32, device=st.dev)
-        o = rasterize_backward_raw(st, g_color, g_da)
+        o = rasterize_backward_raw(st, g_color, g_da, arena=GRAD_ARENA)
         return (o["dL_dmeans3D"], o["dL_dmeans2D"], o["dL_dshs"], o["dL_dcolors"],
                 o["dL_dopacities"].reshape(ctx.opac_shape), o["dL_dscales"], o["dL_drotations"], o["dL_dcov3D"], None)
 

@@ -133,6 +133,8 @@ enum {
 typedef struct GsrProfile GsrProfile;
 GsrProfile* gsr_profile_create(void);
 void gsr_profile_destroy(GsrProfile*);
+/* Record only the stages whose bit (1u << GSR_STAGE_*) is set; default all. */
+void gsr_profile_set_stage_mask(GsrProfile*, uint32_t mask);
 /* Synchronises the recorded events and ADDS each stage's elapsed ms into ms[GSR_STAGE_COUNT] and the
  * number of recordings into counts[]; then clears the recordings. */
 int gsr_profile_collect(GsrProfile*, double* ms, int64_t* counts);

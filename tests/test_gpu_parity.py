@@ -197,3 +197,41 @@ def test_edge_cases(built_lib, c_oracle):
     out0, st0 = _run_hip(e, cam, bg, 2, want_keys=False)
     assert out0["N"] == 0
     assert err(out0["color"].cpu().numpy(), np.broadcast_to(bg[:, None, None], (3, 70, 90))) == 0.0
+
+
+def test_long_lists_multi_batch(built_lib, c_oracle):
+    """Per-tile lists of thousands of entries (many 256-splat staging rounds), early termination inside deep
+    lists, and the backward starting from the tile's max contributor. Integer artefacts stay bit-exact; float
+    outputs within 1e-5 except for the rare pixels where a hard gate (alpha < 1/255, T < 1e-4) falls on the other
+    side of a rounding difference -- counted and bounded here, explained in DESIGN.md 'gates'."""
+    from dreamscene_amd import rasterizer as R, synth
+    P, H, W, K, D = 60000, 192, 192, 16, 3
+    g = synth.g_object(P, seed=77, K=K)
+    g["scales"] = (g["scales"] * 1.5).astype(np.float32)
+    cam = synth.object_cameras(3, H, W, radius=3.2)[2]
+    bg = np.array([1.0, 1.0, 1.0], np.float32)
+    out, st = _run_hip(g, cam, bg, D)
+    v = oracle_view(c_oracle, cam, P, K, D, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    assert f["N"] > 300000 and (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 2000
+    assert np.array_equal(out["radii"].cpu().numpy(), f["radii"])
+    assert np.array_equal(out["point_list"].cpu().numpy().view(np.uint32), f["point_list"])
+    assert np.array_equal(out["keys_sorted"].cpu().numpy().view(np.uint64), f["keys"])
+    assert np.array_equal(out["ranges"].cpu().numpy().view(np.uint32), f["ranges"])
+    d_img = np.abs(out["color"].cpu().numpy() - f["image"]).max(axis=0)
+    flips = (out["n_contrib"].cpu().numpy().view(np.uint32) != f["n_contrib"])
+    bad = d_img > TOL
+    print(f"pixels over 1e-5: {bad.sum()} of {bad.size}; n_contrib differs at {flips.sum()}; max err {d_img.max():.3e}")
+    assert bad.mean() <= 2e-4, "more than 0.02% of pixels exceed 1e-5"
+    assert d_img.max() <= 5e-3      # a flipped gate moves a pixel by at most ~alpha_min * T * |c - behind|
+    gi, gda = synth.upstream_grads(H, W, 3)
+    o = R.rasterize_backward_raw(st, torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV))
+    b = c_oracle.backward(v, f, gi, gda, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    for hk, ok in [("dL_dmeans3D", "dL_dmeans3D"), ("dL_dmeans2D", "dL_dmeans2D"), ("dL_dopacities", "dL_dopacity"),
+                   ("dL_dshs", "dL_dshs"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations")]:
+        a, r = o[hk].cpu().numpy().reshape(-1), np.asarray(b[ok]).reshape(-1)
+        e = np.abs(a - r)
+        scale = max(1.0, float(np.abs(r).max()))
+        frac = float((e > TOL * scale).mean())
+        print(f"{hk}: max err {e.max():.3e} (max|ref| {np.abs(r).max():.3e}), frac over tol {frac:.2e}")
+        assert frac <= 2e-4 and e.max() <= 1e-3 * scale
