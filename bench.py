@@ -124,7 +124,8 @@ def main():
             step()
             sync()
         res = prof.collect()
-        stage_ms = {s: (ms / c if c else 0.0) for s, (ms, c) in res.items()}
+        n_fwd = max(1, res["render_fwd"][1])          # stages recorded several times per view are summed per view
+        stage_ms = {s: ms / n_fwd for s, (ms, c) in res.items()}
         dominant = max(stage_ms, key=stage_ms.get)
         prof.reset()
         prof.set_stages([dominant])      # timed region records only the dominant kernel's events
@@ -152,6 +153,7 @@ def main():
                                            params["scales"], params["rotations"], None)
         N_pairs = int(o["N"])
         if cnt:
+            cnt = args.steps                          # per view (a stage may launch several kernels per view)
             avg_s = ms / cnt * 1e-3
             ab = algorithmic_bytes(dominant, P, N_pairs, H * W, K, D)
             achieved = ab / avg_s / 1e9

@@ -27,11 +27,13 @@ class GsrGaussians(C.Structure):
 
 
 class GsrGeom(C.Structure):
-    _fields_ = [("splat", _f), ("radii", _f), ("tiles_touched", _f), ("block_offsets", _f)]
+    _fields_ = [("splat", _f), ("radii", _f), ("tiles_touched", _f), ("block_offsets", _f), ("scratch", _f),
+                ("scratch_bytes", C.c_size_t), ("sorted_idx", _f)]
 
 
 class GsrBinning(C.Structure):
-    _fields_ = [("point_list", _f), ("ranges", _f), ("keys_sorted", _f), ("scratch", _f), ("scratch_bytes", C.c_size_t)]
+    _fields_ = [("point_list", _f), ("ranges", _f), ("keys_sorted", _f), ("scratch", _f), ("scratch_bytes", C.c_size_t),
+                ("count_on_device", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class GsrImages(C.Structure):
@@ -53,6 +55,7 @@ SYMBOLS = [
     ("gsr_version", C.c_int, []),
     ("gsr_strerror", C.c_char_p, [C.c_int]),
     ("gsr_last_hip_error", C.c_int, []),
+    ("gsr_project_scratch_bytes", C.c_size_t, [C.c_int32]),
     ("gsr_sort_scratch_bytes", C.c_size_t, [C.c_uint64, C.c_uint32]),
     ("gsr_num_tiles", C.c_uint32, [C.c_int32, C.c_int32]),
     ("gsr_num_blocks", C.c_uint32, [C.c_int32]),
@@ -62,6 +65,8 @@ SYMBOLS = [
     ("gsr_profile_collect", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("gsr_forward_project", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom),
                                       C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
+    ("gsr_forward_project_async", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom),
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gsr_forward_render", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGeom), C.c_uint64, C.POINTER(GsrBinning),
                                      C.POINTER(GsrImages), C.c_void_p, C.c_void_p]),
     ("gsr_backward", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom), C.POINTER(GsrBinning),

@@ -6,8 +6,9 @@ thread_local int gsr_tls_hip_error = 0;
 // stage launchers (preprocess.hip, binning.hip, render.hip)
 int gsr_launch_preprocess(const GsrView&, const GsrGaussians&, GsrGeom&, hipStream_t);
 int gsr_launch_preprocess_bwd(const GsrView&, const GsrGaussians&, const GsrGeom&, const GsrGrads&, hipStream_t);
-int gsr_launch_scan(GsrGeom&, int32_t P, uint64_t* n_pairs_dev, hipStream_t);
-int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t n, GsrBinning&, hipStream_t, GsrProfile*);
+int gsr_launch_depth_order(GsrGeom&, int32_t P, uint64_t* n_pairs_dev, hipStream_t, GsrProfile*);
+int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint64_t* n_dev, GsrBinning&, hipStream_t,
+                       GsrProfile*);
 int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, GsrImages&, hipStream_t);
 int gsr_launch_render_bwd(const GsrView&, const GsrGeom&, const GsrBinning&, const GsrImages&, const GsrImageGrads&,
                           GsrGrads&, hipStream_t);
@@ -89,8 +90,14 @@ int gsr_profile_collect(GsrProfile* p, double* ms, int64_t* counts) {
   return GSR_OK;
 }
 
-int gsr_forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geom, uint64_t* n_pairs_host, void* stream_,
-                        GsrProfile* prof) {
+static uint64_t* n_pairs_device(const GsrGeom* geom, int32_t P) {
+  // the device-side u64 total lives right after the u32 offsets (block_offsets has nb+1 entries + 3 spare)
+  const uint32_t nb = gsr_num_blocks(P);
+  return reinterpret_cast<uint64_t*>(geom->block_offsets + ((nb + 1 + 1) & ~1u));
+}
+
+static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geom, uint64_t* n_pairs_host,
+                           void* stream_, GsrProfile* prof, bool sync) {
   int rc = check_view(v);
   if (rc) return rc;
   rc = check_gaussians(v, g);
@@ -98,26 +105,34 @@ int gsr_forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geom, 
   if (!geom || !n_pairs_host) return GSR_EINVAL;
   *n_pairs_host = 0;
   if (v->P == 0) return GSR_OK;
-  if (!geom->splat || !geom->radii || !geom->tiles_touched || !geom->block_offsets) return GSR_EINVAL;
+  if (!geom->splat || !geom->radii || !geom->tiles_touched || !geom->block_offsets || !geom->scratch) return GSR_EINVAL;
   if (!aligned16(geom->splat)) return GSR_EINVAL;
+  if (geom->scratch_bytes < gsr_project_scratch_bytes(v->P)) return GSR_ESCRATCH;
   hipStream_t stream = (hipStream_t)stream_;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS);
     rc = gsr_launch_preprocess(*v, *g, *geom, stream);
     if (rc) return rc;
   }
-  // the device-side u64 total lives right after the u32 offsets (block_offsets has nb+1 entries + 2 spare)
-  const uint32_t nb = gsr_num_blocks(v->P);
-  uint64_t* n_dev = reinterpret_cast<uint64_t*>(geom->block_offsets + ((nb + 1 + 1) & ~1u));
-  {
-    GsrStageTimer t(prof, stream, GSR_STAGE_SCAN);
-    rc = gsr_launch_scan(*geom, v->P, n_dev, stream);
-    if (rc) return rc;
-  }
+  uint64_t* n_dev = n_pairs_device(geom, v->P);
+  rc = gsr_launch_depth_order(*geom, v->P, n_dev, stream, prof);
+  if (rc) return rc;
   GSR_HIP(hipMemcpyAsync(n_pairs_host, n_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-  GSR_HIP(hipStreamSynchronize(stream));
-  if (*n_pairs_host >= (1ull << 32)) return GSR_ECAPACITY;
+  if (sync) {
+    GSR_HIP(hipStreamSynchronize(stream));
+    if (*n_pairs_host >= (1ull << 32)) return GSR_ECAPACITY;
+  }
   return GSR_OK;
+}
+
+int gsr_forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geom, uint64_t* n_pairs_host, void* stream_,
+                        GsrProfile* prof) {
+  return forward_project(v, g, geom, n_pairs_host, stream_, prof, true);
+}
+
+int gsr_forward_project_async(const GsrView* v, const GsrGaussians* g, GsrGeom* geom, uint64_t* n_pairs_pinned,
+                              void* stream_, GsrProfile* prof) {
+  return forward_project(v, g, geom, n_pairs_pinned, stream_, prof, false);
 }
 
 int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, GsrBinning* b, GsrImages* img,
@@ -129,7 +144,9 @@ int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, 
   if (n_pairs && (!b->point_list || !geom->splat)) return GSR_EINVAL;
   if (n_pairs >= (1ull << 32)) return GSR_ECAPACITY;
   hipStream_t stream = (hipStream_t)stream_;
-  rc = gsr_launch_binning(*v, *geom, n_pairs, *b, stream, prof);
+  if (v->P == 0) n_pairs = 0;
+  const uint64_t* n_dev = (b->count_on_device && v->P > 0) ? n_pairs_device(geom, v->P) : nullptr;
+  rc = gsr_launch_binning(*v, *geom, n_pairs, n_dev, *b, stream, prof);
   if (rc) return rc;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_RENDER_FWD);

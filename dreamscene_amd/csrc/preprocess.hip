@@ -183,9 +183,8 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64
 // --------------------------------------------------------------------------------------------------------- K1
 __global__ void __launch_bounds__(256)
 k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, int32_t* __restrict__ radii,
-             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums) {
+             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_keys) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ uint32_t wave_tiles[4];
   const int P = v.P, W = v.image_width, H = v.image_height, K = v.sh_stride;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t i = (int64_t)blockIdx.x * 256 + tid;
@@ -200,7 +199,7 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
 
   bool vis = false;
   float px = 0, py = 0, pz = 0;
-  float q0x = 0, q0y = 0, ca_ = 0, cb_ = 0, cc_ = 0, depth = 0, opac = 0;
+  float q0x = 0, q0y = 0, ca_ = 0, cb_ = 0, cc_ = 0, depth = 0, opac = 0, ext_x = -1.f, ext_y = -1.f;
   int32_t radius = 0;
   uint32_t ntiles = 0;
   if (i < P) {
@@ -246,6 +245,14 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
           ca_ = e.cc * inv; cb_ = -e.cb * inv; cc_ = e.ca * inv;
           depth = e.tz;
           opac = g.opacities[i];
+          // Conservative screen extents of the region where this splat can pass the alpha >= 1/255 gate:
+          // d^T Conic d <= 2 ln(255 sigma)  =>  |dx| <= sqrt(tau * cov_xx). Used only to skip work that cannot
+          // contribute (render.hip); negative = contributes nowhere. Not part of any parity artefact.
+          if (opac * 255.0f > 1.0f) {
+            const float tau = 2.0f * logf(opac * 255.0f) * 1.0001f;
+            ext_x = sqrtf(tau * e.ca) * 1.0001f + 0.02f;
+            ext_y = sqrtf(tau * e.cc) * 1.0001f + 0.02f;
+          }
         } else {
           radius = 0;
         }
@@ -286,21 +293,15 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
   if (i < P) {
     radii[i] = radius;
     tiles_touched[i] = ntiles;
+    depth_keys[i] = vis ? __float_as_uint(depth) : 0xFFFFFFFFu;   // culled Gaussians sort to the end
     if (vis) {
       float4* o = reinterpret_cast<float4*>(splat + 12 * i);
       o[0] = make_float4(q0x, q0y, ca_, cb_);
       o[1] = make_float4(cc_, opac, depth, rgb[0]);
-      o[2] = make_float4(rgb[1], rgb[2], 0.f, 0.f);
+      o[2] = make_float4(rgb[1], rgb[2], ext_x, ext_y);
     }
   }
 
-  // ---- per-block tile count (feeds the scan)
-  uint32_t s = ntiles;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
-  if (lane == 0) wave_tiles[wave] = s;
-  __syncthreads();
-  if (tid == 0) block_sums[blockIdx.x] = (wave_tiles[0] + wave_tiles[1]) + (wave_tiles[2] + wave_tiles[3]);
 }
 
 // --------------------------------------------------------------------------------------------------------- K8
@@ -565,13 +566,15 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
 
 }  // namespace
 
+uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P);   // binning.hip: first key buffer of the depth sort
+
 size_t gsr_preprocess_lds_bytes(int K) { return (size_t)4 * 64 * sh_lds_stride(K) * sizeof(float); }
 
 int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom, hipStream_t stream) {
   const uint32_t nb = gsr_num_blocks(v.P);
   const size_t lds = g.shs ? gsr_preprocess_lds_bytes(v.sh_stride) : 0;
   hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(256), lds, stream, v, g, geom.splat, geom.radii,
-                     geom.tiles_touched, geom.block_offsets /* per-block sums, scanned in place next */);
+                     geom.tiles_touched, gsr_depth_keys(geom, v.P));
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }

@@ -1,9 +1,18 @@
 // render.hip -- K6 front-to-back alpha compositing and K7 its reverse-order backward, gfx950 (wave64).
 //
-// One 256-thread workgroup per 16x16 pixel tile; each of the 4 waves owns an 8x8 pixel block so that the
-// wave-level early-outs (whole wave finished / no lane of the wave touched by this splat) follow the screen
-// footprint of a splat as tightly as a 64-wide wave allows. Splat records (3 x float4, written by K1) are
-// gathered by list index into LDS 256 at a time and then read back as wave-uniform broadcasts.
+// One 256-thread workgroup per 16x16 pixel tile; each of the 4 waves owns an 8x8 pixel block.
+//  * Splat records (3 x float4, written by K1) are gathered by list index 256 at a time into a double-buffered
+//    LDS stage: the gather of batch b+1 is issued before batch b is consumed, so its L2/HBM latency is hidden
+//    behind compute, with ONE workgroup barrier per batch.
+//  * At staging time every thread classifies "its" splat against the four 8x8 blocks using the conservative
+//    extents K1 stored (region where alpha can reach 1/255). Each wave turns that into a 64-bit ballot per 64
+//    staged splats and then walks only the set bits with scalar code: splats that cannot touch the wave's pixels
+//    cost no vector instructions at all. The exact per-pixel gates of the rasterizer (power > 0, alpha < 1/255,
+//    T < 1e-4) are still evaluated unchanged on the survivors, so results are identical to the plain traversal.
+//  * K7 reduces the 10 per-splat gradient components over the wave's 64 pixels with a transposed butterfly
+//    (v_permlane32_swap / v_permlane16_swap halve the register count while crossing lane halves / rows, DPP
+//    row rotations finish inside the 16-lane rows): 28 VALU ops instead of 60, and the 10 sums land in 10
+//    different lanes so that ONE global_atomic_add_f32 instruction commits all of them.
 // Semantics: SURVEY.md Appendix A.2 / A.3, SEMANTICS.md; outputs as consumed at scene_gaussian.py:1012-1032.
 #include "gsr_common.h"
 
@@ -24,7 +33,7 @@ __device__ __forceinline__ float gsr_exp(float x) {
 }
 
 struct TilePix {
-  int px, py;
+  int px, py, bx, by;   // pixel, and origin of the wave's 8x8 block
   bool inside;
 };
 
@@ -32,11 +41,31 @@ __device__ __forceinline__ TilePix tile_pixel(int tile, int gx, int W, int H) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int ty = tile / gx, tx = tile - ty * gx;
   TilePix p;
-  p.px = tx * GSR_TILE + (wave & 1) * 8 + (lane & 7);
-  p.py = ty * GSR_TILE + (wave >> 1) * 8 + (lane >> 3);
+  p.bx = tx * GSR_TILE + (wave & 1) * 8;
+  p.by = ty * GSR_TILE + (wave >> 1) * 8;
+  p.px = p.bx + (lane & 7);
+  p.py = p.by + (lane >> 3);
   p.inside = (p.px < W) && (p.py < H);
   return p;
 }
+
+// 4-bit mask: which of the tile's four 8x8 blocks (bit = wave index) the splat's gate region can touch.
+__device__ __forceinline__ uint32_t block_mask(const float4 q0, const float4 q2, int tile_x0, int tile_y0) {
+  const float ex = q2.z, ey = q2.w;
+  if (!(ex >= 0.f)) return 0u;
+  const float x0 = (float)tile_x0, y0 = (float)tile_y0;
+  const bool xl = (q0.x - ex <= x0 + 7.f) && (q0.x + ex >= x0);
+  const bool xr = (q0.x - ex <= x0 + 15.f) && (q0.x + ex >= x0 + 8.f);
+  const bool yt = (q0.y - ey <= y0 + 7.f) && (q0.y + ey >= y0);
+  const bool yb = (q0.y - ey <= y0 + 15.f) && (q0.y + ey >= y0 + 8.f);
+  return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
+}
+
+struct Stage {
+  float4 s0[2][kBatch], s1[2][kBatch], s2[2][kBatch];
+  uint32_t sid[2][kBatch];
+  uint32_t smask[2][kBatch];
+};
 
 // --------------------------------------------------------------------------------------------------------- K6
 template <bool SCORE>
@@ -45,12 +74,12 @@ k_render_fwd(const int W, const int H, const uint32_t* __restrict__ ranges, cons
              const float4* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ out_color,
              float* __restrict__ out_da, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              float* __restrict__ score, const int score_mode) {
-  __shared__ float4 s0[kBatch], s1[kBatch], s2[kBatch];
-  __shared__ uint32_t sid[kBatch];
+  __shared__ Stage st;
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tile = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const TilePix p = tile_pixel(tile, gx, W, H);
+  const int tile_x0 = p.bx - (wave & 1) * 8, tile_y0 = p.by - (wave >> 1) * 8;
   const float pxf = (float)p.px, pyf = (float)p.py;
   const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
 
@@ -58,49 +87,66 @@ k_render_fwd(const int W, const int H, const uint32_t* __restrict__ ranges, cons
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
   uint32_t last = 0;
 
-  for (uint32_t base = r0; base < r1; base += kBatch) {
-    if (__syncthreads_count(done) == 256) break;
-    const uint32_t idx = base + tid;
-    if (idx < r1) {
-      const uint32_t id = point_list[idx];
-      const float4* r = splat + 3 * (size_t)id;
-      s0[tid] = r[0]; s1[tid] = r[1]; s2[tid] = r[2];
-      if (SCORE) sid[tid] = id;
-    }
-    __syncthreads();
+  // prefetch registers for the next batch
+  uint32_t nid = 0;
+  float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+  if (r0 + tid < r1) {
+    nid = point_list[r0 + tid];
+    const float4* r = splat + 3 * (size_t)nid;
+    n0 = r[0]; n1 = r[1]; n2 = r[2];
+  }
+  int buf = 0;
+  for (uint32_t base = r0; base < r1; base += kBatch, buf ^= 1) {
     const int n = (int)min((uint32_t)kBatch, r1 - base);
-    for (int j = 0; j < n; ++j) {
-      if (__ballot(!done) == 0ull) break;
-      const float4 a = s0[j];
-      const float4 b = s1[j];
-      const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
-      bool hit = !done && (power <= 0.0f) && (alpha >= GSR_ALPHA_MIN);
-      const float test_T = T * (1.0f - alpha);
-      if (hit && test_T < GSR_T_MIN) { done = true; hit = false; }
-      if (SCORE) {
-        // per-wave reduction before the global atomic: 1 atomic per (wave, splat) instead of up to 64
-        const unsigned long long hm = __ballot(hit);
-        if (hm) {
-          float sc;
-          if (score_mode == 0) {
-            sc = b.y * (float)__popcll(hm);
-          } else {
-            sc = gsr_wave_sum_to_lane63(hit ? alpha * T : 0.f);
-            sc = __shfl(sc, 63, 64);
-          }
-          if (lane == 0) unsafeAtomicAdd(score + sid[j], sc);
-        }
+    st.s0[buf][tid] = n0; st.s1[buf][tid] = n1; st.s2[buf][tid] = n2;
+    st.smask[buf][tid] = (tid < n) ? block_mask(n0, n2, tile_x0, tile_y0) : 0u;
+    if (SCORE) st.sid[buf][tid] = nid;
+    if (__syncthreads_count(done) == 256) break;
+    {
+      const uint32_t idx = base + kBatch + tid;
+      if (idx < r1) {
+        nid = point_list[idx];
+        const float4* r = splat + 3 * (size_t)nid;
+        n0 = r[0]; n1 = r[1]; n2 = r[2];
       }
-      if (hit) {
-        const float4 c = s2[j];
-        const float w = alpha * T;
-        C0 += b.w * w; C1 += c.x * w; C2 += c.y * w;
-        Dp += b.z * w;
-        Wt += w;
-        T = test_T;
-        last = (base - r0) + (uint32_t)j + 1u;
+    }
+    for (int k = 0; k < kBatch / 64; ++k) {
+      if (k * 64 >= n) break;
+      unsigned long long bits = __ballot((st.smask[buf][k * 64 + lane] >> wave) & 1u);
+      while (bits) {
+        if (__ballot(!done) == 0ull) break;
+        const int j = k * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1ull;
+        const float4 a = st.s0[buf][j];
+        const float4 b = st.s1[buf][j];
+        const float dx = a.x - pxf, dy = a.y - pyf;
+        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+        const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
+        bool hit = !done && (power <= 0.0f) && (alpha >= GSR_ALPHA_MIN);
+        const float test_T = T * (1.0f - alpha);
+        if (hit && test_T < GSR_T_MIN) { done = true; hit = false; }
+        if (SCORE) {
+          const unsigned long long hm = __ballot(hit);
+          if (hm) {
+            float sc;
+            if (score_mode == 0) {
+              sc = b.y * (float)__popcll(hm);
+            } else {
+              sc = gsr_wave_sum_to_lane63(hit ? alpha * T : 0.f);
+              sc = __shfl(sc, 63, 64);
+            }
+            if (lane == 0) unsafeAtomicAdd(score + st.sid[buf][j], sc);
+          }
+        }
+        if (hit) {
+          const float4 c = st.s2[buf][j];
+          const float w = alpha * T;
+          C0 += b.w * w; C1 += c.x * w; C2 += c.y * w;
+          Dp += b.z * w;
+          Wt += w;
+          T = test_T;
+          last = (base - r0) + (uint32_t)j + 1u;
+        }
       }
     }
   }
@@ -117,6 +163,37 @@ k_render_fwd(const int W, const int H, const uint32_t* __restrict__ ranges, cons
 }
 
 // --------------------------------------------------------------------------------------------------------- K7
+// Transposed butterfly over the 64 lanes for 10 values (see file header). On return lane L holds, for
+// j = L & 3 (j < 3) and row r = L >> 4, the wave total of component comp(j, r) = 4 j + ((r & 1) << 1 | (r >> 1)):
+//   j = 0: rows -> v0 v2 v1 v3     j = 1: rows -> v4 v6 v5 v7     j = 2: rows -> v8 (pad) v9 (pad)
+__device__ __forceinline__ float add_swap32(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_swap16(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float row_sum16(float v) {
+  v += gsr_dpp<0x128>(v);   // row_ror:8
+  v += gsr_dpp<0x124>(v);   // row_ror:4
+  v += gsr_dpp<0x122>(v);   // row_ror:2
+  v += gsr_dpp<0x121>(v);   // row_ror:1
+  return v;
+}
+__device__ __forceinline__ float reduce10(const float v[10], int lane) {
+  const float c01 = add_swap32(v[0], v[1]);
+  const float c23 = add_swap32(v[2], v[3]);
+  const float c45 = add_swap32(v[4], v[5]);
+  const float c67 = add_swap32(v[6], v[7]);
+  const float c89 = add_swap32(v[8], v[9]);
+  const float d0 = row_sum16(add_swap16(c01, c23));
+  const float d1 = row_sum16(add_swap16(c45, c67));
+  const float d2 = row_sum16(add_swap16(c89, 0.f));
+  const int j = lane & 3;
+  return j == 0 ? d0 : (j == 1 ? d1 : d2);
+}
+
 // Accumulates into partials [P,12]:
 //   (dL/dndc_x, dL/dndc_y, dL/dconic_a, dL/dconic_b, dL/dconic_c, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
 __global__ void __launch_bounds__(256)
@@ -124,13 +201,13 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ ranges, cons
              const float4* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_T,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
              const float* __restrict__ dL_dda, float* __restrict__ partials) {
-  __shared__ float4 s0[kBatch], s1[kBatch], s2[kBatch];
-  __shared__ uint32_t sid[kBatch];
+  __shared__ Stage st;
   __shared__ uint32_t wmax[4];
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tile = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const TilePix p = tile_pixel(tile, gx, W, H);
+  const int tile_x0 = p.bx - (wave & 1) * 8, tile_y0 = p.by - (wave >> 1) * 8;
   const float pxf = (float)p.px, pyf = (float)p.py;
   const uint32_t r0 = ranges[2 * tile];
   const size_t pix = (size_t)p.py * W + p.px, HW = (size_t)H * W;
@@ -143,77 +220,95 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ ranges, cons
     gD = dL_dda[pix]; gA = dL_dda[HW + pix];
   }
   const float bg_dot = (bg[0] * gC0 + bg[1] * gC1) + bg[2] * gC2;
-  const float sx = 0.5f * (float)W, sy = 0.5f * (float)H;
 
   const uint32_t wm = gsr_wave_max_u32(last);
   if (lane == 0) wmax[wave] = wm;
   __syncthreads();
   const uint32_t tile_max = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+  if (tile_max == 0) return;
+
+  // lane -> (component slot, scale) of the single atomic that commits a splat's 10 sums (see reduce10)
+  const int rj = lane & 3, rr = lane >> 4;
+  const int comp = 4 * rj + (((rr & 1) << 1) | (rr >> 1));
+  const bool commit = ((lane & 15) < 3) && (comp < 10);
+  const float cscale = comp == 0 ? 0.5f * (float)W : (comp == 1 ? 0.5f * (float)H : 1.0f);
 
   float T = Tf;
   float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, rc0 = 0.f, rc1 = 0.f, rc2 = 0.f;
   float last_z = 0.f, rec_z = 0.f, rec_a = 0.f;
 
-  for (uint32_t hi = tile_max; hi > 0; hi = (hi > kBatch) ? hi - kBatch : 0u) {
+  uint32_t nid = 0;
+  float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+  if ((uint32_t)tid < tile_max) {
+    nid = point_list[r0 + (tile_max - 1u - (uint32_t)tid)];
+    const float4* r = splat + 3 * (size_t)nid;
+    n0 = r[0]; n1 = r[1]; n2 = r[2];
+  }
+  int buf = 0;
+  for (uint32_t hi = tile_max; hi > 0; hi = (hi > kBatch) ? hi - kBatch : 0u, buf ^= 1) {
     const int n = (int)min((uint32_t)kBatch, hi);
+    st.s0[buf][tid] = n0; st.s1[buf][tid] = n1; st.s2[buf][tid] = n2;
+    st.sid[buf][tid] = nid;
+    st.smask[buf][tid] = (tid < n) ? block_mask(n0, n2, tile_x0, tile_y0) : 0u;
     __syncthreads();
-    if (tid < n) {
-      const uint32_t id = point_list[r0 + (hi - 1u - (uint32_t)tid)];
-      const float4* r = splat + 3 * (size_t)id;
-      s0[tid] = r[0]; s1[tid] = r[1]; s2[tid] = r[2];
-      sid[tid] = id;
-    }
-    __syncthreads();
-    for (int j = 0; j < n; ++j) {
-      const uint32_t pos = hi - 1u - (uint32_t)j;      // 0-based list position
-      const bool live = pos < last;
-      if (__ballot(live) == 0ull) continue;
-      const float4 a = s0[j];
-      const float4 b = s1[j];
-      const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      const float G = gsr_exp(power);
-      const float alpha = fminf(GSR_ALPHA_MAX, b.y * G);
-      const bool hit = live && (power <= 0.0f) && (alpha >= GSR_ALPHA_MIN);
-      if (__ballot(hit) == 0ull) continue;
-      float v[10];
-#pragma unroll
-      for (int k = 0; k < 10; ++k) v[k] = 0.f;
-      if (hit) {
-        const float4 c = s2[j];
-        T = T / (1.0f - alpha);
-        const float w = alpha * T;
-        float dL_dalpha;
-        rc0 = last_alpha * lc0 + (1.0f - last_alpha) * rc0; lc0 = b.w;
-        rc1 = last_alpha * lc1 + (1.0f - last_alpha) * rc1; lc1 = c.x;
-        rc2 = last_alpha * lc2 + (1.0f - last_alpha) * rc2; lc2 = c.y;
-        dL_dalpha = (b.w - rc0) * gC0 + (c.x - rc1) * gC1 + (c.y - rc2) * gC2;
-        rec_z = last_alpha * last_z + (1.0f - last_alpha) * rec_z; last_z = b.z;
-        dL_dalpha += (b.z - rec_z) * gD;
-        rec_a = last_alpha + (1.0f - last_alpha) * rec_a;
-        dL_dalpha += (1.0f - rec_a) * gA;
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-Tf / (1.0f - alpha)) * bg_dot;
-        const float dL_dG = b.y * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        v[0] = dL_dG * (-gdx * a.z - gdy * a.w);
-        v[1] = dL_dG * (-gdy * b.x - gdx * a.w);
-        v[2] = -0.5f * gdx * dx * dL_dG;
-        v[3] = -gdx * dy * dL_dG;
-        v[4] = -0.5f * gdy * dy * dL_dG;
-        v[5] = G * dL_dalpha;
-        v[6] = w * gC0; v[7] = w * gC1; v[8] = w * gC2;
-        v[9] = w * gD;
+    if (hi > kBatch) {
+      const uint32_t nhi = hi - kBatch;
+      if ((uint32_t)tid < nhi) {
+        nid = point_list[r0 + (nhi - 1u - (uint32_t)tid)];
+        const float4* r = splat + 3 * (size_t)nid;
+        n0 = r[0]; n1 = r[1]; n2 = r[2];
       }
+    }
+    for (int k = 0; k < kBatch / 64; ++k) {
+      if (k * 64 >= n) break;
+      unsigned long long bits = __ballot((st.smask[buf][k * 64 + lane] >> wave) & 1u);
+      while (bits) {
+        const int j = k * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1ull;
+        const uint32_t pos = hi - 1u - (uint32_t)j;      // 0-based list position
+        const bool live = pos < last;
+        if (__ballot(live) == 0ull) continue;
+        const float4 a = st.s0[buf][j];
+        const float4 b = st.s1[buf][j];
+        const float dx = a.x - pxf, dy = a.y - pyf;
+        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+        const float G = gsr_exp(power);
+        const float alpha = fminf(GSR_ALPHA_MAX, b.y * G);
+        const bool hit = live && (power <= 0.0f) && (alpha >= GSR_ALPHA_MIN);
+        if (__ballot(hit) == 0ull) continue;
+        float v[10];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) v[k] = gsr_wave_sum_to_lane63(v[k]);
-      if (lane == 63) {
-        float* dst = partials + 12 * (size_t)sid[j];
-        unsafeAtomicAdd(dst + 0, v[0] * sx);
-        unsafeAtomicAdd(dst + 1, v[1] * sy);
-#pragma unroll
-        for (int k = 2; k < 10; ++k) unsafeAtomicAdd(dst + k, v[k]);
+        for (int q = 0; q < 10; ++q) v[q] = 0.f;
+        if (hit) {
+          const float4 c = st.s2[buf][j];
+          const float inv = __frcp_rn(1.0f - alpha);
+          T = T * inv;
+          const float w = alpha * T;
+          float dL_dalpha;
+          rc0 = last_alpha * lc0 + (1.0f - last_alpha) * rc0; lc0 = b.w;
+          rc1 = last_alpha * lc1 + (1.0f - last_alpha) * rc1; lc1 = c.x;
+          rc2 = last_alpha * lc2 + (1.0f - last_alpha) * rc2; lc2 = c.y;
+          dL_dalpha = (b.w - rc0) * gC0 + (c.x - rc1) * gC1 + (c.y - rc2) * gC2;
+          rec_z = last_alpha * last_z + (1.0f - last_alpha) * rec_z; last_z = b.z;
+          dL_dalpha += (b.z - rec_z) * gD;
+          rec_a = last_alpha + (1.0f - last_alpha) * rec_a;
+          dL_dalpha += (1.0f - rec_a) * gA;
+          dL_dalpha *= T;
+          last_alpha = alpha;
+          dL_dalpha -= (Tf * inv) * bg_dot;
+          const float dL_dG = b.y * dL_dalpha;
+          const float gdx = G * dx, gdy = G * dy;
+          v[0] = dL_dG * (-gdx * a.z - gdy * a.w);
+          v[1] = dL_dG * (-gdy * b.x - gdx * a.w);
+          v[2] = -0.5f * gdx * dx * dL_dG;
+          v[3] = -gdx * dy * dL_dG;
+          v[4] = -0.5f * gdy * dy * dL_dG;
+          v[5] = G * dL_dalpha;
+          v[6] = w * gC0; v[7] = w * gC1; v[8] = w * gC2;
+          v[9] = w * gD;
+        }
+        const float s = reduce10(v, lane);
+        if (commit) unsafeAtomicAdd(partials + 12 * (size_t)st.sid[buf][j] + comp, s * cscale);
       }
     }
   }

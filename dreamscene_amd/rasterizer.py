@@ -81,8 +81,47 @@ class _State:
     __slots__ = ("view", "gauss", "geom", "binning", "images", "keep", "P", "K", "N", "dev", "cam_grads")
 
 
+class _Workspace:
+    """Per (device, stream) reusable scratch + the pair-count speculation state. Scratch is only touched by work
+    enqueued on that stream, so reuse across calls is ordered by the stream itself."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.n_pinned = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.event = torch.cuda.Event()
+        self.proj_scratch = None
+        self.sort_scratch = None
+        self.hint = {}           # (P, H, W) -> decaying max of recent pair counts
+
+    def scratch(self, which: str, nbytes: int) -> torch.Tensor:
+        t = getattr(self, which)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.dev)
+            setattr(self, which, t)
+        return t
+
+
+_WORKSPACES = {}
+# "auto": speculate the pair capacity from previous calls and enqueue the whole forward without draining the GPU
+# (falls back to an exact re-run if the speculation was too small); "sync": always the exact two-phase forward.
+FORWARD_MODE = "auto"
+
+
+def _workspace(dev, stream) -> _Workspace:
+    key = (dev.index, stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = _Workspace(dev)
+    return ws
+
+
+def _align(n: int, a: int = 256) -> int:
+    return (n + a - 1) // a * a
+
+
 def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
-                          rotations, cov3D_precomp, want_keys: bool = False):
+                          rotations, cov3D_precomp, want_keys: bool = False, want_aux: bool = True,
+                          mode: Optional[str] = None):
     """Forward through the C ABI. Returns (outputs dict, _State). Used by the autograd Function and by tests."""
     lib = L.load()
     dev = means3D.device
@@ -111,53 +150,124 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp)
     st.gauss = g
 
-    i32, u8 = torch.int32, torch.uint8
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = _workspace(dev, stream)
+    prof = PROFILE.handle if PROFILE is not None else None
+    i32 = torch.int32
+    Pm = max(P, 1)
     nb = lib.gsr_num_blocks(P)
     tiles = lib.gsr_num_tiles(H, W)
-    splat = torch.empty((max(P, 1), 12), dtype=torch.float32, device=dev)
-    radii = torch.empty(max(P, 1), dtype=i32, device=dev)
-    tiles_touched = torch.empty(max(P, 1), dtype=i32, device=dev)
-    block_offsets = torch.empty(nb + 4, dtype=i32, device=dev)
-    geom = L.GsrGeom()
-    geom.splat, geom.radii, geom.tiles_touched, geom.block_offsets = (splat.data_ptr(), radii.data_ptr(),
-                                                                      tiles_touched.data_ptr(), block_offsets.data_ptr())
-    st.geom = geom
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    prof = PROFILE.handle if PROFILE is not None else None
-    n_pairs = C.c_uint64(0)
+    mode = mode or FORWARD_MODE
+    hint = ws.hint.get((P, H, W)) if mode == "auto" else None
+
     with torch.cuda.device(dev):
-        L.check(lib.gsr_forward_project(C.byref(st.view), C.byref(g), C.byref(geom), C.byref(n_pairs), stream, prof),
-                "gsr_forward_project")
-        N = int(n_pairs.value)
-        st.N = N
-        point_list = torch.empty(max(N, 1), dtype=i32, device=dev)
-        ranges = torch.empty((tiles, 2), dtype=i32, device=dev)
-        scratch_bytes = int(lib.gsr_sort_scratch_bytes(N, tiles))
-        scratch = torch.empty(scratch_bytes, dtype=u8, device=dev)
-        keys_sorted = torch.empty(max(N, 1), dtype=torch.int64, device=dev) if want_keys else None
-        b = L.GsrBinning()
-        b.point_list, b.ranges, b.keys_sorted = point_list.data_ptr(), ranges.data_ptr(), _ptr(keys_sorted)
-        b.scratch, b.scratch_bytes = scratch.data_ptr(), scratch_bytes
-        st.binning = b
+        radii = torch.empty(Pm, dtype=i32, device=dev)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth_alpha = torch.empty((2, H, W), dtype=torch.float32, device=dev)
-        final_T = torch.empty((H, W), dtype=torch.float32, device=dev)
-        n_contrib = torch.empty((H, W), dtype=i32, device=dev)
         score = torch.zeros(P, dtype=torch.float32, device=dev) if s.score_flag else None
+        proj_bytes = int(lib.gsr_project_scratch_bytes(P))
+        proj_scratch = ws.scratch("proj_scratch", proj_bytes)
+
+        def alloc_state(cap):
+            """One allocation for everything the backward re-reads (splat, tile counts, offsets, lists, ranges,
+            final_T, n_contrib); carved by offsets, no per-tensor allocations."""
+            sizes = dict(splat=Pm * 48, tiles_touched=Pm * 4, block_offsets=(nb + 4) * 4, point_list=max(cap, 1) * 4,
+                         ranges=tiles * 8, final_T=H * W * 4, n_contrib=H * W * 4,
+                         keys_sorted=(max(cap, 1) * 8 if want_keys else 0))
+            offs, tot = {}, 0
+            for k, sz in sizes.items():
+                offs[k] = tot
+                tot += _align(sz)
+            buf = torch.empty(tot, dtype=torch.uint8, device=dev)
+            base = buf.data_ptr()
+            return buf, {k: base + o for k, o in offs.items()}, offs
+
+        geom = L.GsrGeom()
+        b = L.GsrBinning()
         im = L.GsrImages()
-        im.color, im.depth_alpha, im.final_T, im.n_contrib = (color.data_ptr(), depth_alpha.data_ptr(),
-                                                              final_T.data_ptr(), n_contrib.data_ptr())
-        im.important_score = _ptr(score)
-        st.images = im
-        L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), N, C.byref(b), C.byref(im), stream, prof),
-                "gsr_forward_render")
-    # sort scratch is dead after the forward; everything else is kept for backward
-    b.scratch, b.scratch_bytes = None, 0
-    st.keep = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, bg, vm, pm, cp, splat, radii,
-               tiles_touched, block_offsets, point_list, ranges, final_T, n_contrib)
-    out = dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, splat=splat[:P],
-               tiles_touched=tiles_touched[:P], point_list=point_list[:N], ranges=ranges, final_T=final_T,
-               n_contrib=n_contrib, keys_sorted=None if keys_sorted is None else keys_sorted[:N], N=N)
+        im.color, im.depth_alpha, im.important_score = color.data_ptr(), depth_alpha.data_ptr(), _ptr(score)
+
+        def bind(ptrs, cap, on_device):
+            geom.splat, geom.radii, geom.tiles_touched = ptrs["splat"], radii.data_ptr(), ptrs["tiles_touched"]
+            geom.block_offsets = ptrs["block_offsets"]
+            geom.scratch, geom.scratch_bytes = proj_scratch.data_ptr(), proj_scratch.numel()
+            sort_bytes = int(lib.gsr_sort_scratch_bytes(cap, tiles))
+            sort_scratch = ws.scratch("sort_scratch", sort_bytes)
+            b.point_list, b.ranges = ptrs["point_list"], ptrs["ranges"]
+            b.keys_sorted = ptrs["keys_sorted"] if want_keys else None
+            b.scratch, b.scratch_bytes, b.count_on_device = sort_scratch.data_ptr(), sort_scratch.numel(), int(on_device)
+            im.final_T, im.n_contrib = ptrs["final_T"], ptrs["n_contrib"]
+
+        n_pairs = C.c_uint64(0)
+        if hint is None:
+            # exact two-phase forward: project (+ one host sync for N), then allocate exactly, then render
+            buf, ptrs, offs = alloc_state(0)
+            bind(ptrs, 0, False)
+            L.check(lib.gsr_forward_project(C.byref(st.view), C.byref(g), C.byref(geom), C.byref(n_pairs), stream,
+                                            prof), "gsr_forward_project")
+            N = int(n_pairs.value)
+            cap = N
+            buf2, ptrs2, offs2 = alloc_state(cap)
+            # keep the projected state (splat / tile counts / offsets) from the first buffer: re-point only the
+            # N-sized and per-pixel regions into the second one
+            for k in ("point_list", "ranges", "final_T", "n_contrib", "keys_sorted"):
+                ptrs[k] = ptrs2[k]
+            bind(ptrs, cap, False)
+            L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), N, C.byref(b), C.byref(im), stream, prof),
+                    "gsr_forward_render")
+            keep_bufs = (buf, buf2)
+            view_src = {k: (buf2, offs2[k]) if k in ("point_list", "ranges", "final_T", "n_contrib", "keys_sorted")
+                        else (buf, offs[k]) for k in offs}
+        else:
+            cap = int(hint * 1.5) + 65536
+            buf, ptrs, offs = alloc_state(cap)
+            bind(ptrs, cap, True)
+            pinned = ws.n_pinned
+            L.check(lib.gsr_forward_project_async(C.byref(st.view), C.byref(g), C.byref(geom), pinned.data_ptr(),
+                                                  stream, prof), "gsr_forward_project_async")
+            ws.event.record(torch.cuda.current_stream(dev))
+            L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), cap, C.byref(b), C.byref(im), stream, prof),
+                    "gsr_forward_render")
+            ws.event.synchronize()           # projection finished long before the render was even enqueued
+            N = int(pinned[0].item()) if P > 0 else 0
+            keep_bufs = (buf,)
+            view_src = {k: (buf, offs[k]) for k in offs}
+            if N >= (1 << 32):
+                L.check(-2, "gsr_forward_render")
+            if N > cap:
+                # speculation too small: redo binning + render exactly (projection results are still valid)
+                buf2, ptrs2, offs2 = alloc_state(N)
+                for k in ("point_list", "ranges", "final_T", "n_contrib", "keys_sorted"):
+                    ptrs[k] = ptrs2[k]
+                    view_src[k] = (buf2, offs2[k])
+                bind(ptrs, N, False)
+                if score is not None:
+                    score.zero_()
+                L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), N, C.byref(b), C.byref(im), stream,
+                                               prof), "gsr_forward_render")
+                keep_bufs = (buf, buf2)
+                cap = N
+        st.N = N
+        if mode == "auto":
+            ws.hint[(P, H, W)] = max(N, int(ws.hint.get((P, H, W), 0) * 0.9))
+    st.geom, st.binning, st.images = geom, b, im
+    # scratch is dead after the forward; everything else is kept for backward
+    b.scratch, b.scratch_bytes, b.keys_sorted = None, 0, None
+    geom.scratch, geom.scratch_bytes, geom.sorted_idx = None, 0, None
+    st.keep = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, bg, vm, pm, cp, radii,
+               keep_bufs)
+    out = dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, N=N)
+    if want_aux:
+        def view(name, dtype, count, shape=None):
+            bufk, off = view_src[name]
+            esz = torch.empty(0, dtype=dtype).element_size()
+            t = bufk[off:off + count * esz].view(dtype)
+            return t.view(shape) if shape is not None else t
+        out.update(splat=view("splat", torch.float32, P * 12, (P, 12)),
+                   tiles_touched=view("tiles_touched", i32, P),
+                   point_list=view("point_list", i32, N), ranges=view("ranges", i32, tiles * 2, (tiles, 2)),
+                   final_T=view("final_T", torch.float32, H * W, (H, W)), n_contrib=view("n_contrib", i32, H * W, (H, W)),
+                   keys_sorted=view("keys_sorted", torch.int64, N) if want_keys else None)
     return out, st
 
 
@@ -205,7 +315,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
         out, st = rasterize_forward_raw(settings, means3D, opacities, shs, colors_precomp, scales, rotations,
-                                        cov3D_precomp)
+                                        cov3D_precomp, want_aux=False)
         ctx.st = st
         ctx.opac_shape = opacities.shape
         ctx.mark_non_differentiable(out["radii"])

@@ -74,14 +74,21 @@ typedef struct GsrGaussians {
 
 /* Projected per-Gaussian state: written by gsr_forward_project, read by render and backward (save it).
  * splat holds 12 floats per Gaussian as three float4 rows q0,q1,q2 (row-major [P][12]):
- *   q0 = (x_pix, y_pix, conic_a, conic_b)   q1 = (conic_c, opacity, view_depth, r)   q2 = (g, b, 0, 0)
+ *   q0 = (x_pix, y_pix, conic_a, conic_b)   q1 = (conic_c, opacity, view_depth, r)   q2 = (g, b, ext_x, ext_y)
+ * (ext = conservative half-extents, in pixels, of the region where alpha can reach 1/255; < 0 if nowhere)
  * Rows of culled Gaussians (radii == 0) are left unwritten. */
 typedef struct GsrGeom {
   float* splat;            /* [P,12], 16-byte aligned */
   int32_t* radii;          /* [P]  screen radius in pixels, 0 = culled (output `radii`)            */
   uint32_t* tiles_touched; /* [P]  number of 16x16 tiles overlapped                               */
-  uint32_t* block_offsets; /* [gsr_num_blocks(P)+4], 8-byte aligned: exclusive scan of the per-256-Gaussian tile
-                              counts, entry [nb] = N (low 32 bits); the tail holds the 64-bit N on the device */
+  uint32_t* block_offsets; /* [gsr_num_blocks(P)+4], 8-byte aligned: exclusive scan of the tile counts of each
+                              run of 256 Gaussians IN DEPTH ORDER, entry [nb] = N (low 32 bits); the tail holds
+                              the 64-bit N on the device */
+  void* scratch;           /* gsr_project_scratch_bytes(P) bytes, 256-byte aligned: depth-sort buffers. Must stay
+                              alive until gsr_forward_render has been enqueued; not needed for backward          */
+  size_t scratch_bytes;
+  uint32_t* sorted_idx;    /* OUT (set by gsr_forward_project*): [P] Gaussian indices in (depth bits, index) order,
+                              culled ones last; points into scratch                                              */
 } GsrGeom;
 
 /* Tile binning. point_list / ranges are saved for backward; the rest is scratch for the forward only. */
@@ -91,6 +98,12 @@ typedef struct GsrBinning {
   uint64_t* keys_sorted;/* [N] optional: receives the sorted 64-bit keys (tile<<32 | depth bits); may be NULL */
   void* scratch;        /* gsr_sort_scratch_bytes(N, tiles) bytes, 256-byte aligned                   */
   size_t scratch_bytes;
+  int32_t count_on_device; /* 0: n_pairs passed to gsr_forward_render is the exact N (after the synchronous
+                              gsr_forward_project). 1: capacity mode -- n_pairs is the CAPACITY of point_list /
+                              scratch; the kernels take the true N from the device (GsrGeom.block_offsets tail)
+                              and clamp it to the capacity; the caller compares N with the capacity afterwards
+                              and re-runs gsr_forward_render with larger buffers if it did not fit            */
+  int32_t reserved_;
 } GsrBinning;
 
 /* Per-pixel outputs (scene_gaussian.py:1012,1023) and the per-pixel state backward needs. */
@@ -143,16 +156,23 @@ int gsr_version(void);
 const char* gsr_strerror(int code);
 int gsr_last_hip_error(void); /* thread-local hipError_t of the last GSR_EHIP on this thread */
 
+size_t gsr_project_scratch_bytes(int32_t P);
 size_t gsr_sort_scratch_bytes(uint64_t n_pairs, uint32_t n_tiles);
 uint32_t gsr_num_tiles(int32_t image_height, int32_t image_width);
 uint32_t gsr_num_blocks(int32_t P); /* entries of GsrGeom.block_offsets minus one */
 
-/* K1 projection (cull, cov3D, EWA cov2D, conic, radius, tile rect, SH colour) + K2 scan of tile counts.
+/* K1 projection (cull, cov3D, EWA cov2D, conic, radius, tile rect, SH colour), stable depth sort of the P
+ * Gaussians, scan of the depth-ordered tile counts.
  * Synchronises `stream` once and stores the pair count N in *n_pairs_host (ordinary host memory). */
 int gsr_forward_project(const GsrView*, const GsrGaussians*, GsrGeom*, uint64_t* n_pairs_host, void* stream,
                         GsrProfile* prof);
+/* Same work, no host synchronisation: N is copied asynchronously into *n_pairs_pinned (must be page-locked host
+ * memory) and is valid once the caller has waited for the work enqueued so far. Used with capacity mode
+ * (GsrBinning.count_on_device) so that a whole forward is enqueued without draining the GPU. */
+int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uint64_t* n_pairs_pinned, void* stream,
+                              GsrProfile* prof);
 
-/* K3 key/value emission, K4 stable radix sort, K5 tile ranges, K6 front-to-back compositing. */
+/* K3 pair emission in depth order, K4 stable tile sort, K5 tile ranges, K6 front-to-back compositing. */
 int gsr_forward_render(const GsrView*, const GsrGeom*, uint64_t n_pairs, GsrBinning*, GsrImages*, void* stream,
                        GsrProfile* prof);
 

@@ -235,3 +235,25 @@ def test_long_lists_multi_batch(built_lib, c_oracle):
         frac = float((e > TOL * scale).mean())
         print(f"{hk}: max err {e.max():.3e} (max|ref| {np.abs(r).max():.3e}), frac over tol {frac:.2e}")
         assert frac <= 2e-4 and e.max() <= 1e-3 * scale
+
+
+def test_capacity_mode_matches_exact(built_lib):
+    """'auto' forward (speculated pair capacity, no pipeline drain) == exact two-phase forward, bit for bit,
+    including when the speculation is too small and the binning/render has to be redone."""
+    from dreamscene_amd import rasterizer as R
+    g, cam = small_scene(P=4000, H=128, W=160, K=16, seed=91)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    s = settings_for(cam, bg, 3, DEV)
+    t = _to_dev(g)
+    args = (s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None)
+    ref, _ = R.rasterize_forward_raw(*args, want_keys=True, mode="sync")
+    a1, _ = R.rasterize_forward_raw(*args, want_keys=True, mode="auto")     # first auto call: no hint yet
+    a2, _ = R.rasterize_forward_raw(*args, want_keys=True, mode="auto")     # speculated capacity
+    ws = R._workspace(torch.device(DEV), torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
+    ws.hint[(4000, 128, 160)] = 10                                          # force an overflow + exact redo
+    a3, _ = R.rasterize_forward_raw(*args, want_keys=True, mode="auto")
+    torch.cuda.synchronize()
+    for o in (a1, a2, a3):
+        assert o["N"] == ref["N"]
+        for k in ("color", "depth_alpha", "radii", "point_list", "ranges", "keys_sorted", "final_T", "n_contrib"):
+            assert torch.equal(o[k], ref[k]), k
