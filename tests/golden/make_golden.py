@@ -1,0 +1,198 @@
+"""Generates the golden fixtures under tests/golden/ from the reference's OWN importable Python pieces.
+
+Runs ONLY in the build container (needs /root/reference); nothing of the reference travels: the fixtures are
+plain input/output arrays. What each fixture pins:
+  sh_eval.npz        eval_sh(deg 0..3)                       utils/sh_utils.py:56-102
+  cov3d.npz          build_rotation / build_scaling_rotation / strip_symmetric -> 6-vector cov3D
+                                                              gs_renderer.py:79-88, 124-172
+  cameras.npz        RCamera matrices for GenSingleCam poses  utils/cam_utils.py:148-217, 1894-1911
+  projection.npz     geom_transform_points (+1e-7 on w)       utils/graphics_utils.py:29-36
+  object_render.npz  the reference's UNCHANGED SceneGaussian.object_render (scene_gaussian.py:895-1044) driven over
+                     this repo's CPU oracle registered as `diff_gaussian_rasterization` (BASELINE.json config 1,
+                     "plumbing"): settings construction, output dict, disp post-processing, where .grad lands.
+Usage: python tests/golden/make_golden.py
+"""
+import math
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+
+def stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    class _Logger:
+        def __getattr__(self, k):
+            return lambda *a, **kw: None
+    stub("loguru", logger=_Logger())
+    stub("open3d")
+    stub("plyfile", PlyData=object, PlyElement=object)
+    stub("simple_knn")
+    stub("simple_knn._C", distCUDA2=lambda x: torch.ones(x.shape[0]))
+    for n in ("point_e", "point_e.diffusion", "point_e.diffusion.configs", "point_e.diffusion.sampler",
+              "point_e.models", "point_e.models.configs", "point_e.models.download", "point_e.util",
+              "point_e.util.plotting"):
+        stub(n, DIFFUSION_CONFIGS={}, diffusion_from_config=None, PointCloudSampler=None, MODEL_CONFIGS={},
+             model_from_config=None, load_checkpoint=None, plot_point_cloud=None)
+    oc = stub("omegaconf", OmegaConf=object)
+    dc = stub("omegaconf.dictconfig", DictConfig=dict)
+    oc.dictconfig = dc
+    stub("e3nn", o3=None)
+    stub("pytorch3d")
+    stub("pytorch3d.transforms", quaternion_to_matrix=None, matrix_to_quaternion=None, quaternion_multiply=None,
+         matrix_to_euler_angles=None, euler_angles_to_matrix=None)
+    stub("cv2")
+    stub("imageio")
+    # the build's CPU oracle under the name the reference imports
+    from oracle import torch_oracle as TO
+    stub("diff_gaussian_rasterization", GaussianRasterizationSettings=TO.GaussianRasterizationSettings,
+         GaussianRasterizer=lambda raster_settings: TO.GaussianRasterizer(raster_settings, dtype=torch.float64))
+
+
+def cuda_to_cpu():
+    """Callers hard-code device='cuda' (scene_gaussian.py:45,569; gs_renderer.py:80,129,149)."""
+    def wrap(fn):
+        def inner(*a, **kw):
+            if "device" in kw and str(kw["device"]).startswith("cuda"):
+                kw["device"] = "cpu"
+            return fn(*a, **kw)
+        return inner
+    for name in ("zeros", "zeros_like", "ones", "ones_like", "tensor", "empty", "rand", "randn", "full", "eye", "arange"):
+        setattr(torch, name, wrap(getattr(torch, name)))
+    torch.Tensor.cuda = lambda self, *a, **kw: self
+    torch.nn.Module.cuda = lambda self, *a, **kw: self
+    _device = torch.device
+
+    class _Dev:
+        def __new__(cls, *a, **kw):
+            if a and isinstance(a[0], str) and a[0].startswith("cuda"):
+                return _device("cpu")
+            return _device(*a, **kw)
+    torch.device = _Dev
+
+
+def main():
+    install_stubs()
+    cuda_to_cpu()
+    rng = np.random.default_rng(20260926)
+
+    # ---- SH basis
+    from utils.sh_utils import eval_sh
+    P = 64
+    sh = rng.normal(size=(P, 3, 16)).astype(np.float32)          # reference layout [..., C, K]
+    dirs = rng.normal(size=(P, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    outs = {f"deg{d}": eval_sh(d, torch.tensor(sh), torch.tensor(dirs)).numpy() for d in range(4)}
+    np.savez(os.path.join(HERE, "sh_eval.npz"), sh=sh, dirs=dirs, **outs)
+
+    # ---- cov3D
+    import gs_renderer as G
+    scales = np.exp(rng.normal(size=(P, 3))).astype(np.float32) * 0.05
+    quats = rng.normal(size=(P, 4)).astype(np.float32)
+    qn = quats / np.linalg.norm(quats, axis=1, keepdims=True)
+    R = G.build_rotation(torch.tensor(qn)).numpy()
+    L = G.build_scaling_rotation(torch.tensor(scales) * 1.7, torch.tensor(qn))
+    cov6 = G.strip_symmetric(L @ L.transpose(1, 2)).numpy()
+    np.savez(os.path.join(HERE, "cov3d.npz"), scales=scales, quats_normalized=qn, modifier=np.float32(1.7), R=R, cov6=cov6)
+
+    # ---- cameras
+    from config import GenerateCamParams
+    from utils import cam_utils as CU
+    opt = GenerateCamParams()
+    cams = []
+    for (fovx, radius, phi, theta, h, w) in [(0.46, 5.35, 0.0, 75.0, 512, 512), (0.55, 3.5, 135.0, 60.0, 256, 256),
+                                             (0.32, 5.2, -90.0, 100.0, 800, 800), (0.6, 4.0, 45.0, 90.0, 512, 384),
+                                             (0.5, 2.5, 200.0, 45.0, 1024, 1024)]:
+        ok, info = CU.GenSingleCam(opt, fovx, radius, phi, theta, h, w)
+        o2 = GenerateCamParams()
+        o2.image_h, o2.image_w = h, w
+        cam = CU.RCamera(R=info.R, T=info.T, FoVx=info.FovX, FoVy=info.FovY, delta_polar=info.delta_polar,
+                         delta_azimuth=info.delta_azimuth, delta_radius=info.delta_radius, opt=o2)
+        cams.append(dict(args=np.array([fovx, radius, phi, theta, h, w], np.float64), R=np.asarray(info.R, np.float64),
+                         T=np.asarray(info.T, np.float64), FoVx=np.float64(cam.FoVx), FoVy=np.float64(cam.FoVy),
+                         wvt=cam.world_view_transform.numpy(), full=cam.full_proj_transform.numpy(),
+                         center=cam.camera_center.numpy(), H=np.int64(cam.image_height), W=np.int64(cam.image_width)))
+    np.savez(os.path.join(HERE, "cameras.npz"), n=np.int64(len(cams)),
+             **{f"{k}_{i}": v for i, c in enumerate(cams) for k, v in c.items()})
+
+    # ---- projection
+    from utils.graphics_utils import geom_transform_points
+    pts = rng.normal(size=(P, 3)).astype(np.float32)
+    proj = geom_transform_points(torch.tensor(pts), torch.tensor(cams[0]["full"])).numpy()
+    np.savez(os.path.join(HERE, "projection.npz"), points=pts, full_proj=cams[0]["full"], ndc=proj)
+
+    # ---- the reference's object_render over the oracle (config 1 plumbing)
+    import scene_gaussian as SG
+    random.seed(0)
+    torch.manual_seed(0)
+
+    class Cfg:
+        generateCamParams = GenerateCamParams()
+    cfg = Cfg()
+    cfg.generateCamParams.image_h = cfg.generateCamParams.image_w = 64
+    sg = SG.SceneGaussian.__new__(SG.SceneGaussian)
+    try:
+        SG.SceneGaussian.__init__(sg, cfg)
+    except Exception as e:      # constructor may want more config than the render needs
+        print("SceneGaussian.__init__ skipped:", type(e).__name__, e)
+    Pn = 400
+    from dreamscene_amd import synth
+    g = synth.g_object(Pn, seed=5, K=16)
+    g["scales"] = (g["scales"] * 5).astype(np.float32)
+    gm = G.GaussianModel({"sh_degree": 3}, "scene")
+    gm.active_sh_degree = 2
+    gm._xyz = torch.nn.Parameter(torch.tensor(g["means3D"]))
+    gm._scaling = torch.nn.Parameter(torch.log(torch.tensor(g["scales"])))
+    gm._rotation = torch.nn.Parameter(torch.tensor(g["rotations"]) * 1.3)        # un-normalised on purpose
+    op = np.clip(g["opacities"], 1e-4, 1 - 1e-4)
+    gm._opacity = torch.nn.Parameter(torch.tensor(np.log(op / (1 - op))))
+    gm._features_dc = torch.nn.Parameter(torch.tensor(g["shs"][:, :1, :]))
+    gm._features_rest = torch.nn.Parameter(torch.tensor(g["shs"][:, 1:, :]))
+    ok, info = CU.GenSingleCam(opt, 0.5, 3.0, 30.0, 70.0, 64, 64)
+    o2 = GenerateCamParams()
+    o2.image_h = o2.image_w = 64
+    cam = CU.RCamera(R=info.R, T=info.T, FoVx=info.FovX, FoVy=info.FovY, delta_polar=info.delta_polar,
+                     delta_azimuth=info.delta_azimuth, delta_radius=info.delta_radius, opt=o2)
+    bg = torch.tensor([1.0, 1.0, 1.0])
+    out = sg.object_render(gm, cam, bg, test=True)
+    gi = torch.tensor(rng.normal(size=(3, 64, 64)).astype(np.float32))
+    gd = torch.tensor(rng.normal(size=(1, 64, 64)).astype(np.float32))
+    ga = torch.tensor(rng.normal(size=(1, 64, 64)).astype(np.float32))
+    loss = (out["image"] * gi).sum() + (out["depth"] * gd).sum() + (out["alpha"] * ga).sum()
+    loss.backward()
+    np.savez(os.path.join(HERE, "object_render.npz"),
+             xyz=gm._xyz.detach().numpy(), log_scales=gm._scaling.detach().numpy(), raw_rot=gm._rotation.detach().numpy(),
+             logit_opacity=gm._opacity.detach().numpy(), f_dc=gm._features_dc.detach().numpy(),
+             f_rest=gm._features_rest.detach().numpy(), active_sh_degree=np.int64(2),
+             wvt=cam.world_view_transform.numpy(), full=cam.full_proj_transform.numpy(), center=cam.camera_center.numpy(),
+             FoVx=np.float64(cam.FoVx), FoVy=np.float64(cam.FoVy), bg=bg.numpy(), gi=gi.numpy(), gd=gd.numpy(), ga=ga.numpy(),
+             image=out["image"].detach().numpy(), depth=out["depth"].detach().numpy(), alpha=out["alpha"].detach().numpy(),
+             radii=out["radii"].numpy(), visibility_filter=out["visibility_filter"].numpy(),
+             scales_out=out["scales"].detach().numpy(), keys=np.array(sorted(out.keys())),
+             vsp_grad=out["viewspace_points"].grad.numpy(), g_xyz=gm._xyz.grad.numpy(), g_scaling=gm._scaling.grad.numpy(),
+             g_rotation=gm._rotation.grad.numpy(), g_opacity=gm._opacity.grad.numpy(), g_f_dc=gm._features_dc.grad.numpy(),
+             g_f_rest=gm._features_rest.grad.numpy())
+    print("fixtures written to", HERE)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("  ", f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+"""CPU: host-side logic around the boundary (synthetic generators, camera maths, gradient arena)."""
+import numpy as np
+import torch
+
+from dreamscene_amd import multiview, synth
+from dreamscene_amd.camera import look_at_camera, orbit_camera
+
+
+def test_synth_is_seeded_and_shaped():
+    a, b = synth.g_object(1000, seed=3, K=16), synth.g_object(1000, seed=3, K=16)
+    for k in a:
+        assert np.array_equal(a[k], b[k]) and a[k].dtype == np.float32
+    assert a["shs"].shape == (1000, 16, 3) and a["opacities"].shape == (1000, 1)
+    np.testing.assert_allclose(np.linalg.norm(a["rotations"], axis=1), 1.0, atol=1e-5)
+    assert (a["scales"] > 0).all() and (a["opacities"] > 0).all() and (a["opacities"] < 1).all()
+    c = synth.g_object(1000, seed=4, K=16)
+    assert not np.array_equal(a["means3D"], c["means3D"])
+    ind = synth.g_indoor(seed=0, per_wall=200, K=4)
+    assert ind["means3D"].shape == (1000, 3) and ind["shs"].shape == (1000, 4, 3)
+    init = synth.g_object(100, seed=1, init_opacity=True)
+    assert np.allclose(init["opacities"], 0.1)
+
+
+def test_camera_conventions():
+    cam = orbit_camera(5.0, 60.0, 30.0, 0.5, 256, 256)
+    # camera centre = inverse(world_view_transform)[3,:3] and is at the orbit radius
+    np.testing.assert_allclose(np.linalg.norm(cam.camera_center), 5.0, rtol=1e-5)
+    # the origin projects to the image centre and lies at depth = radius (row-vector convention)
+    o = np.array([0, 0, 0, 1], np.float32) @ cam.world_view_transform
+    np.testing.assert_allclose(o[:3], [0, 0, 5.0], atol=1e-5)
+    h = np.array([0, 0, 0, 1], np.float32) @ cam.full_proj_transform
+    np.testing.assert_allclose(h[:2] / h[3], [0, 0], atol=1e-6)
+    # look_at: the target is on the optical axis, in front
+    c2 = look_at_camera([1, 2, 3], [4, 2, 3], 0.9, 128, 128)
+    t = np.array([4, 2, 3, 1], np.float32) @ c2.world_view_transform
+    np.testing.assert_allclose(t[:3], [0, 0, 3.0], atol=1e-5)
+    # +y of the image is "down": a point below the target (smaller world z) lands at larger pixel y
+    p = np.array([4, 2, 2.5, 1], np.float32) @ c2.full_proj_transform
+    assert p[1] / p[3] > 0
+
+
+def test_grad_arena_layout_and_alignment():
+    P, K = 1001, 16
+    a = multiview.GradArena(P, K, "cpu")
+    assert a.views["means3D"].shape == (P, 3) and a.views["shs"].shape == (P, K, 3)
+    assert a.views["rotations"].shape == (P, 4) and a.views["opacities"].shape == (P, 1)
+    base = a.flat.data_ptr()
+    spans = []
+    for n, v in a.views.items():
+        assert v.is_contiguous() and (v.data_ptr() - base) % 16 == 0, n
+        spans.append((v.data_ptr() - base, v.numel() * 4))
+    spans.sort()
+    for (o1, s1), (o2, _) in zip(spans, spans[1:]):
+        assert o1 + s1 <= o2                      # regions do not overlap
+    a.views["shs"].fill_(2.0)
+    assert float(a.flat.sum()) == 2.0 * P * K * 3
+    assert multiview.shard_views(8, 1, 4) == [1, 5] and multiview.shard_views(3, 2, 4) == [2]
+    assert multiview.allreduce_grads(a) is None   # no process group: no-op
+
+
+def test_view_stats_single_process():
+    g = torch.tensor([[3.0, 4.0, 0.0], [0.0, 0.0, 0.0]])
+    r = torch.tensor([5, 0], dtype=torch.int32)
+    norm, vis, maxr = multiview.reduce_view_stats(g, r)
+    assert norm.tolist() == [5.0, 0.0] and vis.tolist() == [1.0, 0.0] and maxr.tolist() == [5, 0]

@@ -1,0 +1,137 @@
+"""CPU: the two independent oracles against each other -- the scalar C restatement (explicit backward) vs the
+vectorised PyTorch restatement (autograd backward, float64). This is what stands in for reference golden vectors
+of the rasterizer arithmetic, which the reference does not hold (parity unpinned)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import err, oracle_view, small_scene
+
+
+def _torch_run(g, cam, bg, D, dt=torch.float64, score=False, score_mode=0, cam_grad=True, gi=None, gda=None):
+    from oracle import torch_oracle as TO
+    P = g["means3D"].shape[0]
+    t = {k: torch.tensor(v, dtype=dt, requires_grad=True) for k, v in g.items()}
+    m2d = torch.zeros(P, 3, dtype=dt, requires_grad=True)
+    vm = torch.tensor(cam.world_view_transform, dtype=dt, requires_grad=cam_grad)
+    pm = torch.tensor(cam.full_proj_transform, dtype=dt, requires_grad=cam_grad)
+    cp = torch.tensor(cam.camera_center, dtype=dt, requires_grad=cam_grad)
+    s = TO.Settings(cam.image_height, cam.image_width, cam.tanfovx, cam.tanfovy, torch.tensor(bg, dtype=dt), 1.0, vm, pm,
+                    D, cp, False, score)
+    res, aux = TO.rasterize(t["means3D"], m2d, t["opacities"], shs=t.get("shs"), colors_precomp=t.get("colors_precomp"),
+                            scales=t.get("scales"), rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"),
+                            settings=s, score_mode=score_mode, return_aux=True)
+    sc = None
+    if score:
+        sc, img, radii, da = res
+    else:
+        img, radii, da = res
+    grads = None
+    if gi is not None:
+        ((img * torch.tensor(gi, dtype=dt)).sum() + (da * torch.tensor(gda, dtype=dt)).sum()).backward()
+        grads = {k: v.grad.numpy() for k, v in t.items()}
+        gz = lambda x: np.zeros(tuple(x.shape)) if x.grad is None else x.grad.numpy()
+        grads = {k: gz(v) for k, v in t.items()}
+        grads.update(means2D=gz(m2d), view=gz(vm), proj=gz(pm), campos=gz(cp))
+    return dict(img=img.detach().numpy(), da=da.detach().numpy(), radii=radii.numpy(), aux=aux, grads=grads,
+                score=None if sc is None else sc.numpy())
+
+
+@pytest.mark.parametrize("D,K,seed", [(0, 16, 1), (1, 4, 2), (2, 9, 3), (3, 16, 4)])
+def test_forward_backward_c_vs_torch(c_oracle, D, K, seed):
+    from dreamscene_amd import synth
+    P = 500
+    g, cam = small_scene(P=P, H=80, W=96, K=K, seed=seed)
+    bg = np.array([0.9, 0.5, 0.1], np.float32)
+    gi, gda = synth.upstream_grads(80, 96, seed)
+    r = _torch_run(g, cam, bg, D, gi=gi, gda=gda)
+    v = oracle_view(c_oracle, cam, P, K, D, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    b = c_oracle.backward(v, f, gi, gda, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
+                          cam_grads=True)
+    # integer artefacts agree exactly between the two restatements
+    assert np.array_equal(f["radii"], r["radii"])
+    assert np.array_equal(f["point_list"], r["aux"]["binning"].point_list)
+    # tile half of the keys identical; the depth half differs by rounding (float64-then-cast vs fp32 arithmetic)
+    assert np.array_equal(f["keys"] >> np.uint64(32), r["aux"]["binning"].keys >> np.uint64(32))
+    assert np.array_equal(f["ranges"], r["aux"]["binning"].ranges)
+    assert np.array_equal(f["n_contrib"], r["aux"]["n_contrib"])
+    assert err(f["image"], r["img"]) <= 2e-6
+    assert err(f["depth_alpha"], r["da"]) <= 2e-5
+    pairs = [("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+             ("opacities", "dL_dopacity"), ("shs", "dL_dshs"), ("means2D", "dL_dmeans2D"), ("view", "dL_dview"),
+             ("proj", "dL_dproj"), ("campos", "dL_dcampos")]
+    for tk, ck in pairs:
+        a, c = r["grads"][tk], b[ck]
+        assert err(a, c) <= 1e-5 * max(1.0, float(np.abs(a).max())), tk
+
+
+def test_colors_precomp_and_cov3d_precomp(c_oracle):
+    from dreamscene_amd import synth
+    from oracle import torch_oracle as TO
+    g, cam = small_scene(P=300, H=64, W=64, K=16, seed=9)
+    cov = TO.cov3d_from_scale_rot(torch.tensor(g["scales"]), 1.0, torch.tensor(g["rotations"])).numpy().astype(np.float32)
+    g2 = dict(means3D=g["means3D"], opacities=g["opacities"], cov3D_precomp=cov,
+              colors_precomp=np.random.default_rng(1).uniform(size=(300, 3)).astype(np.float32))
+    bg = np.zeros(3, np.float32)
+    gi, gda = synth.upstream_grads(64, 64, 2)
+    r = _torch_run(g2, cam, bg, 0, gi=gi, gda=gda)
+    v = oracle_view(c_oracle, cam, 300, 0, 0, bg)
+    f = c_oracle.forward(v, g2["means3D"], g2["opacities"], colors_precomp=g2["colors_precomp"], cov3D_precomp=cov)
+    b = c_oracle.backward(v, f, gi, gda, g2["means3D"], cov3D_precomp=cov, cam_grads=False)
+    assert err(f["image"], r["img"]) <= 2e-6
+    for tk, ck in [("means3D", "dL_dmeans3D"), ("cov3D_precomp", "dL_dcov3D"), ("colors_precomp", "dL_dcolors"),
+                   ("opacities", "dL_dopacity")]:
+        a, c = r["grads"][tk], b[ck]
+        assert err(a, c) <= 1e-5 * max(1.0, float(np.abs(a).max())), tk
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_importance_score(c_oracle, mode):
+    g, cam = small_scene(P=400, H=64, W=64, K=16, seed=12)
+    bg = np.ones(3, np.float32)
+    r = _torch_run(g, cam, bg, 1, score=True, score_mode=mode)
+    v = oracle_view(c_oracle, cam, 400, 16, 1, bg, score_mode=mode)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
+                         score=True)
+    assert err(f["important_score"], r["score"]) <= 1e-3 * max(1.0, float(r["score"].max()))
+    assert (f["important_score"][f["radii"] == 0] == 0).all()
+
+
+def test_edge_cases(c_oracle):
+    """zero scales, behind-camera, off-screen, saturating alpha, sub-threshold alpha, huge footprints, empty set."""
+    g, cam = small_scene(P=600, H=50, W=70, K=16, seed=21)
+    g["scales"][:40] = 0.0
+    g["means3D"][40:80] *= 40.0
+    g["means3D"][80:100, :] = cam.camera_center + 0.05
+    g["opacities"][100:160] = 1.0
+    g["opacities"][160:200] = 0.003
+    g["scales"][200:205] *= 60.0
+    bg = np.array([0.3, 0.6, 0.9], np.float32)
+    r = _torch_run(g, cam, bg, 2)
+    v = oracle_view(c_oracle, cam, 600, 16, 2, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    assert np.array_equal(f["radii"], r["radii"])
+    assert (f["radii"][80:100] == 0).all()                     # inside the near plane: culled
+    assert (f["radii"][:40] > 0).any()                         # zero scale still has the 0.3 px low-pass footprint
+    assert f["tiles_touched"][200:205].max() == ((50 + 15) // 16) * ((70 + 15) // 16)   # clipped to the whole grid
+    assert np.array_equal(f["point_list"], r["aux"]["binning"].point_list)
+    assert err(f["image"], r["img"]) <= 2e-6
+    assert f["image"].shape == (3, 50, 70)
+    # empty input renders the background
+    v0 = oracle_view(c_oracle, cam, 0, 16, 2, bg)
+    z = lambda *s: np.zeros(s, np.float32)
+    f0 = c_oracle.forward(v0, z(0, 3), z(0, 1), shs=z(0, 16, 3), scales=z(0, 3), rotations=z(0, 4))
+    assert f0["N"] == 0 and err(f0["image"], np.broadcast_to(bg[:, None, None], (3, 50, 70))) == 0.0
+
+
+def test_sort_is_stable_on_equal_depths(c_oracle):
+    """Ties in (tile, depth bits) must resolve by Gaussian index (emission order)."""
+    g, cam = small_scene(P=200, H=64, W=64, K=16, seed=33)
+    g["means3D"][:] = g["means3D"][0]                           # all at one point: identical depth bits
+    v = oracle_view(c_oracle, cam, 200, 16, 0, np.zeros(3, np.float32))
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    for t in range(f["ranges"].shape[0]):
+        a, b = f["ranges"][t]
+        seg = f["point_list"][a:b]
+        assert (np.diff(seg.astype(np.int64)) > 0).all()
