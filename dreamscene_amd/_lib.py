@@ -32,12 +32,14 @@ class GsrGeom(C.Structure):
 
 
 class GsrBinning(C.Structure):
-    _fields_ = [("point_list", _f), ("ranges", _f), ("keys_sorted", _f), ("scratch", _f), ("scratch_bytes", C.c_size_t),
+    _fields_ = [("point_list", _f), ("ranges", _f), ("tile_work", _f), ("keys_sorted", _f), ("scratch", _f),
+                ("scratch_bytes", C.c_size_t),
                 ("count_on_device", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class GsrImages(C.Structure):
-    _fields_ = [("color", _f), ("depth_alpha", _f), ("final_T", _f), ("n_contrib", _f), ("important_score", _f)]
+    _fields_ = [("color", _f), ("depth_alpha", _f), ("final_T", _f), ("n_contrib", _f), ("tile_depth", _f),
+                ("important_score", _f)]
 
 
 class GsrImageGrads(C.Structure):

@@ -13,6 +13,11 @@
 //    (v_permlane32_swap / v_permlane16_swap halve the register count while crossing lane halves / rows, DPP
 //    row rotations finish inside the 16-lane rows): 28 VALU ops instead of 60, and the 10 sums land in 10
 //    different lanes so that ONE global_atomic_add_f32 instruction commits all of them.
+//  * Load balance: tiles differ in cost by orders of magnitude (empty / silhouette / deep), and a static
+//    blockIdx -> tile map leaves most CUs idle behind a few heavy ones (measured: VALU 27-50 % busy, all on a
+//    subset of CUs). Both kernels are therefore PERSISTENT: a fixed number of workgroups per CU pull work items
+//    from a global atomic counter, and the items are pre-ordered heaviest-first (k_work_order: bucket sort of the
+//    tiles by log2 of list length for K6, by the tile's deepest contributor for K7).
 // Semantics: SURVEY.md Appendix A.2 / A.3, SEMANTICS.md; outputs as consumed at scene_gaussian.py:1012-1032.
 #include "gsr_common.h"
 
@@ -61,105 +66,222 @@ __device__ __forceinline__ uint32_t block_mask(const float4 q0, const float4 q2,
   return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
 }
 
+// Same for the four 4x4 blocks (bit = wave index) of an 8x8 pixel quarter with origin (x0, y0).
+__device__ __forceinline__ uint32_t block_mask4(const float4 q0, const float4 q2, int qx0, int qy0) {
+  const float ex = q2.z, ey = q2.w;
+  if (!(ex >= 0.f)) return 0u;
+  const float x0 = (float)qx0, y0 = (float)qy0;
+  const bool xl = (q0.x - ex <= x0 + 3.f) && (q0.x + ex >= x0);
+  const bool xr = (q0.x - ex <= x0 + 7.f) && (q0.x + ex >= x0 + 4.f);
+  const bool yt = (q0.y - ey <= y0 + 3.f) && (q0.y + ey >= y0);
+  const bool yb = (q0.y - ey <= y0 + 7.f) && (q0.y + ey >= y0 + 4.f);
+  return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
+}
+
+template <int CTRL>
+__device__ __forceinline__ int gsr_dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// Work list: tile ids ordered heaviest-first (33 buckets of floor(log2(key+1)), descending), plus the zeroed
+// work counter in work[n_tiles]. MODE 0: key = list length from `ranges` (forward; also zeroes tile_depth),
+// MODE 1: key = tile_depth (backward). Single workgroup; the order inside a bucket is arbitrary.
+template <int MODE>
+__global__ void __launch_bounds__(1024)
+k_work_order(const uint32_t n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ tile_depth,
+             uint32_t* __restrict__ work) {
+  __shared__ uint32_t cnt[34], cur[34];
+  const int tid = threadIdx.x;
+  if (tid < 34) cnt[tid] = 0;
+  __syncthreads();
+  for (uint32_t t = tid; t < n_tiles; t += 1024) {
+    const uint32_t key = MODE == 0 ? (ranges[2 * t + 1] - ranges[2 * t]) : tile_depth[t];
+    atomicAdd(&cnt[key ? 32 - __clz(key) : 0], 1u);
+    if (MODE == 0) tile_depth[t] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int b = 33; b >= 0; --b) { cur[b] = run; run += cnt[b]; }
+    work[n_tiles] = 0;
+  }
+  __syncthreads();
+  for (uint32_t t = tid; t < n_tiles; t += 1024) {
+    const uint32_t key = MODE == 0 ? (ranges[2 * t + 1] - ranges[2 * t]) : tile_depth[t];
+    work[atomicAdd(&cur[key ? 32 - __clz(key) : 0], 1u)] = t;
+  }
+}
+
 struct Stage {
   float4 s0[2][kBatch], s1[2][kBatch], s2[2][kBatch];
   uint32_t sid[2][kBatch];
   uint32_t smask[2][kBatch];
+  uint32_t item;
 };
 
 // --------------------------------------------------------------------------------------------------------- K6
+// Forward compositing, "list-parallel lanes": FOUR lanes share a pixel and take four consecutive candidates of
+// the list per step:
+//   * work item = one 8x8 pixel quarter of a 16x16 tile, handled by a 256-thread workgroup; wave = 4x4 pixels;
+//     lane = (pixel = lane>>2, slot = lane&3);
+//   * each lane evaluates alpha of "its" candidate; the transmittance in front of it is T * (exclusive product
+//     of the earlier slots' (1-alpha)) -- a 2-step quad scan on DPP quad_perm, no LDS; the T < 1e-4 stop is an
+//     OR-scan over the quad; the new T is the quad-min of the survivors' T(1-alpha);
+//   * colour / depth / alpha partial sums stay per lane and are folded over the quad once, at the end.
+// 4x more (and 4x finer) work items, 4x shorter dependency chains, tighter 4x4 culling; same gates in the same
+// list order (the only numerical change is the association of the running product inside a quad, ulp-level).
 template <bool SCORE>
 __global__ void __launch_bounds__(256)
-k_render_fwd(const int W, const int H, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-             const float4* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ out_color,
-             float* __restrict__ out_da, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-             float* __restrict__ score, const int score_mode) {
+k_render_fwd(const int W, const int H, const uint32_t n_tiles, const uint32_t* __restrict__ work,
+             uint32_t* __restrict__ counter, const uint32_t* __restrict__ ranges,
+             const uint32_t* __restrict__ point_list, const float4* __restrict__ splat, const float* __restrict__ bg,
+             float* __restrict__ out_color, float* __restrict__ out_da, float* __restrict__ final_T,
+             uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_depth, float* __restrict__ score,
+             const int score_mode) {
   __shared__ Stage st;
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
-  const int tile = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const TilePix p = tile_pixel(tile, gx, W, H);
-  const int tile_x0 = p.bx - (wave & 1) * 8, tile_y0 = p.by - (wave >> 1) * 8;
-  const float pxf = (float)p.px, pyf = (float)p.py;
-  const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+  const int slot = lane & 3, pl = lane >> 2;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  {
+    // Workgroup b takes item b of the heaviest-first work list: the hardware dispatcher hands workgroups out in
+    // index order as CU slots free up, i.e. it performs longest-processing-time-first scheduling for us.
+    const uint32_t item = blockIdx.x;
+    const uint32_t tile = work[item >> 2];
+    const int quarter = (int)(item & 3u);
+    const int ty = (int)tile / gx, tx = (int)tile - ty * gx;
+    const int q_x0 = tx * GSR_TILE + (quarter & 1) * 8, q_y0 = ty * GSR_TILE + (quarter >> 1) * 8;
+    const int px = q_x0 + (wave & 1) * 4 + (pl & 3), py = q_y0 + (wave >> 1) * 4 + (pl >> 2);
+    const bool inside = (px < W) && (py < H);
+    const float pxf = (float)px, pyf = (float)py;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
 
-  bool done = !p.inside;
-  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
-  uint32_t last = 0;
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
+    uint32_t last = 0;
 
-  // prefetch registers for the next batch
-  uint32_t nid = 0;
-  float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
-  if (r0 + tid < r1) {
-    nid = point_list[r0 + tid];
-    const float4* r = splat + 3 * (size_t)nid;
-    n0 = r[0]; n1 = r[1]; n2 = r[2];
-  }
-  int buf = 0;
-  for (uint32_t base = r0; base < r1; base += kBatch, buf ^= 1) {
-    const int n = (int)min((uint32_t)kBatch, r1 - base);
-    st.s0[buf][tid] = n0; st.s1[buf][tid] = n1; st.s2[buf][tid] = n2;
-    st.smask[buf][tid] = (tid < n) ? block_mask(n0, n2, tile_x0, tile_y0) : 0u;
-    if (SCORE) st.sid[buf][tid] = nid;
-    if (__syncthreads_count(done) == 256) break;
-    {
-      const uint32_t idx = base + kBatch + tid;
-      if (idx < r1) {
-        nid = point_list[idx];
-        const float4* r = splat + 3 * (size_t)nid;
-        n0 = r[0]; n1 = r[1]; n2 = r[2];
-      }
+    uint32_t nid = 0;
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+    if (r0 + tid < r1) {
+      nid = point_list[r0 + tid];
+      const float4* r = splat + 3 * (size_t)nid;
+      n0 = r[0]; n1 = r[1]; n2 = r[2];
     }
-    for (int k = 0; k < kBatch / 64; ++k) {
-      if (k * 64 >= n) break;
-      unsigned long long bits = __ballot((st.smask[buf][k * 64 + lane] >> wave) & 1u);
-      while (bits) {
-        if (__ballot(!done) == 0ull) break;
-        const int j = k * 64 + __builtin_ctzll(bits);
-        bits &= bits - 1ull;
-        const float4 a = st.s0[buf][j];
-        const float4 b = st.s1[buf][j];
-        const float dx = a.x - pxf, dy = a.y - pyf;
-        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-        const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
-        bool hit = !done && (power <= 0.0f) && (alpha >= GSR_ALPHA_MIN);
-        const float test_T = T * (1.0f - alpha);
-        if (hit && test_T < GSR_T_MIN) { done = true; hit = false; }
-        if (SCORE) {
-          const unsigned long long hm = __ballot(hit);
-          if (hm) {
+    int buf = 0;
+    for (uint32_t base = r0; base < r1; base += kBatch, buf ^= 1) {
+      const int n = (int)min((uint32_t)kBatch, r1 - base);
+      st.s0[buf][tid] = n0; st.s1[buf][tid] = n1; st.s2[buf][tid] = n2;
+      st.smask[buf][tid] = (tid < n) ? block_mask4(n0, n2, q_x0, q_y0) : 0u;
+      if (SCORE) st.sid[buf][tid] = nid;
+      if (__syncthreads_count(done) == 256) break;
+      {
+        const uint32_t idx = base + kBatch + tid;
+        if (idx < r1) {
+          nid = point_list[idx];
+          const float4* r = splat + 3 * (size_t)nid;
+          n0 = r[0]; n1 = r[1]; n2 = r[2];
+        }
+      }
+      for (int k = 0; k < kBatch / 64; ++k) {
+        if (k * 64 >= n) break;
+        unsigned long long bits = __ballot((st.smask[buf][k * 64 + lane] >> wave) & 1u);
+        while (bits) {
+          if (__ballot(!done) == 0ull) break;
+          // next (up to) four candidates of this wave, in list order; slot s takes the s-th
+          int jc[4];
+          int nv = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool v = bits != 0ull;
+            jc[q] = v ? (k * 64 + (int)__builtin_ctzll(bits)) : (k * 64);
+            nv += (int)v;
+            bits &= bits - 1ull;
+          }
+          const int j = slot == 0 ? jc[0] : (slot == 1 ? jc[1] : (slot == 2 ? jc[2] : jc[3]));
+          const float4 a = st.s0[buf][j];
+          const float4 b = st.s1[buf][j];
+          const float4 c = st.s2[buf][j];
+          const float dx = a.x - pxf, dy = a.y - pyf;
+          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+          const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
+          const bool g = (slot < nv) & (power <= 0.0f) & (alpha >= GSR_ALPHA_MIN) & !done;
+          // inclusive product of (1 - alpha) over the quad's gated slots
+          float P = g ? (1.0f - alpha) : 1.0f;
+          {
+            const float t1 = gsr_dpp<0x90>(P);           // quad_perm [0,0,1,2]: value of slot-1
+            P = (slot >= 1) ? P * t1 : P;
+            const float t2 = gsr_dpp<0x44>(P);           // quad_perm [0,1,0,1]: value of slot-2
+            P = (slot >= 2) ? P * t2 : P;
+          }
+          const float Pex = gsr_dpp<0x90>(P);
+          const float T_before = (slot >= 1) ? T * Pex : T;
+          const float test_T = T * P;
+          // the first slot (in list order) whose own contribution would drop T below the threshold stops the pixel
+          int sflag = (int)(g & (test_T < GSR_T_MIN));
+          {
+            const int u1 = gsr_dpp_i<0x90>(sflag);
+            sflag |= (slot >= 1) ? u1 : 0;
+            const int u2 = gsr_dpp_i<0x44>(sflag);
+            sflag |= (slot >= 2) ? u2 : 0;
+          }
+          const bool hit = g & (sflag == 0);
+          const float w = hit ? alpha * T_before : 0.0f;
+          C0 = fmaf(b.w, w, C0); C1 = fmaf(c.x, w, C1); C2 = fmaf(c.y, w, C2);
+          Dp = fmaf(b.z, w, Dp);
+          Wt += w;
+          last = hit ? ((base - r0) + (uint32_t)j + 1u) : last;
+          if (SCORE) {
+            // the pixels of the wave that composite slot s's splat: the 16 lanes holding this slot
+            const unsigned long long hm = __ballot(hit) & (0x1111111111111111ull << slot);
             float sc;
             if (score_mode == 0) {
               sc = b.y * (float)__popcll(hm);
             } else {
-              sc = gsr_wave_sum_to_lane63(hit ? alpha * T : 0.f);
-              sc = __shfl(sc, 63, 64);
+              float ws = w;                               // sum over the lanes sharing the slot: xor 4,8,16,32
+              ws += gsr_dpp<0x124>(ws);                   // row_ror:4
+              ws += gsr_dpp<0x128>(ws);                   // row_ror:8
+              ws += __shfl_xor(ws, 16, 64);
+              ws += __shfl_xor(ws, 32, 64);
+              sc = ws;
             }
-            if (lane == 0) unsafeAtomicAdd(score + st.sid[buf][j], sc);
+            if (hm != 0ull && lane == slot && slot < nv) unsafeAtomicAdd(score + st.sid[buf][j], sc);
           }
-        }
-        if (hit) {
-          const float4 c = st.s2[buf][j];
-          const float w = alpha * T;
-          C0 += b.w * w; C1 += c.x * w; C2 += c.y * w;
-          Dp += b.z * w;
-          Wt += w;
-          T = test_T;
-          last = (base - r0) + (uint32_t)j + 1u;
+          // T after the quad: the survivors' T(1-alpha) only decrease along the list -> quad minimum
+          float tn = hit ? test_T : T;
+          tn = fminf(tn, gsr_dpp<0xB1>(tn));              // quad_perm [1,0,3,2]
+          tn = fminf(tn, gsr_dpp<0x4E>(tn));              // quad_perm [2,3,0,1]
+          T = tn;
+          done = done | (gsr_dpp_i<0xFF>(sflag) != 0);    // slot 3 holds the OR over the quad
         }
       }
     }
+    // fold the four slots of each pixel
+    C0 += gsr_dpp<0xB1>(C0); C0 += gsr_dpp<0x4E>(C0);
+    C1 += gsr_dpp<0xB1>(C1); C1 += gsr_dpp<0x4E>(C1);
+    C2 += gsr_dpp<0xB1>(C2); C2 += gsr_dpp<0x4E>(C2);
+    Dp += gsr_dpp<0xB1>(Dp); Dp += gsr_dpp<0x4E>(Dp);
+    Wt += gsr_dpp<0xB1>(Wt); Wt += gsr_dpp<0x4E>(Wt);
+    {
+      int l = (int)last;
+      l = max(l, gsr_dpp_i<0xB1>(l));
+      l = max(l, gsr_dpp_i<0x4E>(l));
+      last = (uint32_t)l;
+    }
+    if (inside && slot == 0) {
+      const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+      final_T[pix] = T;
+      n_contrib[pix] = last;
+      out_color[pix] = C0 + T * bg0;
+      out_color[HW + pix] = C1 + T * bg1;
+      out_color[2 * HW + pix] = C2 + T * bg2;
+      out_da[pix] = Dp;
+      out_da[HW + pix] = Wt;
+    }
+    // deepest contributor of the tile: the backward's cost key and its starting depth
+    const uint32_t wm = gsr_wave_max_u32(last);
+    if (lane == 0 && wm) atomicMax(tile_depth + tile, wm);
   }
-  if (p.inside) {
-    const size_t pix = (size_t)p.py * W + p.px, HW = (size_t)H * W;
-    final_T[pix] = T;
-    n_contrib[pix] = last;
-    out_color[pix] = C0 + T * bg[0];
-    out_color[HW + pix] = C1 + T * bg[1];
-    out_color[2 * HW + pix] = C2 + T * bg[2];
-    out_da[pix] = Dp;
-    out_da[HW + pix] = Wt;
-  }
+  (void)counter; (void)n_tiles;
 }
 
 // --------------------------------------------------------------------------------------------------------- K7
@@ -197,15 +319,27 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 // Accumulates into partials [P,12]:
 //   (dL/dndc_x, dL/dndc_y, dL/dconic_a, dL/dconic_b, dL/dconic_c, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
 __global__ void __launch_bounds__(256)
-k_render_bwd(const int W, const int H, const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+k_render_bwd(const int W, const int H, const uint32_t n_tiles, const uint32_t* __restrict__ work,
+             uint32_t* __restrict__ counter, const uint32_t* __restrict__ tile_depth,
+             const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
              const float4* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_T,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
              const float* __restrict__ dL_dda, float* __restrict__ partials) {
   __shared__ Stage st;
-  __shared__ uint32_t wmax[4];
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
-  const int tile = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+  // lane -> (component slot, scale) of the single atomic that commits a splat's 10 sums (see reduce10)
+  const int rj = lane & 3, rr = lane >> 4;
+  const int comp = 4 * rj + (((rr & 1) << 1) | (rr >> 1));
+  const bool commit = ((lane & 15) < 3) && (comp < 10);
+  const float cscale = comp == 0 ? 0.5f * (float)W : (comp == 1 ? 0.5f * (float)H : 1.0f);
+ {
+  const uint32_t item = blockIdx.x;
+  const int tile = (int)work[item];
+  const uint32_t tile_max = tile_depth[tile];
+  if (tile_max == 0) return;
+  (void)counter; (void)n_tiles;
   const TilePix p = tile_pixel(tile, gx, W, H);
   const int tile_x0 = p.bx - (wave & 1) * 8, tile_y0 = p.by - (wave >> 1) * 8;
   const float pxf = (float)p.px, pyf = (float)p.py;
@@ -219,19 +353,7 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ ranges, cons
     gC0 = dL_dcolor[pix]; gC1 = dL_dcolor[HW + pix]; gC2 = dL_dcolor[2 * HW + pix];
     gD = dL_dda[pix]; gA = dL_dda[HW + pix];
   }
-  const float bg_dot = (bg[0] * gC0 + bg[1] * gC1) + bg[2] * gC2;
-
-  const uint32_t wm = gsr_wave_max_u32(last);
-  if (lane == 0) wmax[wave] = wm;
-  __syncthreads();
-  const uint32_t tile_max = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-  if (tile_max == 0) return;
-
-  // lane -> (component slot, scale) of the single atomic that commits a splat's 10 sums (see reduce10)
-  const int rj = lane & 3, rr = lane >> 4;
-  const int comp = 4 * rj + (((rr & 1) << 1) | (rr >> 1));
-  const bool commit = ((lane & 15) < 3) && (comp < 10);
-  const float cscale = comp == 0 ? 0.5f * (float)W : (comp == 1 ? 0.5f * (float)H : 1.0f);
+  const float bg_dot = (bg0 * gC0 + bg1 * gC1) + bg2 * gC2;
 
   float T = Tf;
   float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, rc0 = 0.f, rc1 = 0.f, rc2 = 0.f;
@@ -312,22 +434,39 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ ranges, cons
       }
     }
   }
+ }
 }
 
 }  // namespace
+
+// persistent grid: workgroups per CU chosen so that every SIMD holds ~4 waves; CU count cached per device
+static int persistent_groups(int per_cu) {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t p;
+    cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return cus[dev] * per_cu;
+}
 
 int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, GsrImages& img,
                           hipStream_t stream) {
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
   const float4* splat = reinterpret_cast<const float4*>(geom.splat);
+  uint32_t* work = b.tile_work;
+  uint32_t* counter = b.tile_work + tiles;
+  hipLaunchKernelGGL(k_work_order<0>, dim3(1), dim3(1024), 0, stream, tiles, b.ranges, img.tile_depth, work);
+  const uint32_t grid = tiles * 4;
   if (img.important_score) {
-    hipLaunchKernelGGL(k_render_fwd<true>, dim3(tiles), dim3(256), 0, stream, v.image_width, v.image_height,
-                       b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T, img.n_contrib,
-                       img.important_score, v.score_mode);
+    hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, tiles,
+                       work, counter, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T,
+                       img.n_contrib, img.tile_depth, img.important_score, v.score_mode);
   } else {
-    hipLaunchKernelGGL(k_render_fwd<false>, dim3(tiles), dim3(256), 0, stream, v.image_width, v.image_height,
-                       b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T, img.n_contrib,
-                       (float*)nullptr, 0);
+    hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, tiles,
+                       work, counter, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T,
+                       img.n_contrib, img.tile_depth, (float*)nullptr, 0);
   }
   GSR_HIP(hipGetLastError());
   return GSR_OK;
@@ -336,9 +475,13 @@ int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinnin
 int gsr_launch_render_bwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, const GsrImages& img,
                           const GsrImageGrads& ig, GsrGrads& out, hipStream_t stream) {
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
-  hipLaunchKernelGGL(k_render_bwd, dim3(tiles), dim3(256), 0, stream, v.image_width, v.image_height, b.ranges,
-                     b.point_list, reinterpret_cast<const float4*>(geom.splat), v.bg, img.final_T, img.n_contrib,
-                     ig.dL_dcolor, ig.dL_ddepth_alpha, out.partials);
+  uint32_t* work = b.tile_work;
+  uint32_t* counter = b.tile_work + tiles;
+  hipLaunchKernelGGL(k_work_order<1>, dim3(1), dim3(1024), 0, stream, tiles, b.ranges, img.tile_depth, work);
+  const uint32_t grid = tiles;
+  hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, tiles, work,
+                     counter, img.tile_depth, b.ranges, b.point_list, reinterpret_cast<const float4*>(geom.splat), v.bg,
+                     img.final_T, img.n_contrib, ig.dL_dcolor, ig.dL_ddepth_alpha, out.partials);
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }

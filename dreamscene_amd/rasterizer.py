@@ -172,7 +172,8 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
             """One allocation for everything the backward re-reads (splat, tile counts, offsets, lists, ranges,
             final_T, n_contrib); carved by offsets, no per-tensor allocations."""
             sizes = dict(splat=Pm * 48, tiles_touched=Pm * 4, block_offsets=(nb + 4) * 4, point_list=max(cap, 1) * 4,
-                         ranges=tiles * 8, final_T=H * W * 4, n_contrib=H * W * 4,
+                         ranges=tiles * 8, tile_work=(tiles + 4) * 4, tile_depth=tiles * 4, final_T=H * W * 4,
+                         n_contrib=H * W * 4,
                          keys_sorted=(max(cap, 1) * 8 if want_keys else 0))
             offs, tot = {}, 0
             for k, sz in sizes.items():
@@ -193,11 +194,12 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
             geom.scratch, geom.scratch_bytes = proj_scratch.data_ptr(), proj_scratch.numel()
             sort_bytes = int(lib.gsr_sort_scratch_bytes(cap, tiles))
             sort_scratch = ws.scratch("sort_scratch", sort_bytes)
-            b.point_list, b.ranges = ptrs["point_list"], ptrs["ranges"]
+            b.point_list, b.ranges, b.tile_work = ptrs["point_list"], ptrs["ranges"], ptrs["tile_work"]
             b.keys_sorted = ptrs["keys_sorted"] if want_keys else None
             b.scratch, b.scratch_bytes, b.count_on_device = sort_scratch.data_ptr(), sort_scratch.numel(), int(on_device)
-            im.final_T, im.n_contrib = ptrs["final_T"], ptrs["n_contrib"]
+            im.final_T, im.n_contrib, im.tile_depth = ptrs["final_T"], ptrs["n_contrib"], ptrs["tile_depth"]
 
+        NSIZED = ("point_list", "ranges", "tile_work", "tile_depth", "final_T", "n_contrib", "keys_sorted")
         n_pairs = C.c_uint64(0)
         if hint is None:
             # exact two-phase forward: project (+ one host sync for N), then allocate exactly, then render
@@ -210,14 +212,13 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
             buf2, ptrs2, offs2 = alloc_state(cap)
             # keep the projected state (splat / tile counts / offsets) from the first buffer: re-point only the
             # N-sized and per-pixel regions into the second one
-            for k in ("point_list", "ranges", "final_T", "n_contrib", "keys_sorted"):
+            for k in NSIZED:
                 ptrs[k] = ptrs2[k]
             bind(ptrs, cap, False)
             L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), N, C.byref(b), C.byref(im), stream, prof),
                     "gsr_forward_render")
             keep_bufs = (buf, buf2)
-            view_src = {k: (buf2, offs2[k]) if k in ("point_list", "ranges", "final_T", "n_contrib", "keys_sorted")
-                        else (buf, offs[k]) for k in offs}
+            view_src = {k: (buf2, offs2[k]) if k in NSIZED else (buf, offs[k]) for k in offs}
         else:
             cap = int(hint * 1.5) + 65536
             buf, ptrs, offs = alloc_state(cap)
@@ -237,7 +238,7 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
             if N > cap:
                 # speculation too small: redo binning + render exactly (projection results are still valid)
                 buf2, ptrs2, offs2 = alloc_state(N)
-                for k in ("point_list", "ranges", "final_T", "n_contrib", "keys_sorted"):
+                for k in NSIZED:
                     ptrs[k] = ptrs2[k]
                     view_src[k] = (buf2, offs2[k])
                 bind(ptrs, N, False)

@@ -95,6 +95,8 @@ typedef struct GsrGeom {
 typedef struct GsrBinning {
   uint32_t* point_list; /* [N] Gaussian index per (tile, depth)-sorted pair                         */
   uint32_t* ranges;     /* [tiles,2] (start,end) into point_list; (0,0) for an empty tile            */
+  uint32_t* tile_work;  /* [tiles+4] work list of the persistent render kernels (tile ids, heaviest first) and their
+                           work counter; rewritten by forward and by backward: keep it with the saved state      */
   uint64_t* keys_sorted;/* [N] optional: receives the sorted 64-bit keys (tile<<32 | depth bits); may be NULL */
   void* scratch;        /* gsr_sort_scratch_bytes(N, tiles) bytes, 256-byte aligned                   */
   size_t scratch_bytes;
@@ -112,6 +114,7 @@ typedef struct GsrImages {
   float* depth_alpha;     /* [2,H,W]: plane 0 = sum z_i a_i T_i, plane 1 = sum a_i T_i        */
   float* final_T;         /* [H,W] transmittance after the last contributor                  */
   uint32_t* n_contrib;    /* [H,W] 1-based list position of the last contributor             */
+  uint32_t* tile_depth;   /* [tiles] max of n_contrib over the tile (written by forward, read by backward) */
   float* important_score; /* [P] zero-initialised by the caller, or NULL (score_flag False)   */
 } GsrImages;
 
