@@ -21,8 +21,8 @@
 namespace {
 
 constexpr int kSortThreads = 256;
-constexpr int kSortItems = 16;                       // keys per thread
-constexpr int kSortTile = kSortThreads * kSortItems; // 4096 keys per workgroup
+constexpr int kItemsLarge = 16;   // keys per thread for the N-sized tile sort (4096 keys / workgroup)
+constexpr int kItemsSmall = 4;    // ... for the P-sized depth sort: 4x more workgroups, 4x shorter rank chains
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 
@@ -35,8 +35,9 @@ __device__ __forceinline__ uint64_t eff_count(const uint64_t* n_dev, uint64_t ca
 // ---------------------------------------------------------------------------------------------- radix sort
 // One LSD pass = histogram -> per-digit exclusive scan over workgroups -> stable scatter.
 // Element order inside a workgroup: e = blk*4096 + wave*1024 + item*64 + lane.
+template <int ITEMS>
 __device__ __forceinline__ uint64_t sort_index(uint32_t blk, int wave, int item, int lane) {
-  return (uint64_t)blk * kSortTile + (uint64_t)(wave * (64 * kSortItems) + item * 64 + lane);
+  return (uint64_t)blk * (kSortThreads * ITEMS) + (uint64_t)(wave * (64 * ITEMS) + item * 64 + lane);
 }
 
 // lanes of the wave holding the same 8-bit digit as this lane (among `valid` lanes)
@@ -51,6 +52,7 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
   return m;
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev, uint64_t cap, int shift,
              uint32_t nblk, uint32_t* __restrict__ hist) {
@@ -59,10 +61,10 @@ k_radix_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_d
   const uint64_t n = eff_count(n_dev, cap);
   h[tid] = 0;
   __syncthreads();
-  if ((uint64_t)blockIdx.x * kSortTile < n) {
+  if ((uint64_t)blockIdx.x * (kSortThreads * ITEMS) < n) {
 #pragma unroll 4
-    for (int it = 0; it < kSortItems; ++it) {
-      const uint64_t e = sort_index(blockIdx.x, wave, it, lane);
+    for (int it = 0; it < ITEMS; ++it) {
+      const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
       const bool valid = e < n;
       const uint32_t d = valid ? ((keys[e] >> shift) & (kRadix - 1)) : 0u;
       const unsigned long long m = match_digit(d, valid);
@@ -118,7 +120,7 @@ __global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist,
 }
 
 // IOTA: values are the element indices themselves (first pass of the depth sort), vals_in unused.
-template <bool IOTA>
+template <bool IOTA, int ITEMS>
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint64_t* __restrict__ n_dev,
@@ -129,7 +131,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
   __shared__ uint32_t wtot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t n = eff_count(n_dev, cap);
-  if ((uint64_t)blockIdx.x * kSortTile >= n) return;
+  if ((uint64_t)blockIdx.x * (kSortThreads * ITEMS) >= n) return;
 #pragma unroll
   for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
   {
@@ -148,20 +150,20 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
   }
   __syncthreads();
   volatile uint32_t* mywh = wh[wave];
-  uint32_t key[kSortItems];
-  uint32_t val[kSortItems];
-  uint32_t rank[kSortItems];
+  uint32_t key[ITEMS];
+  uint32_t val[ITEMS];
+  uint32_t rank[ITEMS];
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int it = 0; it < kSortItems; ++it) {
-    const uint64_t e = sort_index(blockIdx.x, wave, it, lane);
+  for (int it = 0; it < ITEMS; ++it) {
+    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
     const bool valid = e < n;
     key[it] = valid ? keys_in[e] : 0xFFFFFFFFu;
     val[it] = IOTA ? (uint32_t)e : (valid ? vals_in[e] : 0u);
   }
 #pragma unroll
-  for (int it = 0; it < kSortItems; ++it) {
-    const uint64_t e = sort_index(blockIdx.x, wave, it, lane);
+  for (int it = 0; it < ITEMS; ++it) {
+    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
     const bool valid = e < n;
     const uint32_t d = (key[it] >> shift) & (kRadix - 1);
     const unsigned long long m = match_digit(d, valid);
@@ -186,8 +188,8 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
   }
   __syncthreads();
 #pragma unroll
-  for (int it = 0; it < kSortItems; ++it) {
-    const uint64_t e = sort_index(blockIdx.x, wave, it, lane);
+  for (int it = 0; it < ITEMS; ++it) {
+    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
     if (e < n) {
       const uint32_t d = (key[it] >> shift) & (kRadix - 1);
       const uint32_t pos = wh[wave][d] + rank[it];
@@ -335,29 +337,39 @@ k_rebuild_keys(const uint32_t* __restrict__ tile_keys, const uint32_t* __restric
 
 __host__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-uint32_t sort_blocks(uint64_t n) { return (uint32_t)((n + kSortTile - 1) / kSortTile); }
+uint32_t sort_blocks(uint64_t n, int items) {
+  const uint64_t t = (uint64_t)kSortThreads * items;
+  return (uint32_t)((n + t - 1) / t);
+}
 
-// One full LSD sort of (u32 key, u32 value) over `bits` key bits. Buffers ping-pong between (k0,v0) and (k1,v1);
-// returns 0 if the result is in (k0,v0), 1 if in (k1,v1). iota: values of the first pass are the indices.
+// One full LSD sort of (u32 key, u32 value) over the key bits [0, bits). Buffers ping-pong between (k0,v0) and
+// (k1,v1); returns 0 if the result is in (k0,v0), 1 if in (k1,v1). iota: values of the first executed pass are
+// the element indices. skip_mask: bit p set = digit p is identical in all keys, the pass is the identity: skipped.
+template <int ITEMS>
 int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
-                   int bits, bool iota, uint32_t* hist, uint32_t* totals, hipStream_t stream) {
-  const uint32_t nblk = sort_blocks(cap);
+                   int bits, bool iota, uint32_t skip_mask, uint32_t* hist, uint32_t* totals, hipStream_t stream) {
+  const uint32_t nblk = sort_blocks(cap, ITEMS);
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
   uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
+  int flips = 0;
+  bool first = true;
   for (int p = 0; p < passes; ++p) {
+    if ((skip_mask >> p) & 1u) continue;
     const int shift = p * kRadixBits;
-    hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift, nblk, hist);
+    hipLaunchKernelGGL(k_radix_hist<ITEMS>, dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift, nblk, hist);
     hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals);
-    if (iota && p == 0)
-      hipLaunchKernelGGL(k_radix_scatter<true>, dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap,
-                         shift, nblk, hist, totals);
+    if (iota && first)
+      hipLaunchKernelGGL((k_radix_scatter<true, ITEMS>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb,
+                         n_dev, cap, shift, nblk, hist, totals);
     else
-      hipLaunchKernelGGL(k_radix_scatter<false>, dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev,
-                         cap, shift, nblk, hist, totals);
+      hipLaunchKernelGGL((k_radix_scatter<false, ITEMS>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb,
+                         n_dev, cap, shift, nblk, hist, totals);
+    first = false;
     uint32_t* t = ka; ka = kb; kb = t;
     t = va; va = vb; vb = t;
+    ++flips;
   }
-  return passes & 1;
+  return flips & 1;
 }
 
 }  // namespace
@@ -370,14 +382,14 @@ extern "C" uint32_t gsr_num_blocks(int32_t P) { return (uint32_t)((P + 255) / 25
 // Scratch of the projection stage (depth sort): keys x2, values x2 (one of them becomes sorted_idx), histograms.
 extern "C" size_t gsr_project_scratch_bytes(int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
-  return 4 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m) * 4) + align256(kRadix * 4) + 1024;
+  return 4 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4) + align256(kRadix * 4) + 1024;
 }
 
 // Scratch of the binning stage: tile keys x2, one value ping buffer, histograms.
 extern "C" size_t gsr_sort_scratch_bytes(uint64_t n, uint32_t n_tiles) {
   (void)n_tiles;
   const uint64_t m = n ? n : 1;
-  return 3 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m) * 4) + align256(kRadix * 4) + 1024;
+  return 3 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m, kItemsLarge) * 4) + align256(kRadix * 4) + 1024;
 }
 
 struct ProjectScratch {
@@ -391,7 +403,7 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
   s.k1 = (uint32_t*)b; b += align256(m * 4);
   s.v0 = (uint32_t*)b; b += align256(m * 4);
   s.v1 = (uint32_t*)b; b += align256(m * 4);
-  s.hist = (uint32_t*)b; b += align256((size_t)kRadix * sort_blocks(m) * 4);
+  s.hist = (uint32_t*)b; b += align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4);
   s.totals = (uint32_t*)b;
   return s;
 }
@@ -399,12 +411,14 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
 uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).k0; }
 
 // After K1 (which wrote the depth keys into scratch.k0): depth sort, depth-ordered block sums, scan -> N.
-int gsr_launch_depth_order(GsrGeom& geom, int32_t P, uint64_t* n_pairs_dev, hipStream_t stream, GsrProfile* prof) {
+int gsr_launch_depth_order(GsrGeom& geom, int32_t P, uint64_t* n_pairs_dev, uint32_t depth_skip_mask, hipStream_t stream,
+                           GsrProfile* prof) {
   if (geom.scratch_bytes < gsr_project_scratch_bytes(P) || !geom.scratch) return GSR_ESCRATCH;
   ProjectScratch s = carve_project(geom.scratch, P);
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    const int where = radix_sort_u32(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, s.hist, s.totals, stream);
+    const int where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, depth_skip_mask,
+                                                   s.hist, s.totals, stream);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }
@@ -432,7 +446,7 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
   uint32_t* keys_a = (uint32_t*)base; base += align256(cap * 4);
   uint32_t* keys_b = (uint32_t*)base; base += align256(cap * 4);
   uint32_t* vals_t = (uint32_t*)base; base += align256(cap * 4);
-  uint32_t* hist = (uint32_t*)base; base += align256((size_t)kRadix * sort_blocks(cap) * 4);
+  uint32_t* hist = (uint32_t*)base; base += align256((size_t)kRadix * sort_blocks(cap, kItemsLarge) * 4);
   uint32_t* totals = (uint32_t*)base;
 
   int tile_bits = 0;
@@ -452,7 +466,8 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
   uint32_t* sorted_keys;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    const int where = radix_sort_u32(keys_a, va, keys_b, vb, n_dev, cap, tile_bits, false, hist, totals, stream);
+    const int where = radix_sort_u32<kItemsLarge>(keys_a, va, keys_b, vb, n_dev, cap, tile_bits, false, 0u, hist, totals,
+                                                   stream);
     sorted_keys = where ? keys_b : keys_a;
     GSR_HIP(hipGetLastError());
   }
