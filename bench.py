@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """bench.py -- fwd+bwd views/s of the MI355X-native Gaussian rasterizer on BASELINE.json's metric config.
 
-A "step" = one pass of the hot path over one view per GPU: GaussianRasterizer forward (K1-K6) + backward
-(K7-K8) from fixed upstream gradients on image and depth_alpha, through the same nn.Module / autograd boundary
-the reference calls (scene_gaussian.py:966-1021). With N GPUs every rank renders its own view of the same
-Gaussians and the parameter gradients are summed with one in-place RCCL all-reduce (weak scaling: per-GPU work
-is fixed). Inputs are synthetic (dreamscene_amd/synth.py), resident in HBM before the timed region.
+A "step" = one pass of the hot path over one batch of views: every GPU renders `--views-per-step` views
+(default 4 = the reference's C_batch_size, configs/objects/sample.yaml:60, training/object_trainer.py:302-382:
+4 views are rendered and their gradients accumulated before each optimizer step), each view being one
+GaussianRasterizer forward (K1-K6) + backward (K7-K8) from fixed upstream gradients on image and depth_alpha,
+through the same nn.Module / autograd boundary the reference calls (scene_gaussian.py:966-1021). The per-view
+parameter gradients are summed on the device (K8 accumulate mode) and, with N GPUs, the sums are combined by ONE
+in-place RCCL all-reduce per step (weak scaling: per-GPU work is fixed). `value` = views/s over all ranks.
+Inputs are synthetic (dreamscene_amd/synth.py), resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the dominant kernel
 (HIP events on the launch stream, via the library's GsrProfile) and `cpu_baseline` (scalar C oracle, N=1 only).
@@ -52,6 +55,7 @@ def main():
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--scene", choices=["object", "indoor"], default="object")
     ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--views-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -81,28 +85,42 @@ def main():
         cams = synth.indoor_cameras(8, H, W)
         workload = f"G-indoor {g['means3D'].shape[0]} Gaussians (K=4, SH degree 1), 1 in-room view/GPU @{W}x{H}, fwd+bwd"
     P = g["means3D"].shape[0]
-    cam = cams[rank % len(cams)]
+    V = max(1, args.views_per_step)
     params = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items()}
     gi_np, gda_np = synth.upstream_grads(H, W, seed=rank)
     gi, gda = torch.tensor(gi_np, device=dev), torch.tensor(gda_np, device=dev)
     t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)
-    settings = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=t([1.0, 1.0, 1.0]),
-        scale_modifier=1.0, viewmatrix=t(cam.world_view_transform), projmatrix=t(cam.full_proj_transform),
-        sh_degree=D, campos=t(cam.camera_center), prefiltered=False, score_flag=False)
-    rast = GaussianRasterizer(raster_settings=settings)
+    # view j of rank r: camera (r * V + j) of the orbit; view 0 of rank 0 is the C3 camera
+    my_cams = [cams[(rank * V + j) % len(cams)] for j in range(V)]
+    cam = my_cams[0]
+    rasts = []
+    for c in my_cams:
+        st_ = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=t([1.0, 1.0, 1.0]),
+            scale_modifier=1.0, viewmatrix=t(c.world_view_transform), projmatrix=t(c.full_proj_transform),
+            sh_degree=D, campos=t(c.camera_center), prefiltered=False, score_flag=False)
+        rasts.append(GaussianRasterizer(raster_settings=st_))
+    settings = rasts[0].raster_settings
     arena = multiview.GradArena(P, K, dev)
     R.GRAD_ARENA = arena
     leaves = [params[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
 
     def step():
-        means2D = torch.zeros_like(params["means3D"], requires_grad=True)
-        img, radii, da = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
-                              opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"],
-                              cov3D_precomp=None)
-        grads = torch.autograd.grad([img, da], leaves + [means2D], [gi, gda])
+        out0 = None
+        for j, rast in enumerate(rasts):
+            means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+            img, radii, da = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
+                                  opacities=params["opacities"], scales=params["scales"],
+                                  rotations=params["rotations"], cov3D_precomp=None)
+            R.ACCUMULATE = j > 0          # views 2..V are added to the arena on the device
+            grads = torch.autograd.grad([img, da], leaves + [means2D], [gi, gda])
+            if j == 0:
+                out0 = (img, da, radii, [x.clone() for x in grads] if capture[0] else grads)
+        R.ACCUMULATE = False
         multiview.allreduce_grads(arena)
-        return img, da, radii, grads
+        return out0
+
+    capture = [False]
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -153,7 +171,7 @@ def main():
                                            params["scales"], params["rotations"], None)
         N_pairs = int(o["N"])
         if cnt:
-            cnt = args.steps                          # per view (a stage may launch several kernels per view)
+            cnt = args.steps * V                      # per view (a stage may launch several kernels per view)
             avg_s = ms / cnt * 1e-3
             ab = algorithmic_bytes(dominant, P, N_pairs, H * W, K, D)
             achieved = ab / avg_s / 1e9
@@ -172,10 +190,13 @@ def main():
     cpu_baseline = None
     grad_err = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        capture[0] = True                 # one more (untimed) step keeping view 0's own gradients for the check
+        out = step()
+        torch.cuda.synchronize(dev)
         cpu_baseline, grad_err = cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, out)
 
     if rank == 0:
-        views = world * args.steps
+        views = world * args.steps * V
         line = {
             "metric": f"fwd+bwd views/s @{W}x{H}, {P} Gaussians",
             "value": round(views / elapsed, 3),
@@ -190,8 +211,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "gaussians": P, "resolution": [H, W], "tile_pairs_N": N_pairs,
-                       "parallelism": f"1 view/GPU x {world}, grads summed by 1 RCCL all-reduce ({arena.nbytes()} B)"
-                       if world > 1 else "single GPU"},
+                       "views_per_step_per_gpu": V,
+                       "parallelism": f"{V} view(s)/GPU/step x {world} GPUs, gradients summed on the device, then 1 RCCL "
+                                      f"all-reduce of {arena.nbytes()} B per step" if world > 1 else
+                                      f"single GPU, {V} view(s) per step, gradients summed on the device"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "max_grad_err_vs_oracle": grad_err,
@@ -201,7 +224,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out):
+def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, hip_n_contrib=None):
     """Times the scalar C oracle (a CPU port of the same algorithm; the reference has no CPU path)
     on ONE fwd+bwd view of the same workload, single thread, and reuses that run to report the HIP path's max
     gradient error at the full benchmark size."""
@@ -216,17 +239,25 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out):
     dt = time.perf_counter() - t0
     img, da, radii, grads = hip_out
     names = ["dL_dmeans3D", "dL_dshs", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]
-    worst = 0.0
+    worst, worst_frac, per = 0.0, 0.0, {}
     for n, gt in zip(names, grads):
         ref = np.asarray(b[n], dtype=np.float64).reshape(-1)
-        e = float(np.abs(gt.detach().cpu().numpy().astype(np.float64).reshape(-1) - ref).max())
-        worst = max(worst, e / max(1.0, float(np.abs(ref).max())))
-    img_err = float(np.abs(img.detach().cpu().numpy() - f["image"]).max())
+        e = np.abs(gt.detach().cpu().numpy().astype(np.float64).reshape(-1) - ref)
+        scale = max(1.0, float(np.abs(ref).max()))
+        per[n] = {"max_err_over_scale": float(e.max() / scale), "frac_over_1e-5": float((e > 1e-5 * scale).mean())}
+        worst = max(worst, per[n]["max_err_over_scale"])
+        worst_frac = max(worst_frac, per[n]["frac_over_1e-5"])
+    d_img = np.abs(img.detach().cpu().numpy() - f["image"]).max(axis=0)
+    nc_diff = int((hip_n_contrib != f["n_contrib"]).sum()) if hip_n_contrib is not None else None
     base = {"value": round(1.0 / dt, 5), "unit": "views/s", "cores": 1, "kind": "port",
             "sample": f"1 fwd+bwd view of the same workload ({P} Gaussians @{W}x{H}) through oracle/gsr_oracle.c, "
                       f"single thread, {dt:.1f} s; host has {os.cpu_count()} cores"}
-    return base, {"grads_rel_to_max1": worst, "image_abs": img_err,
-                  "bit_exact_radii": bool(np.array_equal(radii.cpu().numpy(), f["radii"]))}
+    # hard gates (alpha < 1/255, T < 1e-4) put a few (pixel, splat) pairs on the other side of a rounding
+    # difference at this size (SEMANTICS.md section 6): report how many pixels / entries, not only the max
+    return base, {"bit_exact_radii": bool(np.array_equal(radii.cpu().numpy(), f["radii"])),
+                  "image_max_abs": float(d_img.max()), "image_frac_pixels_over_1e-5": float((d_img > 1e-5).mean()),
+                  "grads_max_err_over_max1": worst, "grads_max_frac_entries_over_1e-5": worst_frac,
+                  "per_tensor": per, "tol": "1e-5 * max(1, max|ref|)"}
 
 
 if __name__ == "__main__":

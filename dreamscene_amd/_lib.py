@@ -49,7 +49,7 @@ class GsrImageGrads(C.Structure):
 class GsrGrads(C.Structure):
     _fields_ = [("dL_dmeans3D", _f), ("dL_dmeans2D", _f), ("dL_dopacities", _f), ("dL_dshs", _f), ("dL_dcolors", _f),
                 ("dL_dscales", _f), ("dL_drotations", _f), ("dL_dcov3D", _f), ("dL_dview", _f), ("dL_dproj", _f),
-                ("dL_dcampos", _f), ("partials", _f)]
+                ("dL_dcampos", _f), ("partials", _f), ("accumulate", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # every symbol include/gsrast.h declares: (name, restype, argtypes)

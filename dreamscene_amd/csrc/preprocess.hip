@@ -157,7 +157,7 @@ __device__ __forceinline__ void stage_sh_in(const float* __restrict__ shs, int64
 
 // LDS -> global coalesced store of the wave's [n_valid, 3K] block.
 __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64_t wave_first, int n_valid, int K,
-                                             const float* lds_wave) {
+                                             const float* lds_wave, bool accumulate) {
   const int F = 3 * K;
   const int stride = sh_lds_stride(K);
   const int total = n_valid * F;
@@ -172,10 +172,15 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64
       e[k] = (f < total) ? lds_wave[g * stride + o] : 0.f;
     }
     if (q + 3 < total) {
-      *reinterpret_cast<float4*>(dst + q) = make_float4(e[0], e[1], e[2], e[3]);
+      float4 o = make_float4(e[0], e[1], e[2], e[3]);
+      if (accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(dst + q);
+        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+      }
+      *reinterpret_cast<float4*>(dst + q) = o;
     } else {
       for (int k = 0; k < 4; ++k)
-        if (q + k < total) dst[q + k] = e[k];
+        if (q + k < total) dst[q + k] = accumulate ? dst[q + k] + e[k] : e[k];
     }
   }
 }
@@ -407,7 +412,7 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (out.dL_dshs) stage_sh_out(out.dL_dshs, wave_first, n_valid, K, lw);
+    if (out.dL_dshs) stage_sh_out(out.dL_dshs, wave_first, n_valid, K, lw, out.accumulate != 0);
   }
 
   float dscale[3] = {0.f, 0.f, 0.f};
@@ -526,10 +531,30 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
   }
 
   if (i < P) {
+    float gop_o = gop;
+    if (out.accumulate) {
+      // sum over views on the device (the reference accumulates C_batch_size views per optimizer step,
+      // training/object_trainer.py:302-382); means2D is per view and is never accumulated
+      dp[0] += out.dL_dmeans3D[3 * i]; dp[1] += out.dL_dmeans3D[3 * i + 1]; dp[2] += out.dL_dmeans3D[3 * i + 2];
+      gop_o += out.dL_dopacities[i];
+      if (out.dL_dscales) { dscale[0] += out.dL_dscales[3 * i]; dscale[1] += out.dL_dscales[3 * i + 1]; dscale[2] += out.dL_dscales[3 * i + 2]; }
+      if (out.dL_drotations) {
+        const float4 o = *reinterpret_cast<const float4*>(out.dL_drotations + 4 * i);
+        drot[0] += o.x; drot[1] += o.y; drot[2] += o.z; drot[3] += o.w;
+      }
+      if (out.dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dc6[k] += out.dL_dcov3D[6 * i + k];
+      }
+    }
     out.dL_dmeans3D[3 * i] = dp[0]; out.dL_dmeans3D[3 * i + 1] = dp[1]; out.dL_dmeans3D[3 * i + 2] = dp[2];
     out.dL_dmeans2D[3 * i] = gndx; out.dL_dmeans2D[3 * i + 1] = gndy; out.dL_dmeans2D[3 * i + 2] = 0.f;
-    out.dL_dopacities[i] = gop;
-    if (out.dL_dcolors) { out.dL_dcolors[3 * i] = grgb[0]; out.dL_dcolors[3 * i + 1] = grgb[1]; out.dL_dcolors[3 * i + 2] = grgb[2]; }
+    out.dL_dopacities[i] = gop_o;
+    if (out.dL_dcolors) {
+      float c0 = grgb[0], c1 = grgb[1], c2 = grgb[2];
+      if (out.accumulate) { c0 += out.dL_dcolors[3 * i]; c1 += out.dL_dcolors[3 * i + 1]; c2 += out.dL_dcolors[3 * i + 2]; }
+      out.dL_dcolors[3 * i] = c0; out.dL_dcolors[3 * i + 1] = c1; out.dL_dcolors[3 * i + 2] = c2;
+    }
     if (out.dL_dscales) { out.dL_dscales[3 * i] = dscale[0]; out.dL_dscales[3 * i + 1] = dscale[1]; out.dL_dscales[3 * i + 2] = dscale[2]; }
     if (out.dL_drotations) *reinterpret_cast<float4*>(out.dL_drotations + 4 * i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
     if (out.dL_dcov3D) {

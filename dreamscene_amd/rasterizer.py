@@ -46,6 +46,9 @@ PROFILE: Optional[L.Profile] = None
 # optional multiview.GradArena: when set, the autograd backward writes the parameter gradients of the view
 # straight into the arena's flat buffer (zero-copy hand-off to the RCCL all-reduce) and returns views of it
 GRAD_ARENA = None
+# with a GRAD_ARENA: False = this view's gradients overwrite the arena, True = they are ADDED to it on the device
+# (sum over the views of one optimizer step before a single all-reduce)
+ACCUMULATE = False
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -272,7 +275,8 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     return out, st
 
 
-def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool = False, arena=None) -> dict:
+def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool = False, arena=None,
+                           accumulate: bool = False) -> dict:
     lib = L.load()
     dev, P, K = st.dev, st.P, st.K
     dL_dcolor = _prep(dL_dcolor, "dL_dcolor", dev)
@@ -301,6 +305,7 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
     for k, t in o.items():
         setattr(gr, k, _ptr(t))
     gr.partials = partials.data_ptr()
+    gr.accumulate = int(bool(accumulate and arena is not None))
     ig = L.GsrImageGrads()
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -337,7 +342,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_color = torch.zeros((3, H, W), dtype=torch.float32, device=st.dev)
         if g_da is None:
             g_da = torch.zeros((2, H, W), dtype=torch.float32, device=st.dev)
-        o = rasterize_backward_raw(st, g_color, g_da, arena=GRAD_ARENA)
+        o = rasterize_backward_raw(st, g_color, g_da, arena=GRAD_ARENA, accumulate=ACCUMULATE)
         return (o["dL_dmeans3D"], o["dL_dmeans2D"], o["dL_dshs"], o["dL_dcolors"],
                 o["dL_dopacities"].reshape(ctx.opac_shape), o["dL_dscales"], o["dL_drotations"], o["dL_dcov3D"], None)
 

@@ -124,7 +124,7 @@ typedef struct GsrImageGrads {
 } GsrImageGrads;
 
 /* Gradients w.r.t. the forward inputs. NULL = not wanted (must be NULL where the input was NULL).
- * Every non-NULL output is fully overwritten (zeros for culled Gaussians). dL_dview / dL_dproj /
+ * Every non-NULL output is fully overwritten (zeros for culled Gaussians) unless `accumulate`. dL_dview / dL_dproj /
  * dL_dcampos treat viewmatrix, projmatrix and campos as three independent inputs. */
 typedef struct GsrGrads {
   float* dL_dmeans3D;   /* [P,3]                                                                     */
@@ -139,6 +139,10 @@ typedef struct GsrGrads {
   float* dL_dproj;      /* [16] or NULL; zero-initialised by the caller                              */
   float* dL_dcampos;    /* [3]  or NULL; zero-initialised by the caller                              */
   float* partials;      /* scratch [P,12]: per-Gaussian screen-space gradient accumulators           */
+  int32_t accumulate;   /* 0: overwrite the parameter gradients; 1: ADD this view's gradients to what the buffers
+                           hold (device-side sum over the views of one optimizer step). dL_dmeans2D is per view
+                           and always overwritten; dL_dview/proj/campos always accumulate                     */
+  int32_t reserved_;
 } GsrGrads;
 
 /* Optional per-stage timing with HIP events on the caller's stream (bench.py uses it for `roofline`). */

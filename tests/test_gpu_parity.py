@@ -257,3 +257,34 @@ def test_capacity_mode_matches_exact(built_lib):
         assert o["N"] == ref["N"]
         for k in ("color", "depth_alpha", "radii", "point_list", "ranges", "keys_sorted", "final_T", "n_contrib"):
             assert torch.equal(o[k], ref[k]), k
+
+
+def test_device_side_accumulation_over_views(built_lib, c_oracle):
+    """K8 accumulate mode + GradArena: the sum over the views of one optimizer step is formed on the device and
+    equals the sum of the per-view oracle gradients (what autograd's accumulation does in the reference loop)."""
+    from dreamscene_amd import multiview, rasterizer as R, synth
+    P, H, W, K, D = 1200, 64, 80, 16, 2
+    g, _ = small_scene(P=P, H=H, W=W, K=K, seed=71)
+    cams = synth.object_cameras(3, H, W, radius=3.0)
+    bg = np.array([1.0, 1.0, 1.0], np.float32)
+    t = _to_dev(g)
+    arena = multiview.GradArena(P, K, torch.device(DEV))
+    ref = {k: 0.0 for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dshs")}
+    for j, cam in enumerate(cams):
+        gi, gda = synth.upstream_grads(H, W, j)
+        s = settings_for(cam, bg, D, DEV)
+        _, st = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None,
+                                        want_aux=False)
+        R.rasterize_backward_raw(st, torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV), arena=arena,
+                                 accumulate=j > 0)
+        v = oracle_view(c_oracle, cam, P, K, D, bg)
+        f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        b = c_oracle.backward(v, f, gi, gda, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        for k in ref:
+            ref[k] = ref[k] + np.asarray(b[k], dtype=np.float64)
+    torch.cuda.synchronize()
+    for ak, rk in [("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                   ("opacities", "dL_dopacity"), ("shs", "dL_dshs")]:
+        a = arena.views[ak].cpu().numpy().reshape(-1)
+        r = ref[rk].reshape(-1)
+        assert err(a, r) <= TOL * max(1.0, float(np.abs(r).max())), ak
