@@ -21,8 +21,13 @@
 // Semantics: SURVEY.md Appendix A.2 / A.3, SEMANTICS.md; outputs as consumed at scene_gaussian.py:1012-1032.
 #include "gsr_common.h"
 
-#ifndef GSR_FAST_EXP
-#define GSR_FAST_EXP 1
+// exp() in the compositing loops. The hard gates (alpha < 1/255, T < 1e-4) make the result sensitive to the last
+// bits of exp: with the 2-instruction __expf (error ~ 5e-7 relative, from rounding x*log2(e)) about one pixel per
+// 10^6 lands on the other side of a gate w.r.t. the oracle at the benchmark size; with a ~1 ulp exp none does.
+// GSR_EXP_MODE: 0 = __expf, 1 = compensated exp2 (default: the product x*log2(e) carried in two floats, 6
+// instructions, ~1 ulp), 2 = libm-grade expf.
+#ifndef GSR_EXP_MODE
+#define GSR_EXP_MODE 1
 #endif
 
 namespace {
@@ -30,8 +35,16 @@ namespace {
 constexpr int kBatch = 256;
 
 __device__ __forceinline__ float gsr_exp(float x) {
-#if GSR_FAST_EXP
+#if GSR_EXP_MODE == 0
   return __expf(x);
+#elif GSR_EXP_MODE == 1
+  constexpr float kL2eHi = 1.44269502162933349609375f;       // float(log2(e))
+  constexpr float kL2eLo = 1.925963033500011e-08f;           // log2(e) - float(log2(e))
+  constexpr float kLn2 = 0.693147180559945309f;
+  const float t = x * kL2eHi;
+  const float lo = __fmaf_rn(x, kL2eLo, __fmaf_rn(x, kL2eHi, -t));   // what the rounded product dropped
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __fmaf_rn(e, lo * kLn2, e);                                  // 2^(t+lo) = 2^t (1 + lo ln 2 + ...)
 #else
   return expf(x);
 #endif
