@@ -32,14 +32,14 @@ class GsrGeom(C.Structure):
 
 
 class GsrBinning(C.Structure):
-    _fields_ = [("point_list", _f), ("ranges", _f), ("tile_work", _f), ("keys_sorted", _f), ("scratch", _f),
-                ("scratch_bytes", C.c_size_t),
+    _fields_ = [("point_list", _f), ("ranges", _f), ("tile_work", _f), ("bwd_items_cap", C.c_uint32),
+                ("reserved2_", C.c_uint32), ("keys_sorted", _f), ("scratch", _f), ("scratch_bytes", C.c_size_t),
                 ("count_on_device", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class GsrImages(C.Structure):
     _fields_ = [("color", _f), ("depth_alpha", _f), ("final_T", _f), ("n_contrib", _f), ("tile_depth", _f),
-                ("important_score", _f)]
+                ("ckpt", _f), ("important_score", _f)]
 
 
 class GsrImageGrads(C.Structure):

@@ -142,7 +142,8 @@ int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, 
   if (rc) return rc;
   if (!geom || !b || !img) return GSR_EINVAL;
   if (!b->ranges || !img->color || !img->depth_alpha || !img->final_T || !img->n_contrib) return GSR_EINVAL;
-  if (!b->tile_work || !img->tile_depth) return GSR_EINVAL;
+  if (!b->tile_work || !img->tile_depth || !img->ckpt) return GSR_EINVAL;
+  if ((uint64_t)b->bwd_items_cap < n_pairs / 256 + gsr_num_tiles(v->image_height, v->image_width)) return GSR_EINVAL;
   if (n_pairs && (!b->point_list || !geom->splat)) return GSR_EINVAL;
   if (n_pairs >= (1ull << 32)) return GSR_ECAPACITY;
   hipStream_t stream = (hipStream_t)stream_;
@@ -167,7 +168,7 @@ int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, c
   if (!geom || !b || !img || !ig || !out) return GSR_EINVAL;
   if (v->P == 0) return GSR_OK;
   if (!ig->dL_dcolor || !ig->dL_ddepth_alpha || !img->final_T || !img->n_contrib || !b->ranges) return GSR_EINVAL;
-  if (!b->tile_work || !img->tile_depth) return GSR_EINVAL;
+  if (!b->tile_work || !img->tile_depth || !img->ckpt || !img->color || !img->depth_alpha) return GSR_EINVAL;
   if (!out->partials || !aligned16(out->partials)) return GSR_EINVAL;
   if (!out->dL_dmeans3D || !out->dL_dmeans2D || !out->dL_dopacities) return GSR_EINVAL;
   if (out->dL_dshs && (!g->shs || !aligned16(out->dL_dshs))) return GSR_EINVAL;

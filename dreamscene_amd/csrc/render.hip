@@ -96,32 +96,100 @@ __device__ __forceinline__ int gsr_dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
-// Work list: tile ids ordered heaviest-first (33 buckets of floor(log2(key+1)), descending), plus the zeroed
-// work counter in work[n_tiles]. MODE 0: key = list length from `ranges` (forward; also zeroes tile_depth),
-// MODE 1: key = tile_depth (backward). Single workgroup; the order inside a bucket is arbitrary.
-template <int MODE>
+// Block-wide exclusive scan helper for a single 1024-thread workgroup walking an array in chunks of 1024.
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t x, uint32_t* wave_tot, uint32_t* carry_s, bool update) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t inc = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+  const uint32_t carry = *carry_s;
+  const uint32_t excl = carry + woff + inc - x;
+  __syncthreads();
+  if (update && tid == 1023) *carry_s = carry + woff + inc;
+  __syncthreads();
+  return excl;
+}
+
+// Forward work list: tile ids ordered heaviest-first (33 buckets of floor(log2(len+1)), descending; the order
+// inside a bucket is arbitrary); zeroes tile_depth; ckpt_base[t] = first checkpoint slot of tile t (a tile of
+// length len owns max(0, ceil(len/256) - 1) slots: one per 256-entry batch boundary). Single workgroup.
 __global__ void __launch_bounds__(1024)
-k_work_order(const uint32_t n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ tile_depth,
-             uint32_t* __restrict__ work) {
-  __shared__ uint32_t cnt[34], cur[34];
+k_work_order_fwd(const uint32_t n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ tile_depth,
+                 uint32_t* __restrict__ work, uint32_t* __restrict__ ckpt_base) {
+  __shared__ uint32_t cnt[34], cur[34], wave_tot[16], carry_s;
   const int tid = threadIdx.x;
   if (tid < 34) cnt[tid] = 0;
+  if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (uint32_t t = tid; t < n_tiles; t += 1024) {
-    const uint32_t key = MODE == 0 ? (ranges[2 * t + 1] - ranges[2 * t]) : tile_depth[t];
-    atomicAdd(&cnt[key ? 32 - __clz(key) : 0], 1u);
-    if (MODE == 0) tile_depth[t] = 0;
+  for (uint32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+    const uint32_t t = t0 + tid;
+    const uint32_t len = t < n_tiles ? (ranges[2 * t + 1] - ranges[2 * t]) : 0u;
+    if (t < n_tiles) {
+      atomicAdd(&cnt[len ? 32 - __clz(len) : 0], 1u);
+      tile_depth[t] = 0;
+    }
+    const uint32_t slots = len > kBatch ? (len - 1) / kBatch : 0u;
+    const uint32_t excl = block_excl_scan_1024(slots, wave_tot, &carry_s, true);
+    if (t < n_tiles) ckpt_base[t] = excl;
   }
   __syncthreads();
   if (tid == 0) {
     uint32_t run = 0;
     for (int b = 33; b >= 0; --b) { cur[b] = run; run += cnt[b]; }
-    work[n_tiles] = 0;
   }
   __syncthreads();
   for (uint32_t t = tid; t < n_tiles; t += 1024) {
-    const uint32_t key = MODE == 0 ? (ranges[2 * t + 1] - ranges[2 * t]) : tile_depth[t];
-    work[atomicAdd(&cur[key ? 32 - __clz(key) : 0], 1u)] = t;
+    const uint32_t len = ranges[2 * t + 1] - ranges[2 * t];
+    work[atomicAdd(&cur[len ? 32 - __clz(len) : 0], 1u)] = t;
+  }
+}
+
+// Backward work list: one item (tile, segment) per started 256-entry segment of [0, tile_depth[tile]), ordered
+// by decreasing number of entries (16 buckets: all the full segments first, then the partial tails longest
+// first) so that the in-order hardware dispatch does longest-first scheduling.
+// items[0] = number of items, items[2 + 2 i] = tile, items[3 + 2 i] = segment. Single workgroup.
+__global__ void __launch_bounds__(1024)
+k_work_order_bwd(const uint32_t n_tiles, const uint32_t* __restrict__ tile_depth, uint32_t* __restrict__ items,
+                 const uint32_t items_cap) {
+  __shared__ uint32_t cnt[16], cur[16];
+  const int tid = threadIdx.x;
+  if (tid < 16) cnt[tid] = 0;
+  __syncthreads();
+  // bucket b (0 = largest): full segments and tails of 241..256 entries in bucket 0, ..., 1..16 entries in 15
+  for (uint32_t t = tid; t < n_tiles; t += 1024) {
+    const uint32_t d = tile_depth[t];
+    if (d == 0) continue;
+    const uint32_t full = d / kBatch, tail = d % kBatch;
+    if (full) atomicAdd(&cnt[0], full);
+    if (tail) atomicAdd(&cnt[15 - ((tail - 1) >> 4)], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int b = 0; b < 16; ++b) { cur[b] = run; run += cnt[b]; }
+    items[0] = min(run, items_cap);
+  }
+  __syncthreads();
+  for (uint32_t t = tid; t < n_tiles; t += 1024) {
+    const uint32_t d = tile_depth[t];
+    if (d == 0) continue;
+    const uint32_t full = d / kBatch, tail = d % kBatch;
+    if (full) {
+      const uint32_t base = atomicAdd(&cur[0], full);
+      for (uint32_t sgi = 0; sgi < full; ++sgi)
+        if (base + sgi < items_cap) { items[2 + 2 * (base + sgi)] = t; items[3 + 2 * (base + sgi)] = sgi; }
+    }
+    if (tail) {
+      const uint32_t i = atomicAdd(&cur[15 - ((tail - 1) >> 4)], 1u);
+      if (i < items_cap) { items[2 + 2 * i] = t; items[3 + 2 * i] = full; }
+    }
   }
 }
 
@@ -145,8 +213,8 @@ struct Stage {
 // list order (the only numerical change is the association of the running product inside a quad, ulp-level).
 template <bool SCORE>
 __global__ void __launch_bounds__(256)
-k_render_fwd(const int W, const int H, const uint32_t n_tiles, const uint32_t* __restrict__ work,
-             uint32_t* __restrict__ counter, const uint32_t* __restrict__ ranges,
+k_render_fwd(const int W, const int H, const uint32_t* __restrict__ work, const uint32_t* __restrict__ ckpt_base,
+             float* __restrict__ ckpt, const uint32_t* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const float4* __restrict__ splat, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ out_da, float* __restrict__ final_T,
              uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_depth, float* __restrict__ score,
@@ -187,6 +255,21 @@ k_render_fwd(const int W, const int H, const uint32_t n_tiles, const uint32_t* _
       st.smask[buf][tid] = (tid < n) ? block_mask4(n0, n2, q_x0, q_y0) : 0u;
       if (SCORE) st.sid[buf][tid] = nid;
       if (__syncthreads_count(done) == 256) break;
+      if (base != r0) {
+        // checkpoint of the per-pixel prefix state at this batch boundary: lets the backward start a traversal
+        // at any multiple of 256 list entries (k_render_bwd splits deep tiles into independent segments)
+        float f0 = C0, f1 = C1, f2 = C2, f3 = Dp, f4 = Wt;       // quad folds: all lanes take part
+        f0 += gsr_dpp<0xB1>(f0); f0 += gsr_dpp<0x4E>(f0);
+        f1 += gsr_dpp<0xB1>(f1); f1 += gsr_dpp<0x4E>(f1);
+        f2 += gsr_dpp<0xB1>(f2); f2 += gsr_dpp<0x4E>(f2);
+        f3 += gsr_dpp<0xB1>(f3); f3 += gsr_dpp<0x4E>(f3);
+        f4 += gsr_dpp<0xB1>(f4); f4 += gsr_dpp<0x4E>(f4);
+        if (slot == 0 && inside) {
+          float* ck = ckpt + ((size_t)ckpt_base[tile] + (base - r0) / kBatch - 1u) * (6 * 256) +
+                      ((py - ty * GSR_TILE) * GSR_TILE + (px - tx * GSR_TILE));
+          ck[0] = T; ck[256] = f0; ck[512] = f1; ck[768] = f2; ck[1024] = f3; ck[1280] = f4;
+        }
+      }
       {
         const uint32_t idx = base + kBatch + tid;
         if (idx < r1) {
@@ -294,7 +377,6 @@ k_render_fwd(const int W, const int H, const uint32_t n_tiles, const uint32_t* _
     const uint32_t wm = gsr_wave_max_u32(last);
     if (lane == 0 && wm) atomicMax(tile_depth + tile, wm);
   }
-  (void)counter; (void)n_tiles;
 }
 
 // --------------------------------------------------------------------------------------------------------- K7
@@ -331,33 +413,58 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 
 // Accumulates into partials [P,12]:
 //   (dL/dndc_x, dL/dndc_y, dL/dconic_a, dL/dconic_b, dL/dconic_c, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
+//
+// Work item = (tile, segment): the <= 256 list entries [256 s, min(256 (s+1), tile_depth)) of one tile, for all of
+// its 256 pixels, traversed back to front. The reverse traversal of a pixel is a serial recurrence over its whole
+// depth (up to thousands of splats), and the deepest tiles used to set the kernel time; segments make the items
+// uniform and independent. A pixel whose last contributor lies beyond the segment starts from the forward's
+// checkpoint at the segment end (prefix transmittance T_c and prefix sums C_c, D_c, W_c): the colour / depth /
+// alpha composited BEHIND that point, normalised to start there, is (X_final - X_c) / T_c, which is exactly the
+// `rec` state the sequential traversal would carry at that position. Other pixels start from their final state.
 __global__ void __launch_bounds__(256)
-k_render_bwd(const int W, const int H, const uint32_t n_tiles, const uint32_t* __restrict__ work,
-             uint32_t* __restrict__ counter, const uint32_t* __restrict__ tile_depth,
+k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const uint32_t* __restrict__ tile_depth,
+             const uint32_t* __restrict__ ckpt_base, const float* __restrict__ ckpt,
              const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-             const float4* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ final_T,
+             const float4* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ color,
+             const float* __restrict__ depth_alpha, const float* __restrict__ final_T,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
              const float* __restrict__ dL_dda, float* __restrict__ partials) {
-  __shared__ Stage st;
+  __shared__ float4 s0[kBatch], s1[kBatch], s2[kBatch];
+  __shared__ uint32_t sid[kBatch], smask[kBatch];
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  // lane -> (component slot, scale) of the single atomic that commits a splat's 10 sums (see reduce10)
-  const int rj = lane & 3, rr = lane >> 4;
-  const int comp = 4 * rj + (((rr & 1) << 1) | (rr >> 1));
-  const bool commit = ((lane & 15) < 3) && (comp < 10);
-  const float cscale = comp == 0 ? 0.5f * (float)W : (comp == 1 ? 0.5f * (float)H : 1.0f);
+  if (blockIdx.x >= items[0]) return;
  {
   const uint32_t item = blockIdx.x;
-  const int tile = (int)work[item];
-  const uint32_t tile_max = tile_depth[tile];
-  if (tile_max == 0) return;
-  (void)counter; (void)n_tiles;
+  const int tile = (int)items[2 + 2 * item];
+  const uint32_t seg = items[3 + 2 * item];
+#ifdef GSR_EXP_LDSPAD
+  __shared__ float pad[GSR_EXP_LDSPAD];
+  if (tile < 0) pad[threadIdx.x] = 1.f;
+#endif
+  const uint32_t depth = tile_depth[tile];
+  const uint32_t lo = seg * kBatch, hi = min(lo + (uint32_t)kBatch, depth);
+  const int n = (int)(hi - lo);
+
   const TilePix p = tile_pixel(tile, gx, W, H);
   const int tile_x0 = p.bx - (wave & 1) * 8, tile_y0 = p.by - (wave >> 1) * 8;
   const float pxf = (float)p.px, pyf = (float)p.py;
   const uint32_t r0 = ranges[2 * tile];
   const size_t pix = (size_t)p.py * W + p.px, HW = (size_t)H * W;
+
+  // stage the segment, last entry first (one gather per thread)
+  {
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = make_float4(0, 0, -1.f, -1.f);
+    uint32_t nid = 0;
+    if (tid < n) {
+      nid = point_list[r0 + (hi - 1u - (uint32_t)tid)];
+      const float4* r = splat + 3 * (size_t)nid;
+      n0 = r[0]; n1 = r[1]; n2 = r[2];
+    }
+    s0[tid] = n0; s1[tid] = n1; s2[tid] = n2;
+    sid[tid] = nid;
+    smask[tid] = (tid < n) ? block_mask(n0, n2, tile_x0, tile_y0) : 0u;
+  }
 
   const float Tf = p.inside ? final_T[pix] : 0.f;
   const uint32_t last = p.inside ? n_contrib[pix] : 0u;
@@ -366,85 +473,83 @@ k_render_bwd(const int W, const int H, const uint32_t n_tiles, const uint32_t* _
     gC0 = dL_dcolor[pix]; gC1 = dL_dcolor[HW + pix]; gC2 = dL_dcolor[2 * HW + pix];
     gD = dL_dda[pix]; gA = dL_dda[HW + pix];
   }
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   const float bg_dot = (bg0 * gC0 + bg1 * gC1) + bg2 * gC2;
 
   float T = Tf;
   float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, rc0 = 0.f, rc1 = 0.f, rc2 = 0.f;
   float last_z = 0.f, rec_z = 0.f, rec_a = 0.f;
-
-  uint32_t nid = 0;
-  float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
-  if ((uint32_t)tid < tile_max) {
-    nid = point_list[r0 + (tile_max - 1u - (uint32_t)tid)];
-    const float4* r = splat + 3 * (size_t)nid;
-    n0 = r[0]; n1 = r[1]; n2 = r[2];
+  if (last > hi) {
+    // this pixel keeps compositing beyond the segment: start from the forward's checkpoint at position hi
+    const float* ck = ckpt + ((size_t)ckpt_base[tile] + seg) * (6 * 256) +
+                      ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
+    const float Tc = ck[0];
+    const float inv = 1.0f / Tc;
+    T = Tc;
+    rc0 = ((color[pix] - Tf * bg0) - ck[256]) * inv;
+    rc1 = ((color[HW + pix] - Tf * bg1) - ck[512]) * inv;
+    rc2 = ((color[2 * HW + pix] - Tf * bg2) - ck[768]) * inv;
+    rec_z = (depth_alpha[pix] - ck[1024]) * inv;
+    rec_a = (depth_alpha[HW + pix] - ck[1280]) * inv;
   }
-  int buf = 0;
-  for (uint32_t hi = tile_max; hi > 0; hi = (hi > kBatch) ? hi - kBatch : 0u, buf ^= 1) {
-    const int n = (int)min((uint32_t)kBatch, hi);
-    st.s0[buf][tid] = n0; st.s1[buf][tid] = n1; st.s2[buf][tid] = n2;
-    st.sid[buf][tid] = nid;
-    st.smask[buf][tid] = (tid < n) ? block_mask(n0, n2, tile_x0, tile_y0) : 0u;
-    __syncthreads();
-    if (hi > kBatch) {
-      const uint32_t nhi = hi - kBatch;
-      if ((uint32_t)tid < nhi) {
-        nid = point_list[r0 + (nhi - 1u - (uint32_t)tid)];
-        const float4* r = splat + 3 * (size_t)nid;
-        n0 = r[0]; n1 = r[1]; n2 = r[2];
-      }
-    }
-    for (int k = 0; k < kBatch / 64; ++k) {
-      if (k * 64 >= n) break;
-      unsigned long long bits = __ballot((st.smask[buf][k * 64 + lane] >> wave) & 1u);
-      while (bits) {
-        const int j = k * 64 + __builtin_ctzll(bits);
-        bits &= bits - 1ull;
-        const uint32_t pos = hi - 1u - (uint32_t)j;      // 0-based list position
-        const bool live = pos < last;
-        if (__ballot(live) == 0ull) continue;
-        const float4 a = st.s0[buf][j];
-        const float4 b = st.s1[buf][j];
-        const float dx = a.x - pxf, dy = a.y - pyf;
-        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-        const float G = gsr_exp(power);
-        const float alpha = fminf(GSR_ALPHA_MAX, b.y * G);
-        const bool hit = live && (power <= 0.0f) && (alpha >= GSR_ALPHA_MIN);
-        if (__ballot(hit) == 0ull) continue;
-        float v[10];
+
+  // lane -> (component slot, scale) of the single atomic that commits a splat's 10 sums (see reduce10)
+  const int rj = lane & 3, rr = lane >> 4;
+  const int comp = 4 * rj + (((rr & 1) << 1) | (rr >> 1));
+  const bool commit = ((lane & 15) < 3) && (comp < 10);
+  const float cscale = comp == 0 ? 0.5f * (float)W : (comp == 1 ? 0.5f * (float)H : 1.0f);
+  __syncthreads();
+
+  for (int k = 0; k < kBatch / 64; ++k) {
+    if (k * 64 >= n) break;
+    unsigned long long bits = __ballot((smask[k * 64 + lane] >> wave) & 1u);
+    while (bits) {
+      const int j = k * 64 + __builtin_ctzll(bits);
+      bits &= bits - 1ull;
+      const uint32_t pos = hi - 1u - (uint32_t)j;      // 0-based list position
+      const bool live = pos < last;
+      if (__ballot(live) == 0ull) continue;
+      const float4 a = s0[j];
+      const float4 b = s1[j];
+      const float dx = a.x - pxf, dy = a.y - pyf;
+      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+      const float G = gsr_exp(power);
+      const float alpha = fminf(GSR_ALPHA_MAX, b.y * G);
+      const bool hit = live && (power <= 0.0f) && (alpha >= GSR_ALPHA_MIN);
+      if (__ballot(hit) == 0ull) continue;
+      float v[10];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) v[q] = 0.f;
-        if (hit) {
-          const float4 c = st.s2[buf][j];
-          const float inv = __frcp_rn(1.0f - alpha);
-          T = T * inv;
-          const float w = alpha * T;
-          float dL_dalpha;
-          rc0 = last_alpha * lc0 + (1.0f - last_alpha) * rc0; lc0 = b.w;
-          rc1 = last_alpha * lc1 + (1.0f - last_alpha) * rc1; lc1 = c.x;
-          rc2 = last_alpha * lc2 + (1.0f - last_alpha) * rc2; lc2 = c.y;
-          dL_dalpha = (b.w - rc0) * gC0 + (c.x - rc1) * gC1 + (c.y - rc2) * gC2;
-          rec_z = last_alpha * last_z + (1.0f - last_alpha) * rec_z; last_z = b.z;
-          dL_dalpha += (b.z - rec_z) * gD;
-          rec_a = last_alpha + (1.0f - last_alpha) * rec_a;
-          dL_dalpha += (1.0f - rec_a) * gA;
-          dL_dalpha *= T;
-          last_alpha = alpha;
-          dL_dalpha -= (Tf * inv) * bg_dot;
-          const float dL_dG = b.y * dL_dalpha;
-          const float gdx = G * dx, gdy = G * dy;
-          v[0] = dL_dG * (-gdx * a.z - gdy * a.w);
-          v[1] = dL_dG * (-gdy * b.x - gdx * a.w);
-          v[2] = -0.5f * gdx * dx * dL_dG;
-          v[3] = -gdx * dy * dL_dG;
-          v[4] = -0.5f * gdy * dy * dL_dG;
-          v[5] = G * dL_dalpha;
-          v[6] = w * gC0; v[7] = w * gC1; v[8] = w * gC2;
-          v[9] = w * gD;
-        }
-        const float s = reduce10(v, lane);
-        if (commit) unsafeAtomicAdd(partials + 12 * (size_t)st.sid[buf][j] + comp, s * cscale);
+      for (int q = 0; q < 10; ++q) v[q] = 0.f;
+      if (hit) {
+        const float4 c = s2[j];
+        const float inv = __frcp_rn(1.0f - alpha);
+        T = T * inv;
+        const float w = alpha * T;
+        float dL_dalpha;
+        rc0 = last_alpha * lc0 + (1.0f - last_alpha) * rc0; lc0 = b.w;
+        rc1 = last_alpha * lc1 + (1.0f - last_alpha) * rc1; lc1 = c.x;
+        rc2 = last_alpha * lc2 + (1.0f - last_alpha) * rc2; lc2 = c.y;
+        dL_dalpha = (b.w - rc0) * gC0 + (c.x - rc1) * gC1 + (c.y - rc2) * gC2;
+        rec_z = last_alpha * last_z + (1.0f - last_alpha) * rec_z; last_z = b.z;
+        dL_dalpha += (b.z - rec_z) * gD;
+        rec_a = last_alpha + (1.0f - last_alpha) * rec_a;
+        dL_dalpha += (1.0f - rec_a) * gA;
+        dL_dalpha *= T;
+        last_alpha = alpha;
+        dL_dalpha -= (Tf * inv) * bg_dot;
+        const float dL_dG = b.y * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        v[0] = dL_dG * (-gdx * a.z - gdy * a.w);
+        v[1] = dL_dG * (-gdy * b.x - gdx * a.w);
+        v[2] = -0.5f * gdx * dx * dL_dG;
+        v[3] = -gdx * dy * dL_dG;
+        v[4] = -0.5f * gdy * dy * dL_dG;
+        v[5] = G * dL_dalpha;
+        v[6] = w * gC0; v[7] = w * gC1; v[8] = w * gC2;
+        v[9] = w * gD;
       }
+      const float sred = reduce10(v, lane);
+      if (commit) unsafeAtomicAdd(partials + 12 * (size_t)sid[j] + comp, sred * cscale);
     }
   }
  }
@@ -452,7 +557,7 @@ k_render_bwd(const int W, const int H, const uint32_t n_tiles, const uint32_t* _
 
 }  // namespace
 
-// persistent grid: workgroups per CU chosen so that every SIMD holds ~4 waves; CU count cached per device
+// fixed grid for strided kernels: workgroups per CU x CU count (cached per device)
 static int persistent_groups(int per_cu) {
   static int cus[64] = {0};
   int dev = 0;
@@ -469,17 +574,17 @@ int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinnin
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
   const float4* splat = reinterpret_cast<const float4*>(geom.splat);
   uint32_t* work = b.tile_work;
-  uint32_t* counter = b.tile_work + tiles;
-  hipLaunchKernelGGL(k_work_order<0>, dim3(1), dim3(1024), 0, stream, tiles, b.ranges, img.tile_depth, work);
+  uint32_t* ckpt_base = b.tile_work + tiles;
+  hipLaunchKernelGGL(k_work_order_fwd, dim3(1), dim3(1024), 0, stream, tiles, b.ranges, img.tile_depth, work, ckpt_base);
   const uint32_t grid = tiles * 4;
   if (img.important_score) {
-    hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, tiles,
-                       work, counter, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T,
-                       img.n_contrib, img.tile_depth, img.important_score, v.score_mode);
+    hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, work,
+                       ckpt_base, img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha,
+                       img.final_T, img.n_contrib, img.tile_depth, img.important_score, v.score_mode);
   } else {
-    hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, tiles,
-                       work, counter, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T,
-                       img.n_contrib, img.tile_depth, (float*)nullptr, 0);
+    hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, work,
+                       ckpt_base, img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha,
+                       img.final_T, img.n_contrib, img.tile_depth, (float*)nullptr, 0);
   }
   GSR_HIP(hipGetLastError());
   return GSR_OK;
@@ -488,13 +593,14 @@ int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinnin
 int gsr_launch_render_bwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, const GsrImages& img,
                           const GsrImageGrads& ig, GsrGrads& out, hipStream_t stream) {
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
-  uint32_t* work = b.tile_work;
-  uint32_t* counter = b.tile_work + tiles;
-  hipLaunchKernelGGL(k_work_order<1>, dim3(1), dim3(1024), 0, stream, tiles, b.ranges, img.tile_depth, work);
-  const uint32_t grid = tiles;
-  hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, tiles, work,
-                     counter, img.tile_depth, b.ranges, b.point_list, reinterpret_cast<const float4*>(geom.splat), v.bg,
-                     img.final_T, img.n_contrib, ig.dL_dcolor, ig.dL_ddepth_alpha, out.partials);
+  const uint32_t* ckpt_base = b.tile_work + tiles;
+  uint32_t* items = b.tile_work + 2 * tiles;
+  const uint32_t items_cap = b.bwd_items_cap;
+  hipLaunchKernelGGL(k_work_order_bwd, dim3(1), dim3(1024), 0, stream, tiles, img.tile_depth, items, items_cap);
+  hipLaunchKernelGGL(k_render_bwd, dim3(items_cap), dim3(256), 0, stream, v.image_width, v.image_height, items,
+                     img.tile_depth, ckpt_base, img.ckpt, b.ranges, b.point_list,
+                     reinterpret_cast<const float4*>(geom.splat), v.bg, img.color, img.depth_alpha, img.final_T,
+                     img.n_contrib, ig.dL_dcolor, ig.dL_ddepth_alpha, out.partials);
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }

@@ -175,7 +175,8 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
             """One allocation for everything the backward re-reads (splat, tile counts, offsets, lists, ranges,
             final_T, n_contrib); carved by offsets, no per-tensor allocations."""
             sizes = dict(splat=Pm * 48, tiles_touched=Pm * 4, block_offsets=(nb + 4) * 4, point_list=max(cap, 1) * 4,
-                         ranges=tiles * 8, tile_work=(tiles + 4) * 4, tile_depth=tiles * 4, final_T=H * W * 4,
+                         ranges=tiles * 8, tile_work=(2 * tiles + 2 + 2 * (cap // 256 + tiles)) * 4 + 64,
+                         tile_depth=tiles * 4, ckpt=(cap // 256 + 1) * 6 * 256 * 4, final_T=H * W * 4,
                          n_contrib=H * W * 4,
                          keys_sorted=(max(cap, 1) * 8 if want_keys else 0))
             offs, tot = {}, 0
@@ -198,11 +199,13 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
             sort_bytes = int(lib.gsr_sort_scratch_bytes(cap, tiles))
             sort_scratch = ws.scratch("sort_scratch", sort_bytes)
             b.point_list, b.ranges, b.tile_work = ptrs["point_list"], ptrs["ranges"], ptrs["tile_work"]
+            b.bwd_items_cap = cap // 256 + tiles
             b.keys_sorted = ptrs["keys_sorted"] if want_keys else None
             b.scratch, b.scratch_bytes, b.count_on_device = sort_scratch.data_ptr(), sort_scratch.numel(), int(on_device)
             im.final_T, im.n_contrib, im.tile_depth = ptrs["final_T"], ptrs["n_contrib"], ptrs["tile_depth"]
+            im.ckpt = ptrs["ckpt"]
 
-        NSIZED = ("point_list", "ranges", "tile_work", "tile_depth", "final_T", "n_contrib", "keys_sorted")
+        NSIZED = ("point_list", "ranges", "tile_work", "tile_depth", "ckpt", "final_T", "n_contrib", "keys_sorted")
         n_pairs = C.c_uint64(0)
         if hint is None:
             # exact two-phase forward: project (+ one host sync for N), then allocate exactly, then render
@@ -259,7 +262,7 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     b.scratch, b.scratch_bytes, b.keys_sorted = None, 0, None
     geom.scratch, geom.scratch_bytes, geom.sorted_idx = None, 0, None
     st.keep = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, bg, vm, pm, cp, radii,
-               keep_bufs)
+               keep_bufs, color, depth_alpha)   # backward re-reads the output image (suffix sums from checkpoints)
     out = dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, N=N)
     if want_aux:
         def view(name, dtype, count, shape=None):

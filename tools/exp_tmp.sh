@@ -1,9 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for flags in "" "-DGSR_EXP_MODE=2" "-DGSR_EXP_MODE=0"; do
-python - <<PY
-from dreamscene_amd import build
-build.build(force=True, extra_flags="$flags".split())
-PY
-echo "== [$flags]"
-python bench.py --steps 10 --warmup 3 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], json.dumps(d['max_grad_err_vs_oracle']))"
+timeout 600 python -m pytest tests/ -m gpu -x -q 2>&1 | tail -3
+for cfg in "--gaussians 500000 --res 1024" "--gaussians 100000 --res 512" "--gaussians 1000000 --res 512" "--scene indoor --gaussians 2000000 --res 1024"; do
+  echo "== $cfg"
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $cfg 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['config']['tile_pairs_N'], {k:round(v) for k,v in d['roofline']['stage_us_warmup'].items()})"
 done
