@@ -255,10 +255,12 @@ __global__ void __launch_bounds__(256)
 k_emit_pairs(const int P, const int W, const int H, const float* __restrict__ splat, const int32_t* __restrict__ radii,
              const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ sorted_idx,
              const uint32_t* __restrict__ block_offsets, const uint64_t cap, uint32_t* __restrict__ keys,
-             uint32_t* __restrict__ vals) {
+             uint32_t* __restrict__ vals, uint32_t* __restrict__ ranges, const uint32_t n_range_words) {
   __shared__ uint32_t wave_tot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t s = (int64_t)blockIdx.x * 256 + tid;
+  // tile ranges start out as (0,0): cleared here (grid-stride) instead of by a separate fill launch
+  for (uint32_t w = (uint32_t)s; w < n_range_words; w += gridDim.x * 256u) ranges[w] = 0u;
   const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
   const uint32_t i = (s < P) ? sorted_idx[s] : 0u;
   const uint32_t cnt = (s < P) ? tiles_touched[i] : 0u;
@@ -438,8 +440,10 @@ int gsr_launch_depth_order(GsrGeom& geom, int32_t P, uint64_t* n_pairs_dev, uint
 int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, const uint64_t* n_dev, GsrBinning& b,
                        hipStream_t stream, GsrProfile* prof) {
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
-  GSR_HIP(hipMemsetAsync(b.ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), stream));
-  if (cap == 0) return GSR_OK;
+  if (cap == 0 || v.P == 0) {
+    GSR_HIP(hipMemsetAsync(b.ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), stream));
+    return GSR_OK;
+  }
   if (b.scratch_bytes < gsr_sort_scratch_bytes(cap, tiles) || !b.scratch) return GSR_ESCRATCH;
   if (!geom.sorted_idx) return GSR_EINVAL;
   char* base = (char*)b.scratch;
@@ -460,7 +464,7 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
     GsrStageTimer t(prof, stream, GSR_STAGE_DUPLICATE);
     hipLaunchKernelGGL(k_emit_pairs, dim3(gsr_num_blocks(v.P)), dim3(256), 0, stream, v.P, v.image_width,
                        v.image_height, geom.splat, geom.radii, geom.tiles_touched, geom.sorted_idx, geom.block_offsets,
-                       cap, keys_a, va);
+                       cap, keys_a, va, b.ranges, tiles * 2);
     GSR_HIP(hipGetLastError());
   }
   uint32_t* sorted_keys;

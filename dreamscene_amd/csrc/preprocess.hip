@@ -310,7 +310,8 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
 }
 
 // --------------------------------------------------------------------------------------------------------- K8
-// partials [P,12]: (dL/dndc_x, dL/dndc_y, dL/dconic a,b,c, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
+// partials [P,12] from K7: (S1 = sum q dx, S2 = sum q dy, S3 = sum q dx^2, S4 = sum q dx dy, S5 = sum q dy^2,
+//                          dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -), q = dL/dG * G
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restrict__ radii,
                  const float* __restrict__ partials, const GsrGrads out) {
@@ -339,7 +340,8 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
     const float4* pp = reinterpret_cast<const float4*>(partials + 12 * i);
     pa = pp[0]; pb = pp[1]; pc = pp[2];
   }
-  const float gndx = pa.x, gndy = pa.y, gca = pa.z, gcb = pa.w, gcc = pb.x, gop = pb.y;
+  const float S1 = pa.x, S2 = pa.y, S3 = pa.z, S4 = pa.w, S5 = pb.x, gop = pb.y;
+  float gndx = 0.f, gndy = 0.f;
   const float grgb[3] = {pb.z, pb.w, pc.x};
   const float gdep = pc.y;
 
@@ -435,9 +437,17 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
     Ewa e;
     ewa_forward(vc, px, py, pz, c6, fx, fy, limx, limy, e);
 
-    // (2) conic -> cov2D (lineage denominator det^2 + 1e-7)
-    const float d2i = 1.0f / (e.det * e.det + 0.0000001f);
+    // (2a) moments -> dL/d(ndc xy) and dL/dconic: power = -1/2 (A dx^2 + C dy^2) - B dx dy, dG/ddx = -G (A dx + B dy)
     const float ca = e.ca, cb = e.cb, cc = e.cc;
+    {
+      const float inv = 1.0f / e.det;
+      const float A = cc * inv, B = -cb * inv, C = ca * inv;
+      gndx = -(A * S1 + B * S2) * (0.5f * (float)W);
+      gndy = -(C * S2 + B * S1) * (0.5f * (float)H);
+    }
+    const float gca = -0.5f * S3, gcb = -S4, gcc = -0.5f * S5;
+    // (2b) conic -> cov2D (lineage denominator det^2 + 1e-7)
+    const float d2i = 1.0f / (e.det * e.det + 0.0000001f);
     const float dca = d2i * ((-cc * cc * gca + cb * cc * gcb) - cb * cb * gcc);
     const float dcc = d2i * ((-cb * cb * gca + cb * ca * gcb) - ca * ca * gcc);
     const float dcb = d2i * ((2.0f * cb * cc * gca - (e.det + 2.0f * cb * cb) * gcb) + 2.0f * cb * ca * gcc);

@@ -118,26 +118,18 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t x, uint32_t* w
 }
 
 // Forward work list: tile ids ordered heaviest-first (33 buckets of floor(log2(len+1)), descending; the order
-// inside a bucket is arbitrary); zeroes tile_depth; ckpt_base[t] = first checkpoint slot of tile t (a tile of
-// length len owns max(0, ceil(len/256) - 1) slots: one per 256-entry batch boundary). Single workgroup.
+// inside a bucket is arbitrary); zeroes tile_depth. Single workgroup.
 __global__ void __launch_bounds__(1024)
 k_work_order_fwd(const uint32_t n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ tile_depth,
-                 uint32_t* __restrict__ work, uint32_t* __restrict__ ckpt_base) {
-  __shared__ uint32_t cnt[34], cur[34], wave_tot[16], carry_s;
+                 uint32_t* __restrict__ work) {
+  __shared__ uint32_t cnt[34], cur[34];
   const int tid = threadIdx.x;
   if (tid < 34) cnt[tid] = 0;
-  if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (uint32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
-    const uint32_t t = t0 + tid;
-    const uint32_t len = t < n_tiles ? (ranges[2 * t + 1] - ranges[2 * t]) : 0u;
-    if (t < n_tiles) {
-      atomicAdd(&cnt[len ? 32 - __clz(len) : 0], 1u);
-      tile_depth[t] = 0;
-    }
-    const uint32_t slots = len > kBatch ? (len - 1) / kBatch : 0u;
-    const uint32_t excl = block_excl_scan_1024(slots, wave_tot, &carry_s, true);
-    if (t < n_tiles) ckpt_base[t] = excl;
+  for (uint32_t t = tid; t < n_tiles; t += 1024) {
+    const uint32_t len = ranges[2 * t + 1] - ranges[2 * t];
+    atomicAdd(&cnt[len ? 32 - __clz(len) : 0], 1u);
+    tile_depth[t] = 0;
   }
   __syncthreads();
   if (tid == 0) {
@@ -213,8 +205,8 @@ struct Stage {
 // list order (the only numerical change is the association of the running product inside a quad, ulp-level).
 template <bool SCORE>
 __global__ void __launch_bounds__(256)
-k_render_fwd(const int W, const int H, const uint32_t* __restrict__ work, const uint32_t* __restrict__ ckpt_base,
-             float* __restrict__ ckpt, const uint32_t* __restrict__ ranges,
+k_render_fwd(const int W, const int H, const uint32_t* __restrict__ work, float* __restrict__ ckpt,
+             const uint32_t* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const float4* __restrict__ splat, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ out_da, float* __restrict__ final_T,
              uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_depth, float* __restrict__ score,
@@ -265,8 +257,9 @@ k_render_fwd(const int W, const int H, const uint32_t* __restrict__ work, const 
         f3 += gsr_dpp<0xB1>(f3); f3 += gsr_dpp<0x4E>(f3);
         f4 += gsr_dpp<0xB1>(f4); f4 += gsr_dpp<0x4E>(f4);
         if (slot == 0 && inside) {
-          float* ck = ckpt + ((size_t)ckpt_base[tile] + (base - r0) / kBatch - 1u) * (6 * 256) +
-                      ((py - ty * GSR_TILE) * GSR_TILE + (px - tx * GSR_TILE));
+          // slot = absolute list position / 256: boundaries of one list are 256 apart and the first boundary of
+          // a tile lies >= 256 entries after the end of the previous tile's list, so slots never collide
+          float* ck = ckpt + (size_t)(base / kBatch) * (6 * 256) + ((py - ty * GSR_TILE) * GSR_TILE + (px - tx * GSR_TILE));
           ck[0] = T; ck[256] = f0; ck[512] = f1; ck[768] = f2; ck[1024] = f3; ck[1280] = f4;
         }
       }
@@ -411,8 +404,9 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
   return j == 0 ? d0 : (j == 1 ? d1 : d2);
 }
 
-// Accumulates into partials [P,12]:
-//   (dL/dndc_x, dL/dndc_y, dL/dconic_a, dL/dconic_b, dL/dconic_c, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
+// Accumulates into partials [P,12], with q = dL/dG * G per (pixel, splat) and d = centre - pixel:
+//   (sum q dx, sum q dy, sum q dx^2, sum q dx dy, sum q dy^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
+// (K8 converts the five moments into dL/dmean2D and dL/dconic: they are linear in them with per-splat factors).
 //
 // Work item = (tile, segment): the <= 256 list entries [256 s, min(256 (s+1), tile_depth)) of one tile, for all of
 // its 256 pixels, traversed back to front. The reverse traversal of a pixel is a serial recurrence over its whole
@@ -423,7 +417,7 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 // `rec` state the sequential traversal would carry at that position. Other pixels start from their final state.
 __global__ void __launch_bounds__(256)
 k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const uint32_t* __restrict__ tile_depth,
-             const uint32_t* __restrict__ ckpt_base, const float* __restrict__ ckpt,
+             const float* __restrict__ ckpt,
              const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
              const float4* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ color,
              const float* __restrict__ depth_alpha, const float* __restrict__ final_T,
@@ -481,8 +475,7 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const
   float last_z = 0.f, rec_z = 0.f, rec_a = 0.f;
   if (last > hi) {
     // this pixel keeps compositing beyond the segment: start from the forward's checkpoint at position hi
-    const float* ck = ckpt + ((size_t)ckpt_base[tile] + seg) * (6 * 256) +
-                      ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
+    const float* ck = ckpt + (size_t)((r0 + hi) / kBatch) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
     const float Tc = ck[0];
     const float inv = 1.0f / Tc;
     T = Tc;
@@ -497,7 +490,6 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const
   const int rj = lane & 3, rr = lane >> 4;
   const int comp = 4 * rj + (((rr & 1) << 1) | (rr >> 1));
   const bool commit = ((lane & 15) < 3) && (comp < 10);
-  const float cscale = comp == 0 ? 0.5f * (float)W : (comp == 1 ? 0.5f * (float)H : 1.0f);
   __syncthreads();
 
   for (int k = 0; k < kBatch / 64; ++k) {
@@ -537,19 +529,17 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const
         dL_dalpha *= T;
         last_alpha = alpha;
         dL_dalpha -= (Tf * inv) * bg_dot;
-        const float dL_dG = b.y * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        v[0] = dL_dG * (-gdx * a.z - gdy * a.w);
-        v[1] = dL_dG * (-gdy * b.x - gdx * a.w);
-        v[2] = -0.5f * gdx * dx * dL_dG;
-        v[3] = -gdx * dy * dL_dG;
-        v[4] = -0.5f * gdy * dy * dL_dG;
+        // raw moments of q = dL/dG * G over the pixels; K8 turns them into dL/dmean2D and dL/dconic
+        const float q = (b.y * dL_dalpha) * G;
+        const float m1 = q * dx, m2 = q * dy;
+        v[0] = m1; v[1] = m2;
+        v[2] = m1 * dx; v[3] = m1 * dy; v[4] = m2 * dy;
         v[5] = G * dL_dalpha;
         v[6] = w * gC0; v[7] = w * gC1; v[8] = w * gC2;
         v[9] = w * gD;
       }
       const float sred = reduce10(v, lane);
-      if (commit) unsafeAtomicAdd(partials + 12 * (size_t)sid[j] + comp, sred * cscale);
+      if (commit) unsafeAtomicAdd(partials + 12 * (size_t)sid[j] + comp, sred);
     }
   }
  }
@@ -574,16 +564,15 @@ int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinnin
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
   const float4* splat = reinterpret_cast<const float4*>(geom.splat);
   uint32_t* work = b.tile_work;
-  uint32_t* ckpt_base = b.tile_work + tiles;
-  hipLaunchKernelGGL(k_work_order_fwd, dim3(1), dim3(1024), 0, stream, tiles, b.ranges, img.tile_depth, work, ckpt_base);
+  hipLaunchKernelGGL(k_work_order_fwd, dim3(1), dim3(1024), 0, stream, tiles, b.ranges, img.tile_depth, work);
   const uint32_t grid = tiles * 4;
   if (img.important_score) {
     hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, work,
-                       ckpt_base, img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha,
+                       img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha,
                        img.final_T, img.n_contrib, img.tile_depth, img.important_score, v.score_mode);
   } else {
     hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, work,
-                       ckpt_base, img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha,
+                       img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha,
                        img.final_T, img.n_contrib, img.tile_depth, (float*)nullptr, 0);
   }
   GSR_HIP(hipGetLastError());
@@ -593,12 +582,11 @@ int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinnin
 int gsr_launch_render_bwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, const GsrImages& img,
                           const GsrImageGrads& ig, GsrGrads& out, hipStream_t stream) {
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
-  const uint32_t* ckpt_base = b.tile_work + tiles;
-  uint32_t* items = b.tile_work + 2 * tiles;
+  uint32_t* items = b.tile_work + tiles;
   const uint32_t items_cap = b.bwd_items_cap;
   hipLaunchKernelGGL(k_work_order_bwd, dim3(1), dim3(1024), 0, stream, tiles, img.tile_depth, items, items_cap);
   hipLaunchKernelGGL(k_render_bwd, dim3(items_cap), dim3(256), 0, stream, v.image_width, v.image_height, items,
-                     img.tile_depth, ckpt_base, img.ckpt, b.ranges, b.point_list,
+                     img.tile_depth, img.ckpt, b.ranges, b.point_list,
                      reinterpret_cast<const float4*>(geom.splat), v.bg, img.color, img.depth_alpha, img.final_T,
                      img.n_contrib, ig.dL_dcolor, ig.dL_ddepth_alpha, out.partials);
   GSR_HIP(hipGetLastError());

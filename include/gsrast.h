@@ -95,9 +95,9 @@ typedef struct GsrGeom {
 typedef struct GsrBinning {
   uint32_t* point_list; /* [N] Gaussian index per (tile, depth)-sorted pair                         */
   uint32_t* ranges;     /* [tiles,2] (start,end) into point_list; (0,0) for an empty tile            */
-  uint32_t* tile_work;  /* [2*tiles + 2 + 2*bwd_items_cap] u32: forward work list (tile ids, heaviest first),
-                           checkpoint base per tile, then the backward's (tile, segment) item list; written by the
-                           forward and by the backward: keep it with the saved state                              */
+  uint32_t* tile_work;  /* [tiles + 2 + 2*bwd_items_cap] u32: forward work list (tile ids, heaviest first), then the
+                           backward's (tile, segment) item list; written by the forward and by the backward: keep
+                           it with the saved state                                                                */
   uint32_t bwd_items_cap; /* capacity of the backward item list: >= n_pairs / 256 + tiles                         */
   uint32_t reserved2_;
   uint64_t* keys_sorted;/* [N] optional: receives the sorted 64-bit keys (tile<<32 | depth bits); may be NULL */
@@ -118,8 +118,9 @@ typedef struct GsrImages {
   float* final_T;         /* [H,W] transmittance after the last contributor                  */
   uint32_t* n_contrib;    /* [H,W] 1-based list position of the last contributor             */
   uint32_t* tile_depth;   /* [tiles] max of n_contrib over the tile (written by forward, read by backward) */
-  float* ckpt;            /* [n_pairs/256 + 1][6][256] per-pixel prefix state (T, C rgb, depth, alpha) at every
-                             256-entry boundary of every tile list, written by the forward, read by the backward   */
+  float* ckpt;            /* [n_pairs/256 + 1][6][256] per-pixel prefix state (T, C rgb, depth, alpha) at the 256-entry
+                             boundaries of the tile lists (slot = absolute list position / 256), written by the
+                             forward as far as it composites, read by the backward                                 */
   float* important_score; /* [P] zero-initialised by the caller, or NULL (score_flag False)   */
 } GsrImages;
 
