@@ -118,15 +118,36 @@ __device__ __forceinline__ void sh_basis(int D, float x, float y, float z, float
   }
 }
 
+// colour_c = sum_k b_k sh[k][c] accumulated in ascending k (the oracle's order), written so that every index into the
+// register array b[] is a compile-time constant (a runtime-indexed register array costs s_set_gpr_idx round trips).
+#define GSR_SH_BAND(K0, K1)                                   \
+  _Pragma("unroll") for (int k = K0; k <= K1; ++k) {          \
+    acc[0] = acc[0] + b[k] * sh[3 * k];                       \
+    acc[1] = acc[1] + b[k] * sh[3 * k + 1];                   \
+    acc[2] = acc[2] + b[k] * sh[3 * k + 2];                   \
+  }
+__device__ __forceinline__ void sh_colour(int D, const float* sh, const float b[16], float acc[3]) {
+  acc[0] = b[0] * sh[0]; acc[1] = b[0] * sh[1]; acc[2] = b[0] * sh[2];
+  if (D > 0) {
+    GSR_SH_BAND(1, 3)
+    if (D > 1) {
+      GSR_SH_BAND(4, 8)
+      if (D > 2) { GSR_SH_BAND(9, 15) }
+    }
+  }
+}
+#undef GSR_SH_BAND
+
 // Row stride (in floats) of one Gaussian's SH block inside the LDS transpose buffer: odd => the 64 lanes of a
 // wave reading "their" row element k hit 64 different banks pairs (ds_read_b32, 32-lane groups).
 __host__ __device__ __forceinline__ int sh_lds_stride(int K) { return (3 * K) | 1; }
 
 // Coalesced global -> LDS load of the wave's SH block. `vis` = ballot of lanes whose Gaussian needs its row.
+template <int KT>
 __device__ __forceinline__ void stage_sh_in(const float* __restrict__ shs, int64_t wave_first, int n_valid, int K,
                                             unsigned long long vis, float* lds_wave) {
-  const int F = 3 * K;
-  const int stride = sh_lds_stride(K);
+  const int F = KT > 0 ? 3 * KT : 3 * K;          // compile-time for the common strides: / and % become mul-shift
+  const int stride = F | 1;
   const int total = n_valid * F;                                   // floats in the wave's block
   const float* src = shs + wave_first * (int64_t)F;
   const int lane = gsr_lane();
@@ -156,10 +177,11 @@ __device__ __forceinline__ void stage_sh_in(const float* __restrict__ shs, int64
 }
 
 // LDS -> global coalesced store of the wave's [n_valid, 3K] block.
+template <int KT>
 __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64_t wave_first, int n_valid, int K,
                                              const float* lds_wave, bool accumulate) {
-  const int F = 3 * K;
-  const int stride = sh_lds_stride(K);
+  const int F = KT > 0 ? 3 * KT : 3 * K;
+  const int stride = F | 1;
   const int total = n_valid * F;
   float* dst = dst_base + wave_first * (int64_t)F;
   const int lane = gsr_lane();
@@ -186,11 +208,12 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64
 }
 
 // --------------------------------------------------------------------------------------------------------- K1
+template <int KT>
 __global__ void __launch_bounds__(256)
 k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, int32_t* __restrict__ radii,
              uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_keys) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int P = v.P, W = v.image_width, H = v.image_height, K = v.sh_stride;
+  const int P = v.P, W = v.image_width, H = v.image_height, K = KT > 0 ? KT : v.sh_stride;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t i = (int64_t)blockIdx.x * 256 + tid;
   const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
@@ -272,7 +295,7 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
   if (g.shs) {
     const unsigned long long vmask = __ballot(vis);
     float* lw = lds + wave * (64 * sh_lds_stride(K));
-    if (vmask) stage_sh_in(g.shs, wave_first, n_valid, K, vmask, lw);
+    if (vmask) stage_sh_in<KT>(g.shs, wave_first, n_valid, K, vmask, lw);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (vis) {
@@ -281,15 +304,11 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
       dx = dx / len; dy = dy / len; dz = dz / len;
       float b[16];
       sh_basis(v.sh_degree, dx, dy, dz, b);
-      const int nb = (v.sh_degree + 1) * (v.sh_degree + 1);
       const float* sh = lw + lane * sh_lds_stride(K);
+      float acc[3];
+      sh_colour(v.sh_degree, sh, b, acc);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float acc = b[0] * sh[c];
-        for (int k = 1; k < nb; ++k) acc = acc + b[k] * sh[3 * k + c];
-        acc = acc + 0.5f;
-        rgb[c] = fmaxf(acc, 0.0f);
-      }
+      for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
     }
   } else if (vis) {
     rgb[0] = g.colors_precomp[3 * i]; rgb[1] = g.colors_precomp[3 * i + 1]; rgb[2] = g.colors_precomp[3 * i + 2];
@@ -312,12 +331,13 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
 // --------------------------------------------------------------------------------------------------------- K8
 // partials [P,12] from K7: (S1 = sum q dx, S2 = sum q dy, S3 = sum q dx^2, S4 = sum q dx dy, S5 = sum q dy^2,
 //                          dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -), q = dL/dG * G
+template <int KT>
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restrict__ radii,
                  const float* __restrict__ partials, const GsrGrads out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float cam_red[4][32];
-  const int P = v.P, W = v.image_width, H = v.image_height, K = v.sh_stride, D = v.sh_degree;
+  const int P = v.P, W = v.image_width, H = v.image_height, K = KT > 0 ? KT : v.sh_stride, D = v.sh_degree;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t i = (int64_t)blockIdx.x * 256 + tid;
   const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
@@ -357,7 +377,7 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
     const unsigned long long vmask = __ballot(vis);
     const int stride = sh_lds_stride(K);
     float* lw = lds + wave * (64 * stride);
-    if (vmask) stage_sh_in(g.shs, wave_first, n_valid, K, vmask, lw);
+    if (vmask) stage_sh_in<KT>(g.shs, wave_first, n_valid, K, vmask, lw);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     float* sh = lw + lane * stride;
@@ -369,20 +389,30 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
       sh_basis(D, x, y, z, b);
       const int nb = (D + 1) * (D + 1);
       float gch[3];
+      {
+        float acc[3];
+        sh_colour(D, sh, b, acc);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float acc = b[0] * sh[c];
-        for (int k = 1; k < nb; ++k) acc = acc + b[k] * sh[3 * k + c];
-        acc = acc + 0.5f;
-        gch[c] = (acc < 0.0f) ? 0.0f : grgb[c];           // same clamp decision as K1 (same operator order)
+        for (int c = 0; c < 3; ++c) gch[c] = (acc[c] + 0.5f < 0.0f) ? 0.0f : grgb[c];   // K1's clamp decision (same operator order)
       }
       float s[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) s[k] = 0.f;
-      for (int k = 0; k < nb; ++k) {
-        s[k] = (sh[3 * k] * gch[0] + sh[3 * k + 1] * gch[1]) + sh[3 * k + 2] * gch[2];
-        sh[3 * k] = b[k] * gch[0]; sh[3 * k + 1] = b[k] * gch[1]; sh[3 * k + 2] = b[k] * gch[2];
+      // s_k = <sh_k, g>, and the row is overwritten in place by dL/dsh_k = b_k g (constant register indices per band)
+#define GSR_SH_BWD_BAND(K0, K1)                                                                        \
+  _Pragma("unroll") for (int k = K0; k <= K1; ++k) {                                                   \
+    s[k] = (sh[3 * k] * gch[0] + sh[3 * k + 1] * gch[1]) + sh[3 * k + 2] * gch[2];                     \
+    sh[3 * k] = b[k] * gch[0]; sh[3 * k + 1] = b[k] * gch[1]; sh[3 * k + 2] = b[k] * gch[2];           \
+  }
+      GSR_SH_BWD_BAND(0, 0)
+      if (D > 0) {
+        GSR_SH_BWD_BAND(1, 3)
+        if (D > 1) {
+          GSR_SH_BWD_BAND(4, 8)
+          if (D > 2) { GSR_SH_BWD_BAND(9, 15) }
+        }
       }
+#undef GSR_SH_BWD_BAND
       for (int k = 3 * nb; k < 3 * K; ++k) sh[k] = 0.f;
       float ddx = 0.f, ddy = 0.f, ddz = 0.f;
       if (D > 0) {
@@ -414,7 +444,7 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (out.dL_dshs) stage_sh_out(out.dL_dshs, wave_first, n_valid, K, lw, out.accumulate != 0);
+    if (out.dL_dshs) stage_sh_out<KT>(out.dL_dshs, wave_first, n_valid, K, lw, out.accumulate != 0);
   }
 
   float dscale[3] = {0.f, 0.f, 0.f};
@@ -608,8 +638,17 @@ size_t gsr_preprocess_lds_bytes(int K) { return (size_t)4 * 64 * sh_lds_stride(K
 int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom, hipStream_t stream) {
   const uint32_t nb = gsr_num_blocks(v.P);
   const size_t lds = g.shs ? gsr_preprocess_lds_bytes(v.sh_stride) : 0;
-  hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(256), lds, stream, v, g, geom.splat, geom.radii,
-                     geom.tiles_touched, gsr_depth_keys(geom, v.P));
+#define GSR_LAUNCH_K1(KT)                                                                                      \
+  hipLaunchKernelGGL(k_preprocess<KT>, dim3(nb), dim3(256), lds, stream, v, g, geom.splat, geom.radii,        \
+                     geom.tiles_touched, gsr_depth_keys(geom, v.P))
+  switch (g.shs ? v.sh_stride : 0) {
+    case 16: GSR_LAUNCH_K1(16); break;
+    case 9: GSR_LAUNCH_K1(9); break;
+    case 4: GSR_LAUNCH_K1(4); break;
+    case 1: GSR_LAUNCH_K1(1); break;
+    default: GSR_LAUNCH_K1(0); break;
+  }
+#undef GSR_LAUNCH_K1
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }
@@ -618,7 +657,16 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const Gsr
                               hipStream_t stream) {
   const uint32_t nb = gsr_num_blocks(v.P);
   const size_t lds = g.shs ? gsr_preprocess_lds_bytes(v.sh_stride) : 0;
-  hipLaunchKernelGGL(k_preprocess_bwd, dim3(nb), dim3(256), lds, stream, v, g, geom.radii, out.partials, out);
+#define GSR_LAUNCH_K8(KT) \
+  hipLaunchKernelGGL(k_preprocess_bwd<KT>, dim3(nb), dim3(256), lds, stream, v, g, geom.radii, out.partials, out)
+  switch (g.shs ? v.sh_stride : 0) {
+    case 16: GSR_LAUNCH_K8(16); break;
+    case 9: GSR_LAUNCH_K8(9); break;
+    case 4: GSR_LAUNCH_K8(4); break;
+    case 1: GSR_LAUNCH_K8(1); break;
+    default: GSR_LAUNCH_K8(0); break;
+  }
+#undef GSR_LAUNCH_K8
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }
