@@ -136,6 +136,24 @@ __device__ __forceinline__ void sh_colour(int D, const float* sh, const float b[
     }
   }
 }
+// same, for a register row of exactly KN coefficients (bands beyond KN cannot be active: D is validated against K)
+template <int KN>
+__device__ __forceinline__ void sh_colour_n(int D, const float* sh, const float b[16], float acc[3]) {
+  acc[0] = b[0] * sh[0]; acc[1] = b[0] * sh[1]; acc[2] = b[0] * sh[2];
+  if constexpr (KN >= 4) {
+    if (D > 0) {
+      GSR_SH_BAND(1, 3)
+      if constexpr (KN >= 9) {
+        if (D > 1) {
+          GSR_SH_BAND(4, 8)
+          if constexpr (KN >= 16) {
+            if (D > 2) { GSR_SH_BAND(9, 15) }
+          }
+        }
+      }
+    }
+  }
+}
 #undef GSR_SH_BAND
 
 // Row stride (in floats) of one Gaussian's SH block inside the LDS transpose buffer: odd => the 64 lanes of a
@@ -292,7 +310,33 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
 
   // ---- colour
   float rgb[3] = {0.f, 0.f, 0.f};
-  if (g.shs) {
+  if (g.shs && KT > 0) {
+    // compile-time SH stride: every lane pulls its own 12*KT-byte row straight into registers (measured faster
+    // than the coalesced-load + LDS-transpose path K8 uses for its read-modify-write of the same block: the rows
+    // of a wave are contiguous, so L1/TA serve the 16-byte pieces of one line to successive loads)
+    if (vis) {
+      constexpr int F = 3 * (KT > 0 ? KT : 1);
+      float shr[F];
+      const float* rp = g.shs + (size_t)i * F;
+      if constexpr (F % 4 == 0) {
+        const float4* r = reinterpret_cast<const float4*>(rp);
+#pragma unroll
+        for (int q = 0; q < F / 4; ++q) { const float4 t = r[q]; shr[4*q] = t.x; shr[4*q+1] = t.y; shr[4*q+2] = t.z; shr[4*q+3] = t.w; }
+      } else {
+#pragma unroll
+        for (int q = 0; q < F; ++q) shr[q] = rp[q];
+      }
+      float dx = px - vc.cam[0], dy = py - vc.cam[1], dz = pz - vc.cam[2];
+      const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+      dx = dx / len; dy = dy / len; dz = dz / len;
+      float b[16];
+      sh_basis(v.sh_degree, dx, dy, dz, b);
+      float acc[3];
+      sh_colour_n<(KT > 0 ? KT : 1)>(v.sh_degree, shr, b, acc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
+    }
+  } else if (g.shs) {
     const unsigned long long vmask = __ballot(vis);
     float* lw = lds + wave * (64 * sh_lds_stride(K));
     if (vmask) stage_sh_in<KT>(g.shs, wave_first, n_valid, K, vmask, lw);
@@ -638,9 +682,10 @@ size_t gsr_preprocess_lds_bytes(int K) { return (size_t)4 * 64 * sh_lds_stride(K
 int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom, hipStream_t stream) {
   const uint32_t nb = gsr_num_blocks(v.P);
   const size_t lds = g.shs ? gsr_preprocess_lds_bytes(v.sh_stride) : 0;
+  // compile-time strides read their rows directly (no LDS); only the generic stride stages through LDS
 #define GSR_LAUNCH_K1(KT)                                                                                      \
-  hipLaunchKernelGGL(k_preprocess<KT>, dim3(nb), dim3(256), lds, stream, v, g, geom.splat, geom.radii,        \
-                     geom.tiles_touched, gsr_depth_keys(geom, v.P))
+  hipLaunchKernelGGL(k_preprocess<KT>, dim3(nb), dim3(256), (KT) > 0 ? 0 : lds, stream, v, g, geom.splat,     \
+                     geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P))
   switch (g.shs ? v.sh_stride : 0) {
     case 16: GSR_LAUNCH_K1(16); break;
     case 9: GSR_LAUNCH_K1(9); break;

@@ -1,6 +1,10 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/ -m gpu -x -q 2>&1 | tail -3
-for cfg in "--gaussians 500000 --res 1024" "--gaussians 100000 --res 512" "--gaussians 1000000 --res 512" "--scene indoor --gaussians 2000000 --res 1024"; do
-  echo "== $cfg"
-  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $cfg 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['config']['tile_pairs_N'], {k:round(v) for k,v in d['roofline']['stage_us_warmup'].items()})"
+for flags in "" "-DGSR_EXP_K1_DIRECT"; do
+python - <<PY
+from dreamscene_amd import build
+build.build(force=True, extra_flags="$flags".split())
+PY
+echo "== [$flags]"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -1
+for i in 1 2; do python bench.py --steps 15 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], {k:round(v) for k,v in d['roofline']['stage_us_warmup'].items()})"; done
 done
