@@ -421,10 +421,23 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
     const unsigned long long vmask = __ballot(vis);
     const int stride = sh_lds_stride(K);
     float* lw = lds + wave * (64 * stride);
-    if (vmask) stage_sh_in<KT>(g.shs, wave_first, n_valid, K, vmask, lw);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     float* sh = lw + lane * stride;
+    if constexpr (KT > 0 && (3 * KT) % 4 == 0) {
+      // compile-time stride: each lane pulls its own row (as K1 does) and parks it in its LDS row; LDS is still
+      // needed for the coalesced write-back of dL/dSH
+      if (vis) {
+        const float4* r = reinterpret_cast<const float4*>(g.shs + (size_t)i * (3 * KT));
+#pragma unroll
+        for (int q = 0; q < (3 * KT) / 4; ++q) {
+          const float4 t = r[q];
+          sh[4 * q] = t.x; sh[4 * q + 1] = t.y; sh[4 * q + 2] = t.z; sh[4 * q + 3] = t.w;
+        }
+      }
+    } else {
+      if (vmask) stage_sh_in<KT>(g.shs, wave_first, n_valid, K, vmask, lw);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     if (vis) {
       const float vx = px - vc.cam[0], vy = py - vc.cam[1], vz = pz - vc.cam[2];
       const float len = sqrtf((vx * vx + vy * vy) + vz * vz);
