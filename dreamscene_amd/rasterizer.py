@@ -226,7 +226,12 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
             keep_bufs = (buf, buf2)
             view_src = {k: (buf2, offs2[k]) if k in NSIZED else (buf, offs[k]) for k in offs}
         else:
-            cap = int(hint * 1.5) + 65536
+            # capacity = 1.5x the recent maximum, rounded UP to a coarse grid (1/8 octave) so that consecutive calls
+            # ask the caching allocator for identical block sizes (jittering sizes fragment it and end in
+            # device-synchronising hipMalloc/hipFree calls: measured 3.5x slowdown after a few hundred views)
+            want = int(hint * 1.5) + 65536
+            q = max(65536, 1 << max(0, want.bit_length() - 4))
+            cap = (want + q - 1) // q * q
             buf, ptrs, offs = alloc_state(cap)
             bind(ptrs, cap, True)
             pinned = ws.n_pinned
@@ -262,7 +267,10 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     b.scratch, b.scratch_bytes, b.keys_sorted = None, 0, None
     geom.scratch, geom.scratch_bytes, geom.sorted_idx = None, 0, None
     st.keep = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, bg, vm, pm, cp, radii,
-               keep_bufs, color, depth_alpha)   # backward re-reads the output image (suffix sums from checkpoints)
+               keep_bufs, color.detach(), depth_alpha.detach())
+    # ^ backward re-reads the output image (suffix sums from checkpoints). DETACHED aliases on purpose: the objects
+    #   returned to autograd acquire grad_fn -> ctx -> this state; keeping them here would close a reference cycle
+    #   and defer every free to Python's cyclic GC (measured: memory bloat and 5x slowdown after ~500 views).
     out = dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, N=N)
     if want_aux:
         def view(name, dtype, count, shape=None):

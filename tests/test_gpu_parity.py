@@ -288,3 +288,33 @@ def test_device_side_accumulation_over_views(built_lib, c_oracle):
         a = arena.views[ak].cpu().numpy().reshape(-1)
         r = ref[rk].reshape(-1)
         assert err(a, r) <= TOL * max(1.0, float(np.abs(r).max())), ak
+
+
+def test_state_is_freed_without_cyclic_gc(built_lib):
+    """The saved state (tens of MB per view) must be released by reference counting alone: a ctx -> state ->
+    output tensor -> grad_fn -> ctx cycle would defer every free to Python's cyclic GC and bloat the allocator."""
+    import gc
+    from dreamscene_amd.rasterizer import GaussianRasterizer
+    g, cam = small_scene(P=3000, H=128, W=128, K=16, seed=5)
+    t = {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in g.items()}
+    rast = GaussianRasterizer(raster_settings=settings_for(cam, np.ones(3, np.float32), 3, DEV))
+
+    def one():
+        m2d = torch.zeros(3000, 3, device=DEV, requires_grad=True)
+        img, radii, da = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
+                              scales=t["scales"], rotations=t["rotations"])
+        torch.autograd.grad([img, da], [t["means3D"], t["shs"]], [torch.ones_like(img), torch.ones_like(da)])
+    for _ in range(3):
+        one()
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        for _ in range(20):
+            one()
+        torch.cuda.synchronize()
+        grown = torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+    assert grown < 4 << 20, f"{grown} bytes still allocated after 20 views without gc: reference cycle?"
