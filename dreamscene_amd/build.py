@@ -20,6 +20,7 @@ SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": ["-ffp-contract=off"],
     "render.hip": [],
+    "knn.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-fno-gpu-rdc",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
@@ -43,7 +44,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     cc = hipcc()
     objdir = os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "gsr_common.h"), os.path.join(ROOT, "include", "gsrast.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, "gsr_common.h"), os.path.join(CSRC, "radix_sort.h"),
+               os.path.join(ROOT, "include", "gsrast.h"), os.path.abspath(__file__)]
     jobs = []
     for src, flags in SOURCES.items():
         s = os.path.join(CSRC, src)

@@ -17,187 +17,9 @@
 // memory and clamps it to the capacity of the caller's buffers, so the whole forward can be enqueued without a
 // host round trip; the host checks N against the capacity afterwards (gsrast.h, gsr_forward_render).
 #include "gsr_common.h"
+#include "radix_sort.h"
 
 namespace {
-
-constexpr int kSortThreads = 256;
-constexpr int kItemsLarge = 16;   // keys per thread for the N-sized tile sort (4096 keys / workgroup)
-constexpr int kItemsSmall = 4;    // ... for the P-sized depth sort: 4x more workgroups, 4x shorter rank chains
-constexpr int kRadixBits = 8;
-constexpr int kRadix = 1 << kRadixBits;
-
-__device__ __forceinline__ uint64_t eff_count(const uint64_t* n_dev, uint64_t cap) {
-  if (!n_dev) return cap;
-  const uint64_t n = *n_dev;
-  return n < cap ? n : cap;
-}
-
-// ---------------------------------------------------------------------------------------------- radix sort
-// One LSD pass = histogram -> per-digit exclusive scan over workgroups -> stable scatter.
-// Element order inside a workgroup: e = blk*4096 + wave*1024 + item*64 + lane.
-template <int ITEMS>
-__device__ __forceinline__ uint64_t sort_index(uint32_t blk, int wave, int item, int lane) {
-  return (uint64_t)blk * (kSortThreads * ITEMS) + (uint64_t)(wave * (64 * ITEMS) + item * 64 + lane);
-}
-
-// lanes of the wave holding the same 8-bit digit as this lane (among `valid` lanes)
-__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid) {
-  unsigned long long m = __ballot(valid);
-#pragma unroll
-  for (int b = 0; b < kRadixBits; ++b) {
-    const bool bit = (d >> b) & 1u;
-    const unsigned long long bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
-  }
-  return m;
-}
-
-template <int ITEMS>
-__global__ void __launch_bounds__(kSortThreads)
-k_radix_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev, uint64_t cap, int shift,
-             uint32_t nblk, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t h[kRadix];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t n = eff_count(n_dev, cap);
-  h[tid] = 0;
-  __syncthreads();
-  if ((uint64_t)blockIdx.x * (kSortThreads * ITEMS) < n) {
-#pragma unroll 4
-    for (int it = 0; it < ITEMS; ++it) {
-      const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-      const bool valid = e < n;
-      const uint32_t d = valid ? ((keys[e] >> shift) & (kRadix - 1)) : 0u;
-      const unsigned long long m = match_digit(d, valid);
-      // one LDS atomic per distinct digit per wave (digits of tile ids / exponents are heavily clustered)
-      if (valid && lane == __ffsll((long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
-    }
-  }
-  __syncthreads();
-  hist[(uint64_t)tid * nblk + blockIdx.x] = h[tid];
-}
-
-// Workgroup d scans row d of hist[256][nblk] in place (exclusive) and writes the row total to totals[d].
-__global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblk,
-                                                    uint32_t* __restrict__ totals) {
-  __shared__ uint32_t wave_tot[4];
-  __shared__ uint32_t carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t* row = hist + (uint64_t)blockIdx.x * nblk;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  constexpr uint32_t kPer = 4;
-  for (uint32_t base = 0; base < nblk; base += 256 * kPer) {
-    uint32_t x[kPer];
-    uint32_t s = 0;
-    const uint32_t first = base + tid * kPer;
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {
-      x[k] = (first + k < nblk) ? row[first + k] : 0u;
-      s += x[k];
-    }
-    uint32_t inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wave_tot[w];
-    const uint32_t carry = carry_s;
-    uint32_t run = carry + woff + inc - s;
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {
-      if (first + k < nblk) row[first + k] = run;
-      run += x[k];
-    }
-    __syncthreads();
-    if (tid == 255) carry_s = carry + woff + inc;
-    __syncthreads();
-  }
-  if (tid == 0) totals[blockIdx.x] = carry_s;
-}
-
-// IOTA: values are the element indices themselves (first pass of the depth sort), vals_in unused.
-template <bool IOTA, int ITEMS>
-__global__ void __launch_bounds__(kSortThreads)
-k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint64_t* __restrict__ n_dev,
-                uint64_t cap, int shift, uint32_t nblk, const uint32_t* __restrict__ hist,
-                const uint32_t* __restrict__ totals) {
-  __shared__ uint32_t wh[4][kRadix];   // running per-wave digit counters, then per-wave global bases
-  __shared__ uint32_t dbase[kRadix];   // exclusive scan of the 256 digit totals
-  __shared__ uint32_t wtot[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t n = eff_count(n_dev, cap);
-  if ((uint64_t)blockIdx.x * (kSortThreads * ITEMS) >= n) return;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
-  {
-    const uint32_t x = totals[tid];
-    uint32_t inc = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wtot[w];
-    dbase[tid] = woff + inc - x;
-  }
-  __syncthreads();
-  volatile uint32_t* mywh = wh[wave];
-  uint32_t key[ITEMS];
-  uint32_t val[ITEMS];
-  uint32_t rank[ITEMS];
-  const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-    const bool valid = e < n;
-    key[it] = valid ? keys_in[e] : 0xFFFFFFFFu;
-    val[it] = IOTA ? (uint32_t)e : (valid ? vals_in[e] : 0u);
-  }
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-    const bool valid = e < n;
-    const uint32_t d = (key[it] >> shift) & (kRadix - 1);
-    const unsigned long long m = match_digit(d, valid);
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t old = 0;
-    if (valid && lane == leader) {
-      old = mywh[d];
-      mywh[d] = old + (uint32_t)__popcll(m);
-    }
-    old = (uint32_t)__shfl((int)old, valid ? leader : lane, 64);
-    rank[it] = old + (uint32_t)__popcll(m & lt);
-  }
-  __syncthreads();
-  {
-    uint32_t run = dbase[tid] + hist[(uint64_t)tid * nblk + blockIdx.x];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t c = wh[w][tid];
-      wh[w][tid] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-    if (e < n) {
-      const uint32_t d = (key[it] >> shift) & (kRadix - 1);
-      const uint32_t pos = wh[wave][d] + rank[it];
-      keys_out[pos] = key[it];
-      vals_out[pos] = val[it];
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------- depth-ordered counts
 // Per-256 sums of tiles_touched taken in depth order (feeds the scan that yields N and the emission offsets).
@@ -335,43 +157,6 @@ k_rebuild_keys(const uint32_t* __restrict__ tile_keys, const uint32_t* __restric
   if (j >= n) return;
   const uint32_t dbits = __float_as_uint(splat[12 * (size_t)point_list[j] + 6]);
   keys64[j] = ((uint64_t)tile_keys[j] << 32) | dbits;
-}
-
-__host__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-uint32_t sort_blocks(uint64_t n, int items) {
-  const uint64_t t = (uint64_t)kSortThreads * items;
-  return (uint32_t)((n + t - 1) / t);
-}
-
-// One full LSD sort of (u32 key, u32 value) over the key bits [0, bits). Buffers ping-pong between (k0,v0) and
-// (k1,v1); returns 0 if the result is in (k0,v0), 1 if in (k1,v1). iota: values of the first executed pass are
-// the element indices. skip_mask: bit p set = digit p is identical in all keys, the pass is the identity: skipped.
-template <int ITEMS>
-int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
-                   int bits, bool iota, uint32_t skip_mask, uint32_t* hist, uint32_t* totals, hipStream_t stream) {
-  const uint32_t nblk = sort_blocks(cap, ITEMS);
-  const int passes = (bits + kRadixBits - 1) / kRadixBits;
-  uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
-  int flips = 0;
-  bool first = true;
-  for (int p = 0; p < passes; ++p) {
-    if ((skip_mask >> p) & 1u) continue;
-    const int shift = p * kRadixBits;
-    hipLaunchKernelGGL(k_radix_hist<ITEMS>, dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift, nblk, hist);
-    hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals);
-    if (iota && first)
-      hipLaunchKernelGGL((k_radix_scatter<true, ITEMS>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb,
-                         n_dev, cap, shift, nblk, hist, totals);
-    else
-      hipLaunchKernelGGL((k_radix_scatter<false, ITEMS>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb,
-                         n_dev, cap, shift, nblk, hist, totals);
-    first = false;
-    uint32_t* t = ka; ka = kb; kb = t;
-    t = va; va = vb; vb = t;
-    ++flips;
-  }
-  return flips & 1;
 }
 
 }  // namespace

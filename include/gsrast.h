@@ -193,6 +193,13 @@ int gsr_forward_render(const GsrView*, const GsrGeom*, uint64_t n_pairs, GsrBinn
 int gsr_backward(const GsrView*, const GsrGaussians*, const GsrGeom*, const GsrBinning*, const GsrImages*,
                  const GsrImageGrads*, GsrGrads*, void* stream, GsrProfile* prof);
 
+/* ---- replacement of `simple_knn._C.distCUDA2` (gs_renderer.py:9, 590-593) --------
+ * out[i] = mean of the squared distances from points[i] to its 3 nearest other points (exact; FLT_MAX stands in
+ * for neighbours that do not exist when n < 4). points [n,3] fp32, out [n] fp32, both on the device; scratch:
+ * gsr_knn_scratch_bytes(n) bytes, 256-byte aligned. Enqueued on `stream`, no host synchronisation. */
+size_t gsr_knn_scratch_bytes(int32_t n);
+int gsr_knn_mean_dist2(const float* points, int32_t n, float* out, void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
