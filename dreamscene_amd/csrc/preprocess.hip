@@ -245,7 +245,7 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
 
   bool vis = false;
   float px = 0, py = 0, pz = 0;
-  float q0x = 0, q0y = 0, ca_ = 0, cb_ = 0, cc_ = 0, depth = 0, opac = 0, ext_x = -1.f, ext_y = -1.f;
+  float q0x = 0, q0y = 0, ca_ = 0, cb_ = 0, cc_ = 0, depth = 0, opac = 0, tau_ = -1.f;
   int32_t radius = 0;
   uint32_t ntiles = 0;
   if (i < P) {
@@ -291,14 +291,11 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
           ca_ = e.cc * inv; cb_ = -e.cb * inv; cc_ = e.ca * inv;
           depth = e.tz;
           opac = g.opacities[i];
-          // Conservative screen extents of the region where this splat can pass the alpha >= 1/255 gate:
-          // d^T Conic d <= 2 ln(255 sigma)  =>  |dx| <= sqrt(tau * cov_xx). Used only to skip work that cannot
-          // contribute (render.hip); negative = contributes nowhere. Not part of any parity artefact.
-          if (opac * 255.0f > 1.0f) {
-            const float tau = 2.0f * logf(opac * 255.0f) * 1.0001f;
-            ext_x = sqrtf(tau * e.ca) * 1.0001f + 0.02f;
-            ext_y = sqrtf(tau * e.cc) * 1.0001f + 0.02f;
-          }
+          // Level of the conic form below which this splat can pass the alpha >= 1/255 gate:
+          // sigma exp(-q/2) >= 1/255  <=>  q = d^T Conic d <= 2 ln(255 sigma) =: tau (slightly inflated).
+          // Used only to skip (pixel block, splat) pairs that cannot contribute (render.hip); negative = the
+          // splat contributes nowhere. Not part of any parity artefact.
+          if (opac * 255.0f > 1.0f) tau_ = 2.0f * logf(opac * 255.0f) * 1.0001f + 0.001f;
         } else {
           radius = 0;
         }
@@ -366,7 +363,7 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
       float4* o = reinterpret_cast<float4*>(splat + 12 * i);
       o[0] = make_float4(q0x, q0y, ca_, cb_);
       o[1] = make_float4(cc_, opac, depth, rgb[0]);
-      o[2] = make_float4(rgb[1], rgb[2], ext_x, ext_y);
+      o[2] = make_float4(rgb[1], rgb[2], tau_, 0.f);
     }
   }
 

@@ -67,28 +67,50 @@ __device__ __forceinline__ TilePix tile_pixel(int tile, int gx, int W, int H) {
   return p;
 }
 
-// 4-bit mask: which of the tile's four 8x8 blocks (bit = wave index) the splat's gate region can touch.
-__device__ __forceinline__ uint32_t block_mask(const float4 q0, const float4 q2, int tile_x0, int tile_y0) {
-  const float ex = q2.z, ey = q2.w;
-  if (!(ex >= 0.f)) return 0u;
-  const float x0 = (float)tile_x0, y0 = (float)tile_y0;
-  const bool xl = (q0.x - ex <= x0 + 7.f) && (q0.x + ex >= x0);
-  const bool xr = (q0.x - ex <= x0 + 15.f) && (q0.x + ex >= x0 + 8.f);
-  const bool yt = (q0.y - ey <= y0 + 7.f) && (q0.y + ey >= y0);
-  const bool yb = (q0.y - ey <= y0 + 15.f) && (q0.y + ey >= y0 + 8.f);
-  return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
+// Can the splat pass the alpha gate anywhere on the W1 x W1 pixel block with origin (bx, by)?  Exact up to the
+// inflation of tau: minimum of the convex form q(d) = A dx^2 + 2 B dx dy + C dy^2 over the block's rectangle (in
+// d = centre - pixel coordinates) compared with tau. The minimum is 0 if the centre lies inside, else it sits on
+// one of the four edges, where q restricted to the edge is a 1-D parabola with a clamped vertex.
+template <int W1>
+__device__ __forceinline__ bool block_reach(float A, float B, float C, float iA, float iC, float tau, float cx, float cy,
+                                            float bx, float by) {
+  const float dx1 = cx - bx, dx0 = dx1 - (float)(W1 - 1), dy1 = cy - by, dy0 = dy1 - (float)(W1 - 1);
+  if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
+  float qmin;
+  {
+    const float y = fminf(dy1, fmaxf(dy0, -B * dx0 * iC));
+    qmin = A * dx0 * dx0 + (2.f * B * dx0 + C * y) * y;
+  }
+  {
+    const float y = fminf(dy1, fmaxf(dy0, -B * dx1 * iC));
+    qmin = fminf(qmin, A * dx1 * dx1 + (2.f * B * dx1 + C * y) * y);
+  }
+  {
+    const float x = fminf(dx1, fmaxf(dx0, -B * dy0 * iA));
+    qmin = fminf(qmin, C * dy0 * dy0 + (2.f * B * dy0 + A * x) * x);
+  }
+  {
+    const float x = fminf(dx1, fmaxf(dx0, -B * dy1 * iA));
+    qmin = fminf(qmin, C * dy1 * dy1 + (2.f * B * dy1 + A * x) * x);
+  }
+  return qmin <= tau;
 }
 
-// Same for the four 4x4 blocks (bit = wave index) of an 8x8 pixel quarter with origin (x0, y0).
-__device__ __forceinline__ uint32_t block_mask4(const float4 q0, const float4 q2, int qx0, int qy0) {
-  const float ex = q2.z, ey = q2.w;
-  if (!(ex >= 0.f)) return 0u;
-  const float x0 = (float)qx0, y0 = (float)qy0;
-  const bool xl = (q0.x - ex <= x0 + 3.f) && (q0.x + ex >= x0);
-  const bool xr = (q0.x - ex <= x0 + 7.f) && (q0.x + ex >= x0 + 4.f);
-  const bool yt = (q0.y - ey <= y0 + 3.f) && (q0.y + ey >= y0);
-  const bool yb = (q0.y - ey <= y0 + 7.f) && (q0.y + ey >= y0 + 4.f);
-  return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
+// 4-bit mask over the 2x2 grid of W1 x W1 blocks with origin (x0, y0): bit (wave index) set = the splat can reach it.
+// W1 = 8: the four 8x8 blocks of a 16x16 tile (K7); W1 = 4: the four 4x4 blocks of an 8x8 quarter (K6).
+template <int W1>
+__device__ __forceinline__ uint32_t block_mask_t(const float4 q0, const float4 q1, const float4 q2, int x0i, int y0i) {
+  const float tau = q2.z;
+  if (!(tau >= 0.f)) return 0u;
+  const float A = q0.z, B = q0.w, C = q1.x;
+  const float iA = 1.0f / A, iC = 1.0f / C;
+  const float x0 = (float)x0i, y0 = (float)y0i;
+  uint32_t m = 0;
+  m |= (uint32_t)block_reach<W1>(A, B, C, iA, iC, tau, q0.x, q0.y, x0, y0);
+  m |= (uint32_t)block_reach<W1>(A, B, C, iA, iC, tau, q0.x, q0.y, x0 + (float)W1, y0) << 1;
+  m |= (uint32_t)block_reach<W1>(A, B, C, iA, iC, tau, q0.x, q0.y, x0, y0 + (float)W1) << 2;
+  m |= (uint32_t)block_reach<W1>(A, B, C, iA, iC, tau, q0.x, q0.y, x0 + (float)W1, y0 + (float)W1) << 3;
+  return m;
 }
 
 template <int CTRL>
@@ -244,7 +266,7 @@ k_render_fwd(const int W, const int H, const uint32_t* __restrict__ work, float*
     for (uint32_t base = r0; base < r1; base += kBatch, buf ^= 1) {
       const int n = (int)min((uint32_t)kBatch, r1 - base);
       st.s0[buf][tid] = n0; st.s1[buf][tid] = n1; st.s2[buf][tid] = n2;
-      st.smask[buf][tid] = (tid < n) ? block_mask4(n0, n2, q_x0, q_y0) : 0u;
+      st.smask[buf][tid] = (tid < n) ? block_mask_t<4>(n0, n1, n2, q_x0, q_y0) : 0u;
       if (SCORE) st.sid[buf][tid] = nid;
       if (__syncthreads_count(done) == 256) break;
       if (base != r0) {
@@ -457,7 +479,7 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const
     }
     s0[tid] = n0; s1[tid] = n1; s2[tid] = n2;
     sid[tid] = nid;
-    smask[tid] = (tid < n) ? block_mask(n0, n2, tile_x0, tile_y0) : 0u;
+    smask[tid] = (tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u;
   }
 
   const float Tf = p.inside ? final_T[pix] : 0.f;

@@ -74,8 +74,9 @@ typedef struct GsrGaussians {
 
 /* Projected per-Gaussian state: written by gsr_forward_project, read by render and backward (save it).
  * splat holds 12 floats per Gaussian as three float4 rows q0,q1,q2 (row-major [P][12]):
- *   q0 = (x_pix, y_pix, conic_a, conic_b)   q1 = (conic_c, opacity, view_depth, r)   q2 = (g, b, ext_x, ext_y)
- * (ext = conservative half-extents, in pixels, of the region where alpha can reach 1/255; < 0 if nowhere)
+ *   q0 = (x_pix, y_pix, conic_a, conic_b)   q1 = (conic_c, opacity, view_depth, r)   q2 = (g, b, tau, 0)
+ * (tau = 2 ln(255 opacity), slightly inflated: the level of the conic form inside which alpha can reach 1/255;
+ *  < 0 if nowhere; used only to skip work)
  * Rows of culled Gaussians (radii == 0) are left unwritten. */
 typedef struct GsrGeom {
   float* splat;            /* [P,12], 16-byte aligned */
