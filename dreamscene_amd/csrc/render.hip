@@ -157,6 +157,7 @@ k_work_order_fwd(const uint32_t n_tiles, const uint32_t* __restrict__ ranges, ui
   if (tid == 0) {
     uint32_t run = 0;
     for (int b = 33; b >= 0; --b) { cur[b] = run; run += cnt[b]; }
+    work[n_tiles] = n_tiles - cnt[0];          // number of non-empty tiles (a statistic for the host's mode choice)
   }
   __syncthreads();
   for (uint32_t t = tid; t < n_tiles; t += 1024) {
@@ -394,6 +395,110 @@ k_render_fwd(const int W, const int H, const uint32_t* __restrict__ work, float*
   }
 }
 
+// K6, whole-tile variant: work item = one 16x16 tile, 4 waves = four 8x8 blocks, ONE pixel per lane. It spends the
+// fewest instructions per (pixel, splat) evaluation (about half of the list-parallel kernel) and is the right
+// choice when thousands of similar, shallow tiles saturate the machine (camera inside a room: every tile active,
+// ~250 entries each); with few, deep tiles its long per-pixel chains make the tail (1 M Gaussians at 512^2:
+// 377 us vs 124 us). The host picks the variant per call from the previous view's statistics
+// (GsrBinning.fwd_mode); both produce the same images up to the association of the transmittance product.
+template <bool SCORE>
+__global__ void __launch_bounds__(256)
+k_render_fwd_tile(const int W, const int H, const uint32_t* __restrict__ work, float* __restrict__ ckpt,
+                  const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                  const float4* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ out_color,
+                  float* __restrict__ out_da, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                  uint32_t* __restrict__ tile_depth, float* __restrict__ score, const int score_mode) {
+  __shared__ Stage st;
+  const int gx = (W + GSR_TILE - 1) / GSR_TILE;
+  const int tile = (int)work[blockIdx.x];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const TilePix p = tile_pixel(tile, gx, W, H);
+  const int tile_x0 = p.bx - (wave & 1) * 8, tile_y0 = p.by - (wave >> 1) * 8;
+  const float pxf = (float)p.px, pyf = (float)p.py;
+  const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+  bool done = !p.inside;
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
+  uint32_t last = 0;
+  uint32_t nid = 0;
+  float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+  if (r0 + tid < r1) {
+    nid = point_list[r0 + tid];
+    const float4* r = splat + 3 * (size_t)nid;
+    n0 = r[0]; n1 = r[1]; n2 = r[2];
+  }
+  int buf = 0;
+  for (uint32_t base = r0; base < r1; base += kBatch, buf ^= 1) {
+    const int n = (int)min((uint32_t)kBatch, r1 - base);
+    st.s0[buf][tid] = n0; st.s1[buf][tid] = n1; st.s2[buf][tid] = n2;
+    st.smask[buf][tid] = (tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u;
+    if (SCORE) st.sid[buf][tid] = nid;
+    if (__syncthreads_count(done) == 256) break;
+    if (base != r0 && p.inside) {
+      float* ck = ckpt + (size_t)(base / kBatch) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
+      ck[0] = T; ck[256] = C0; ck[512] = C1; ck[768] = C2; ck[1024] = Dp; ck[1280] = Wt;
+    }
+    {
+      const uint32_t idx = base + kBatch + tid;
+      if (idx < r1) {
+        nid = point_list[idx];
+        const float4* r = splat + 3 * (size_t)nid;
+        n0 = r[0]; n1 = r[1]; n2 = r[2];
+      }
+    }
+    for (int k = 0; k < kBatch / 64; ++k) {
+      if (k * 64 >= n) break;
+      unsigned long long bits = __ballot((st.smask[buf][k * 64 + lane] >> wave) & 1u);
+      while (bits) {
+        if (__ballot(!done) == 0ull) break;
+        const int j = k * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1ull;
+        const float4 a = st.s0[buf][j];
+        const float4 b = st.s1[buf][j];
+        const float4 c = st.s2[buf][j];
+        const float dx = a.x - pxf, dy = a.y - pyf;
+        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+        const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
+        const float test_T = T * (1.0f - alpha);
+        bool hit = !done & (power <= 0.0f) & (alpha >= GSR_ALPHA_MIN);
+        const bool stop = hit & (test_T < GSR_T_MIN);
+        done = done | stop;
+        hit = hit & !stop;
+        const float w = hit ? alpha * T : 0.0f;
+        if (SCORE) {
+          const unsigned long long hm = __ballot(hit);       // one atomic per (wave, splat), not per pixel
+          if (hm) {
+            float sc;
+            if (score_mode == 0) {
+              sc = b.y * (float)__popcll(hm);
+            } else {
+              sc = gsr_wave_sum_to_lane63(w);
+              sc = __shfl(sc, 63, 64);
+            }
+            if (lane == 0) unsafeAtomicAdd(score + st.sid[buf][j], sc);
+          }
+        }
+        C0 = fmaf(b.w, w, C0); C1 = fmaf(c.x, w, C1); C2 = fmaf(c.y, w, C2);
+        Dp = fmaf(b.z, w, Dp);
+        Wt += w;
+        T = hit ? test_T : T;
+        last = hit ? ((base - r0) + (uint32_t)j + 1u) : last;
+      }
+    }
+  }
+  if (p.inside) {
+    const size_t pix = (size_t)p.py * W + p.px, HW = (size_t)H * W;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    out_color[pix] = C0 + T * bg[0];
+    out_color[HW + pix] = C1 + T * bg[1];
+    out_color[2 * HW + pix] = C2 + T * bg[2];
+    out_da[pix] = Dp;
+    out_da[HW + pix] = Wt;
+  }
+  const uint32_t wm = gsr_wave_max_u32(last);
+  if (lane == 0 && wm) atomicMax(tile_depth + tile, wm);
+}
+
 // --------------------------------------------------------------------------------------------------------- K7
 // Transposed butterfly over the 64 lanes for 10 values (see file header). On return lane L holds, for
 // j = L & 3 (j < 3) and row r = L >> 4, the wave total of component comp(j, r) = 4 j + ((r & 1) << 1 | (r >> 1)):
@@ -587,6 +692,19 @@ int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinnin
   const float4* splat = reinterpret_cast<const float4*>(geom.splat);
   uint32_t* work = b.tile_work;
   hipLaunchKernelGGL(k_work_order_fwd, dim3(1), dim3(1024), 0, stream, tiles, b.ranges, img.tile_depth, work);
+  if (b.fwd_mode == 1) {
+    if (img.important_score)
+      hipLaunchKernelGGL(k_render_fwd_tile<true>, dim3(tiles), dim3(256), 0, stream, v.image_width, v.image_height, work,
+                         img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T,
+                         img.n_contrib, img.tile_depth, img.important_score, v.score_mode);
+    else
+      hipLaunchKernelGGL(k_render_fwd_tile<false>, dim3(tiles), dim3(256), 0, stream, v.image_width, v.image_height,
+                         work, img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T,
+                         img.n_contrib, img.tile_depth, (float*)nullptr, 0);
+    GSR_HIP(hipGetLastError());
+    if (b.stats_host) GSR_HIP(hipMemcpyAsync(b.stats_host, work + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    return GSR_OK;
+  }
   const uint32_t grid = tiles * 4;
   if (img.important_score) {
     hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, work,
@@ -598,6 +716,7 @@ int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinnin
                        img.final_T, img.n_contrib, img.tile_depth, (float*)nullptr, 0);
   }
   GSR_HIP(hipGetLastError());
+  if (b.stats_host) GSR_HIP(hipMemcpyAsync(b.stats_host, work + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   return GSR_OK;
 }
 

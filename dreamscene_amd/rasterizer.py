@@ -91,10 +91,12 @@ class _Workspace:
     def __init__(self, dev):
         self.dev = dev
         self.n_pinned = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.stats_pinned = torch.zeros(2, dtype=torch.int32).pin_memory()   # [0]: non-empty tiles of the last view
         self.event = torch.cuda.Event()
         self.proj_scratch = None
         self.sort_scratch = None
         self.hint = {}           # (P, H, W) -> decaying max of recent pair counts
+        self.last_stats = {}     # (P, H, W) -> (non-empty tiles or None = read the pinned word, pair count)
 
     def scratch(self, which: str, nbytes: int) -> torch.Tensor:
         t = getattr(self, which)
@@ -108,6 +110,8 @@ _WORKSPACES = {}
 # "auto": speculate the pair capacity from previous calls and enqueue the whole forward without draining the GPU
 # (falls back to an exact re-run if the speculation was too small); "sync": always the exact two-phase forward.
 FORWARD_MODE = "auto"
+# forward compositing variant (GsrBinning.fwd_mode): None = choose per call from the previous view's statistics
+FWD_MODE: Optional[int] = None
 
 
 def _workspace(dev, stream) -> _Workspace:
@@ -202,6 +206,13 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
             b.bwd_items_cap = cap // 256 + tiles
             b.keys_sorted = ptrs["keys_sorted"] if want_keys else None
             b.scratch, b.scratch_bytes, b.count_on_device = sort_scratch.data_ptr(), sort_scratch.numel(), int(on_device)
+            # forward variant from the PREVIOUS view's statistics (complete by now; a wrong guess only costs speed):
+            # whole-tile items when thousands of shallow tiles saturate the machine, quarter items otherwise
+            last_active, last_n = ws.last_stats.get((P, H, W), (0, 0))
+            act = int(ws.stats_pinned[0]) if last_active is None else last_active
+            b.fwd_mode = int(FWD_MODE if FWD_MODE is not None else
+                             (act >= 2048 and last_n > 0 and last_n / max(act, 1) < 1024))
+            b.stats_host = ws.stats_pinned.data_ptr()
             im.final_T, im.n_contrib, im.tile_depth = ptrs["final_T"], ptrs["n_contrib"], ptrs["tile_depth"]
             im.ckpt = ptrs["ckpt"]
 
@@ -260,6 +271,7 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
                 keep_bufs = (buf, buf2)
                 cap = N
         st.N = N
+        ws.last_stats[(P, H, W)] = (None, N)     # the tile count lands in stats_pinned asynchronously
         if mode == "auto":
             ws.hint[(P, H, W)] = max(N, int(ws.hint.get((P, H, W), 0) * 0.9))
     st.geom, st.binning, st.images = geom, b, im

@@ -96,9 +96,9 @@ typedef struct GsrGeom {
 typedef struct GsrBinning {
   uint32_t* point_list; /* [N] Gaussian index per (tile, depth)-sorted pair                         */
   uint32_t* ranges;     /* [tiles,2] (start,end) into point_list; (0,0) for an empty tile            */
-  uint32_t* tile_work;  /* [tiles + 2 + 2*bwd_items_cap] u32: forward work list (tile ids, heaviest first), then the
-                           backward's (tile, segment) item list; written by the forward and by the backward: keep
-                           it with the saved state                                                                */
+  uint32_t* tile_work;  /* [tiles + 2 + 2*bwd_items_cap] u32: forward work list (tile ids, heaviest first) followed by
+                           the number of non-empty tiles, then the backward's (tile, segment) item list; written by
+                           the forward and by the backward: keep it with the saved state                          */
   uint32_t bwd_items_cap; /* capacity of the backward item list: >= n_pairs / 256 + tiles                         */
   uint32_t reserved2_;
   uint64_t* keys_sorted;/* [N] optional: receives the sorted 64-bit keys (tile<<32 | depth bits); may be NULL */
@@ -109,7 +109,11 @@ typedef struct GsrBinning {
                               scratch; the kernels take the true N from the device (GsrGeom.block_offsets tail)
                               and clamp it to the capacity; the caller compares N with the capacity afterwards
                               and re-runs gsr_forward_render with larger buffers if it did not fit            */
-  int32_t reserved_;
+  int32_t fwd_mode;        /* forward compositing variant: 0 = four 8x8-quarter work items per tile, 4 lanes per pixel
+                              (few / deep tiles); 1 = one work item per tile, one pixel per lane (thousands of
+                              shallow tiles). Same semantics; a performance choice                 */
+  uint32_t* stats_host;    /* optional page-locked host word: receives (asynchronously) the number of non-empty
+                              tiles of this view, the statistic a caller can base the next call's fwd_mode on    */
 } GsrBinning;
 
 /* Per-pixel outputs (scene_gaussian.py:1012,1023) and the per-pixel state backward needs. */

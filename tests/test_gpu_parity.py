@@ -373,3 +373,37 @@ def test_score_mode_alpha_T(built_lib, c_oracle):
                          score=True)
     ref = f["important_score"]
     assert err(out["score"].cpu().numpy(), ref) <= 1e-4 * max(1.0, float(ref.max()))
+
+
+def test_whole_tile_forward_variant(built_lib, c_oracle):
+    """GsrBinning.fwd_mode = 1 (one work item per tile, one pixel per lane): same parity bars as the default variant,
+    including the checkpoints the segmented backward starts from and the score output."""
+    from dreamscene_amd import rasterizer as R, synth
+    old = R.FWD_MODE
+    try:
+        R.FWD_MODE = 1
+        g, cam = small_scene(P=2000, H=128, W=112, K=16, seed=13)
+        bg = np.array([1.0, 0.4, 0.1], np.float32)
+        out, _ = _run_hip(g, cam, bg, 3)
+        v = oracle_view(c_oracle, cam, 2000, 16, 3, bg)
+        f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        _check_forward(out, f, 2000)
+        _grad_check(g, cam, bg, 3, c_oracle)
+        # deep lists: multi-segment backward from this variant's checkpoints
+        P, H, W = 30000, 128, 128
+        g = synth.g_object(P, seed=78, K=16)
+        g["scales"] = (g["scales"] * 1.5).astype(np.float32)
+        cam = synth.object_cameras(3, H, W, radius=3.2)[2]
+        rep = _grad_check(g, cam, np.ones(3, np.float32), 3, c_oracle)
+        assert rep
+        s = settings_for(cam, np.ones(3, np.float32), 3, DEV, score_flag=True)
+        t = _to_dev(g)
+        o, _ = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None)
+        v = oracle_view(c_oracle, cam, P, 16, 3, np.ones(3, np.float32))
+        f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
+                             score=True)
+        assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 512
+        ref = f["important_score"]
+        assert err(o["score"].cpu().numpy(), ref) <= 1e-4 * max(1.0, float(ref.max()))
+    finally:
+        R.FWD_MODE = old

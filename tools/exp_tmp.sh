@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for a in "50 10" "50 5" "30 10" "100 5" "50 10 --no-roofline"; do
- set -- $a
- echo "steps $1 warmup $2 $3: $(python bench.py --steps $1 --warmup $2 $3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
+for cfg in "--gaussians 500000 --res 1024" "--scene indoor --gaussians 2000000 --res 1024" "--gaussians 1000000 --res 512" "--gaussians 100000 --res 512"; do
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline $cfg 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], {k:round(v) for k,v in d['roofline']['stage_us_warmup'].items() if 'render' in k})"
 done
