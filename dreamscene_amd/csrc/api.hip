@@ -8,8 +8,8 @@ int gsr_launch_preprocess(const GsrView&, const GsrGaussians&, GsrGeom&, hipStre
 int gsr_launch_preprocess_bwd(const GsrView&, const GsrGaussians&, const GsrGeom&, const GsrGrads&, hipStream_t);
 int gsr_launch_depth_order(GsrGeom&, int32_t P, uint64_t* n_pairs_dev, uint32_t depth_skip_mask, hipStream_t,
                            GsrProfile*);
-int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint64_t* n_dev, GsrBinning&, hipStream_t,
-                       GsrProfile*);
+int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint64_t* n_dev, const uint64_t* n_dev_vis,
+                       GsrBinning&, hipStream_t, GsrProfile*);
 int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, GsrImages&, hipStream_t);
 int gsr_launch_render_bwd(const GsrView&, const GsrGeom&, const GsrBinning&, const GsrImages&, const GsrImageGrads&,
                           GsrGrads&, hipStream_t);
@@ -149,7 +149,8 @@ int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, 
   hipStream_t stream = (hipStream_t)stream_;
   if (v->P == 0) n_pairs = 0;
   const uint64_t* n_dev = (b->count_on_device && v->P > 0) ? n_pairs_device(geom, v->P) : nullptr;
-  rc = gsr_launch_binning(*v, *geom, n_pairs, n_dev, *b, stream, prof);
+  const uint64_t* n_vis = v->P > 0 ? n_pairs_device(geom, v->P) + 1 : nullptr;
+  rc = gsr_launch_binning(*v, *geom, n_pairs, n_dev, n_vis, *b, stream, prof);
   if (rc) return rc;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_RENDER_FWD);

@@ -24,12 +24,12 @@ namespace {
 // ------------------------------------------------------------------------------------- depth-ordered counts
 // Per-256 sums of tiles_touched taken in depth order (feeds the scan that yields N and the emission offsets).
 __global__ void __launch_bounds__(256)
-k_sorted_block_sums(const int P, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ tiles_touched,
-                    uint32_t* __restrict__ block_sums) {
+k_sorted_block_sums(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sorted_idx,
+                    const uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t wave_tiles[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t s = (int64_t)blockIdx.x * 256 + tid;
-  uint32_t c = (s < P) ? tiles_touched[sorted_idx[s]] : 0u;
+  uint32_t c = (s < (int64_t)*n_vis) ? tiles_touched[sorted_idx[s]] : 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
   if (lane == 0) wave_tiles[wave] = c;
@@ -74,7 +74,8 @@ __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t* __restrict__ sum
 // ------------------------------------------------------------------------------------------- pair emission
 // Thread s handles the s-th Gaussian in depth order; pairs beyond `cap` are dropped (capacity mode).
 __global__ void __launch_bounds__(256)
-k_emit_pairs(const int P, const int W, const int H, const float* __restrict__ splat, const int32_t* __restrict__ radii,
+k_emit_pairs(const uint64_t* __restrict__ n_vis, const int W, const int H, const float* __restrict__ splat,
+             const int32_t* __restrict__ radii,
              const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ sorted_idx,
              const uint32_t* __restrict__ block_offsets, const uint64_t cap, uint32_t* __restrict__ keys,
              uint32_t* __restrict__ vals, uint32_t* __restrict__ ranges, const uint32_t n_range_words) {
@@ -84,8 +85,9 @@ k_emit_pairs(const int P, const int W, const int H, const float* __restrict__ sp
   // tile ranges start out as (0,0): cleared here (grid-stride) instead of by a separate fill launch
   for (uint32_t w = (uint32_t)s; w < n_range_words; w += gridDim.x * 256u) ranges[w] = 0u;
   const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
-  const uint32_t i = (s < P) ? sorted_idx[s] : 0u;
-  const uint32_t cnt = (s < P) ? tiles_touched[i] : 0u;
+  const bool in = s < (int64_t)*n_vis;          // sorted_idx holds the visible Gaussians only, in depth order
+  const uint32_t i = in ? sorted_idx[s] : 0u;
+  const uint32_t cnt = in ? tiles_touched[i] : 0u;
   uint32_t inc = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -202,9 +204,11 @@ int gsr_launch_depth_order(GsrGeom& geom, int32_t P, uint64_t* n_pairs_dev, uint
                            GsrProfile* prof) {
   if (geom.scratch_bytes < gsr_project_scratch_bytes(P) || !geom.scratch) return GSR_ESCRATCH;
   ProjectScratch s = carve_project(geom.scratch, P);
+  uint64_t* n_vis_dev = n_pairs_dev + 1;     // number of visible Gaussians, next to the pair count (block_offsets tail)
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    const int where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, depth_skip_mask,
+    (void)depth_skip_mask;
+    const int where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev,
                                                    s.hist, s.totals, stream);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
@@ -212,7 +216,7 @@ int gsr_launch_depth_order(GsrGeom& geom, int32_t P, uint64_t* n_pairs_dev, uint
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SCAN);
     const uint32_t nb = gsr_num_blocks(P);
-    hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(256), 0, stream, P, geom.sorted_idx, geom.tiles_touched,
+    hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx, geom.tiles_touched,
                        geom.block_offsets);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, geom.block_offsets, nb, n_pairs_dev);
     GSR_HIP(hipGetLastError());
@@ -222,8 +226,8 @@ int gsr_launch_depth_order(GsrGeom& geom, int32_t P, uint64_t* n_pairs_dev, uint
 
 // Emits, tile-sorts and ranges. `cap` = pairs the buffers hold; n_dev (may be NULL = exactly cap pairs) is the
 // true count on the device. On return binning.point_list holds the sorted values.
-int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, const uint64_t* n_dev, GsrBinning& b,
-                       hipStream_t stream, GsrProfile* prof) {
+int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, const uint64_t* n_dev,
+                       const uint64_t* n_dev_vis, GsrBinning& b, hipStream_t stream, GsrProfile* prof) {
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
   if (cap == 0 || v.P == 0) {
     GSR_HIP(hipMemsetAsync(b.ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), stream));
@@ -247,7 +251,7 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
   uint32_t* vb = (passes % 2 == 0) ? vals_t : b.point_list;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_DUPLICATE);
-    hipLaunchKernelGGL(k_emit_pairs, dim3(gsr_num_blocks(v.P)), dim3(256), 0, stream, v.P, v.image_width,
+    hipLaunchKernelGGL(k_emit_pairs, dim3(gsr_num_blocks(v.P)), dim3(256), 0, stream, n_dev_vis, v.image_width,
                        v.image_height, geom.splat, geom.radii, geom.tiles_touched, geom.sorted_idx, geom.block_offsets,
                        cap, keys_a, va, b.ranges, tiles * 2);
     GSR_HIP(hipGetLastError());

@@ -193,7 +193,7 @@ extern "C" int gsr_knn_mean_dist2(const float* points, int32_t n, float* out, vo
   const int nb = (n + 255) / 256;
   hipLaunchKernelGGL(k_knn_bbox, dim3(std::min(nb, 1024)), dim3(256), 0, stream, points, n, bbox);
   hipLaunchKernelGGL(k_knn_cells, dim3(nb), dim3(256), 0, stream, points, n, bbox, k0);
-  const int where = radix_sort_u32<kItemsSmall>(k0, v0, k1, v1, nullptr, m, 24, true, 0u, hist, totals, stream);
+  const int where = radix_sort_u32<kItemsSmall>(k0, v0, k1, v1, nullptr, m, 24, true, nullptr, hist, totals, stream);
   const uint32_t* sk = where ? k1 : k0;
   const uint32_t* sv = where ? v1 : v0;
   hipLaunchKernelGGL(k_knn_ranges, dim3(nb), dim3(256), 0, stream, sk, n, ranges);

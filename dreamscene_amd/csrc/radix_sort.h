@@ -37,7 +37,9 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
   return m;
 }
 
-template <int ITEMS>
+// DROP: elements whose key is the sentinel 0xFFFFFFFF are not counted (and not written by the scatter): the first
+// pass of the depth sort compacts the culled Gaussians away for free, later passes run on the survivors only.
+template <int ITEMS, bool DROP>
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev, uint64_t cap, int shift,
              uint32_t nblk, uint32_t* __restrict__ hist) {
@@ -50,8 +52,10 @@ k_radix_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_d
 #pragma unroll 4
     for (int it = 0; it < ITEMS; ++it) {
       const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-      const bool valid = e < n;
-      const uint32_t d = valid ? ((keys[e] >> shift) & (kRadix - 1)) : 0u;
+      bool valid = e < n;
+      const uint32_t kk = valid ? keys[e] : 0u;
+      if (DROP) valid = valid && (kk != 0xFFFFFFFFu);
+      const uint32_t d = (kk >> shift) & (kRadix - 1);
       const unsigned long long m = match_digit(d, valid);
       // one LDS atomic per distinct digit per wave (digits of tile ids / exponents are heavily clustered)
       if (valid && lane == __ffsll((long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
@@ -105,12 +109,12 @@ __global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist,
 }
 
 // IOTA: values are the element indices themselves (first pass of the depth sort), vals_in unused.
-template <bool IOTA, int ITEMS>
+template <bool IOTA, int ITEMS, bool DROP>
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint64_t* __restrict__ n_dev,
                 uint64_t cap, int shift, uint32_t nblk, const uint32_t* __restrict__ hist,
-                const uint32_t* __restrict__ totals) {
+                const uint32_t* __restrict__ totals, uint64_t* __restrict__ n_out) {
   __shared__ uint32_t wh[4][kRadix];   // running per-wave digit counters, then per-wave global bases
   __shared__ uint32_t dbase[kRadix];   // exclusive scan of the 256 digit totals
   __shared__ uint32_t wtot[4];
@@ -132,6 +136,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     uint32_t woff = 0;
     for (int w = 0; w < wave; ++w) woff += wtot[w];
     dbase[tid] = woff + inc - x;
+    if (DROP && n_out && blockIdx.x == 0 && tid == kSortThreads - 1) *n_out = (uint64_t)(woff + inc);   // survivors
   }
   __syncthreads();
   volatile uint32_t* mywh = wh[wave];
@@ -146,10 +151,13 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     key[it] = valid ? keys_in[e] : 0xFFFFFFFFu;
     val[it] = IOTA ? (uint32_t)e : (valid ? vals_in[e] : 0u);
   }
+  const auto is_valid = [&](int it) {
+    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
+    return (e < n) && (!DROP || key[it] != 0xFFFFFFFFu);
+  };
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
-    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-    const bool valid = e < n;
+    const bool valid = is_valid(it);
     const uint32_t d = (key[it] >> shift) & (kRadix - 1);
     const unsigned long long m = match_digit(d, valid);
     const int leader = __ffsll((long long)m) - 1;
@@ -174,8 +182,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
-    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-    if (e < n) {
+    if (is_valid(it)) {
       const uint32_t d = (key[it] >> shift) & (kRadix - 1);
       const uint32_t pos = wh[wave][d] + rank[it];
       keys_out[pos] = key[it];
@@ -192,33 +199,39 @@ uint32_t sort_blocks(uint64_t n, int items) {
 }
 
 // One full LSD sort of (u32 key, u32 value) over the key bits [0, bits). Buffers ping-pong between (k0,v0) and
-// (k1,v1); returns 0 if the result is in (k0,v0), 1 if in (k1,v1). iota: values of the first executed pass are
-// the element indices. skip_mask: bit p set = digit p is identical in all keys, the pass is the identity: skipped.
+// (k1,v1); returns 0 if the result is in (k0,v0), 1 if in (k1,v1). iota: values of the first pass are the element
+// indices. n_compact (device, may be NULL; only with iota): the first pass drops the elements keyed 0xFFFFFFFF and
+// stores the number of survivors there; the remaining passes (and the caller) work on that many elements.
 template <int ITEMS>
 int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
-                   int bits, bool iota, uint32_t skip_mask, uint32_t* hist, uint32_t* totals, hipStream_t stream) {
+                   int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream) {
   const uint32_t nblk = sort_blocks(cap, ITEMS);
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
   uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
-  int flips = 0;
-  bool first = true;
   for (int p = 0; p < passes; ++p) {
-    if ((skip_mask >> p) & 1u) continue;
     const int shift = p * kRadixBits;
-    hipLaunchKernelGGL(k_radix_hist<ITEMS>, dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift, nblk, hist);
-    hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals);
-    if (iota && first)
-      hipLaunchKernelGGL((k_radix_scatter<true, ITEMS>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb,
-                         n_dev, cap, shift, nblk, hist, totals);
-    else
-      hipLaunchKernelGGL((k_radix_scatter<false, ITEMS>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb,
-                         n_dev, cap, shift, nblk, hist, totals);
-    first = false;
+    if (iota && p == 0 && n_compact) {
+      hipLaunchKernelGGL((k_radix_hist<ITEMS, true>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift,
+                         nblk, hist);
+      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals);
+      hipLaunchKernelGGL((k_radix_scatter<true, ITEMS, true>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb,
+                         n_dev, cap, shift, nblk, hist, totals, n_compact);
+      n_dev = n_compact;
+    } else {
+      hipLaunchKernelGGL((k_radix_hist<ITEMS, false>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift,
+                         nblk, hist);
+      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals);
+      if (iota && p == 0)
+        hipLaunchKernelGGL((k_radix_scatter<true, ITEMS, false>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb,
+                           vb, n_dev, cap, shift, nblk, hist, totals, (uint64_t*)nullptr);
+      else
+        hipLaunchKernelGGL((k_radix_scatter<false, ITEMS, false>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb,
+                           vb, n_dev, cap, shift, nblk, hist, totals, (uint64_t*)nullptr);
+    }
     uint32_t* t = ka; ka = kb; kb = t;
     t = va; va = vb; vb = t;
-    ++flips;
   }
-  return flips & 1;
+  return passes & 1;
 }
 
 }  // namespace

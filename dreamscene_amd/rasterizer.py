@@ -178,7 +178,7 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
         def alloc_state(cap):
             """One allocation for everything the backward re-reads (splat, tile counts, offsets, lists, ranges,
             final_T, n_contrib); carved by offsets, no per-tensor allocations."""
-            sizes = dict(splat=Pm * 48, tiles_touched=Pm * 4, block_offsets=(nb + 4) * 4, point_list=max(cap, 1) * 4,
+            sizes = dict(splat=Pm * 48, tiles_touched=Pm * 4, block_offsets=(nb + 8) * 4, point_list=max(cap, 1) * 4,
                          ranges=tiles * 8, tile_work=(2 * tiles + 2 + 2 * (cap // 256 + tiles)) * 4 + 64,
                          tile_depth=tiles * 4, ckpt=(cap // 256 + 1) * 6 * 256 * 4, final_T=H * W * 4,
                          n_contrib=H * W * 4,

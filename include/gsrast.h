@@ -82,9 +82,9 @@ typedef struct GsrGeom {
   float* splat;            /* [P,12], 16-byte aligned */
   int32_t* radii;          /* [P]  screen radius in pixels, 0 = culled (output `radii`)            */
   uint32_t* tiles_touched; /* [P]  number of 16x16 tiles overlapped                               */
-  uint32_t* block_offsets; /* [gsr_num_blocks(P)+4], 8-byte aligned: exclusive scan of the tile counts of each
+  uint32_t* block_offsets; /* [gsr_num_blocks(P)+8], 8-byte aligned: exclusive scan of the tile counts of each
                               run of 256 Gaussians IN DEPTH ORDER, entry [nb] = N (low 32 bits); the tail holds
-                              the 64-bit N on the device */
+                              the 64-bit N and the 64-bit count of visible Gaussians on the device */
   void* scratch;           /* gsr_project_scratch_bytes(P) bytes, 256-byte aligned: depth-sort buffers. Must stay
                               alive until gsr_forward_render has been enqueued; not needed for backward          */
   size_t scratch_bytes;
