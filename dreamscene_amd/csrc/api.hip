@@ -6,7 +6,7 @@ thread_local int gsr_tls_hip_error = 0;
 // stage launchers (preprocess.hip, binning.hip, render.hip)
 int gsr_launch_preprocess(const GsrView&, const GsrGaussians&, GsrGeom&, hipStream_t);
 int gsr_launch_preprocess_bwd(const GsrView&, const GsrGaussians&, const GsrGeom&, const GsrGrads&, hipStream_t);
-int gsr_launch_depth_order(GsrGeom&, int32_t P, uint64_t* n_pairs_dev, uint32_t depth_skip_mask, hipStream_t,
+int gsr_launch_depth_order(GsrGeom&, const GsrView&, uint64_t* n_pairs_dev, hipStream_t,
                            GsrProfile*);
 int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint64_t* n_dev, const uint64_t* n_dev_vis,
                        GsrBinning&, hipStream_t, GsrProfile*);
@@ -116,7 +116,7 @@ static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geo
     if (rc) return rc;
   }
   uint64_t* n_dev = n_pairs_device(geom, v->P);
-  rc = gsr_launch_depth_order(*geom, v->P, n_dev, 0u, stream, prof);
+  rc = gsr_launch_depth_order(*geom, *v, n_dev, stream, prof);
   if (rc) return rc;
   GSR_HIP(hipMemcpyAsync(n_pairs_host, n_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   if (sync) {

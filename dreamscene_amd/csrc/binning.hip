@@ -10,6 +10,16 @@
 //   3. stable LSD radix sort of the N pairs by tile id (2 passes of 8 bits up to 65536 tiles)
 //        -> order (tile, depth bits, Gaussian index)  == the reference order, bit for bit.
 // Traffic: 4 passes over P x 8 B + 2 passes over N x 8 B instead of 6 passes over N x 12 B.
+//
+// Column path (grids of at most 256 x 256 tiles, i.e. images up to 4096 x 4096): step 2 and the first pass of
+// step 3 are ONE kernel. tile id = ty * gx + tx, so an LSD sort by tile id is "stable by tx, then stable by ty".
+// A Gaussian's pairs with a given tx are its tiles ty = y0..y1-1, contiguous in emission order, so the position of
+// the strip (Gaussian s, column tx) in the tx-sorted list is  colstart[tx] + sum over Gaussians s' < s (depth
+// order) covering tx of h(s')  -- a per-column prefix sum over the depth-ordered rectangles. k_col_hist / k_radix_scan
+// / k_col_plan compute it per run of 256 Gaussians (and N falls out), k_emit_cols writes every pair straight to its
+// tx-sorted position (one lane per tile column walks the run's rectangles), and the remaining pass (by ty, 1-byte
+// keys, workgroups aligned to column starts) also yields the tile ranges: the first workgroup of column tx knows,
+// for every ty, the final position of the first pair of tile (ty, tx).
 // The sorted value list and the tile ranges are bit-exact against oracle/gsr_oracle.c (orc_bin_sort); the
 // 64-bit keys can be reconstructed on request (GsrBinning.keys_sorted) for the parity tests.
 //
@@ -161,6 +171,317 @@ k_rebuild_keys(const uint32_t* __restrict__ tile_keys, const uint32_t* __restric
   keys64[j] = ((uint64_t)tile_keys[j] << 32) | dbits;
 }
 
+
+// =================================================================================== column path (see header)
+constexpr int kColRun = 64;        // Gaussians (in depth order) per emission wave: short runs = many stores in flight
+constexpr int kPass2Items = 16;    // pairs per thread in the ty pass (4096 per workgroup)
+constexpr uint32_t kPass2Block = kSortThreads * kPass2Items;
+
+__device__ __forceinline__ unsigned long long match_digit_n(uint32_t d, bool valid, int nbits) {
+  unsigned long long m = __ballot(valid);
+  for (int b = 0; b < nbits; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+__device__ __forceinline__ uint32_t rect_x0(uint32_t r) { return r & 255u; }
+__device__ __forceinline__ uint32_t rect_y0(uint32_t r) { return (r >> 8) & 255u; }
+__device__ __forceinline__ uint32_t rect_w(uint32_t r) { return ((r >> 16) & 255u) + 1u; }
+__device__ __forceinline__ uint32_t rect_h(uint32_t r) { return (r >> 24) + 1u; }
+
+// Per run of 64 depth-ordered Gaussians (one wave): pairs per tile column -> hist1[tx][run]; also the rectangles in
+// depth order.
+__global__ void __launch_bounds__(256)
+k_col_hist(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sorted_idx,
+           const uint32_t* __restrict__ rects, uint32_t* __restrict__ rect_sorted, const int gx, const uint32_t nrun,
+           uint32_t* __restrict__ hist1) {
+  __shared__ uint32_t bins[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) bins[w][tid] = 0;
+  __syncthreads();
+  uint32_t* mybins = bins[wave];
+  const int64_t s = (int64_t)blockIdx.x * 256 + tid;
+  const bool in = s < (int64_t)*n_vis;
+  uint32_t r = 0, w = 0, h = 0, x0 = 0;
+  if (in) {
+    r = rects[sorted_idx[s]];
+    rect_sorted[s] = r;
+    x0 = rect_x0(r); w = rect_w(r); h = rect_h(r);
+  }
+  constexpr uint32_t kCoop = 8;
+  if (in && w <= kCoop)
+    for (uint32_t c = 0; c < w; ++c) atomicAdd(&mybins[x0 + c], h);
+  unsigned long long big = __ballot(in && w > kCoop);
+  while (big) {   // wide footprints: the wave adds one Gaussian's columns together
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const uint32_t sx0 = (uint32_t)__shfl((int)x0, src, 64), sw = (uint32_t)__shfl((int)w, src, 64);
+    const uint32_t sh = (uint32_t)__shfl((int)h, src, 64);
+    for (uint32_t c = lane; c < sw; c += 64) atomicAdd(&mybins[sx0 + c], sh);
+  }
+  __syncthreads();
+  if (tid < gx) {
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const uint32_t run = blockIdx.x * 4 + w2;
+      if (run < nrun && (int64_t)run * kColRun < (int64_t)*n_vis) hist1[(uint64_t)tid * nrun + run] = bins[w2][tid];
+    }
+  }
+}
+
+// colstart[0..gx] = exclusive scan of the column totals (saturating u32), *n_pairs = N (64-bit).
+__global__ void __launch_bounds__(256)
+k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restrict__ colstart,
+           uint64_t* __restrict__ n_pairs) {
+  __shared__ uint64_t wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t x = tid < gx ? (uint64_t)totals1[tid] : 0ull;
+  uint64_t inc = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  uint64_t woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wtot[w];
+  const uint64_t excl = woff + inc - x;
+  if (tid < gx) colstart[tid] = excl > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)excl;
+  if (tid == 255) {
+    const uint64_t n = woff + inc;
+    colstart[gx] = n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n;
+    *n_pairs = n;
+  }
+}
+
+// One wave per run of 64 depth-ordered Gaussians. Lanes enumerate the run's PAIRS (Gaussian-major, then row-major
+// inside the rectangle) 64 at a time; a pair's position in the "sorted by tx" list is the running counter of its
+// column (start: colstart + scanned hist1) plus its rank among the round's pairs of the same column -- the stable
+// scatter of a radix pass, fused with the generation of its input. One word per pair: ty << 24 | Gaussian index.
+__global__ void __launch_bounds__(64)
+k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x, const uint32_t* __restrict__ rect_sorted,
+            const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ hist1, const uint32_t nrun,
+            const uint32_t* __restrict__ colstart, const uint32_t cap, uint32_t* __restrict__ vals) {
+  __shared__ uint32_t col_run[256];
+  __shared__ uint32_t pbase[65];
+  __shared__ uint32_t rs[64], ids[64], mg[64];
+  const int64_t s0 = (int64_t)blockIdx.x * kColRun;
+  const int64_t nv = (int64_t)*n_vis;
+  if (s0 >= nv) return;
+  const int lane = threadIdx.x;
+  for (int tx = lane; tx < gx; tx += 64) col_run[tx] = colstart[tx] + hist1[(uint64_t)tx * nrun + blockIdx.x];
+  const bool in = s0 + lane < nv;
+  const uint32_t r = in ? rect_sorted[s0 + lane] : 0u;
+  const uint32_t w = rect_w(r);
+  const uint32_t cnt = in ? w * rect_h(r) : 0u;
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+  pbase[lane] = inc - cnt;
+  if (lane == 0) pbase[64] = total;
+  rs[lane] = r;
+  ids[lane] = in ? sorted_idx[s0 + lane] : 0u;
+  mg[lane] = w > 1 ? 0xFFFFFFFFu / w + 1u : 0u;   // floor(q / w) == umulhi(q, mg) for q < 2^16, w <= 256
+  __syncthreads();
+  volatile uint32_t* run = col_run;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+    const uint32_t q = q0 + (uint32_t)lane;
+    const bool valid = q < total;
+    int i = 0;   // the Gaussian pair q belongs to: largest i with pbase[i] <= q
+#pragma unroll
+    for (int st = 32; st > 0; st >>= 1)
+      if (pbase[i + st] <= q) i += st;
+    const uint32_t rr = rs[i], gid = ids[i], m_ = mg[i];
+    const uint32_t rem = valid ? q - pbase[i] : 0u;
+    const uint32_t ww = rect_w(rr);
+    const uint32_t k = m_ ? __umulhi(rem, m_) : rem;
+    const uint32_t c = m_ ? rem - k * ww : 0u;
+    const uint32_t tx = rect_x0(rr) + c, ty = rect_y0(rr) + k;
+    const unsigned long long m = match_digit_n(tx, valid, nbits_x);
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t old = 0;
+    if (valid && lane == leader) {
+      old = run[tx];
+      run[tx] = old + (uint32_t)__popcll(m);
+    }
+    old = (uint32_t)__shfl((int)old, valid ? leader : lane, 64);
+    const uint32_t p = old + (uint32_t)__popcll(m & lt);
+    if (valid && p < cap) vals[p] = gid | (ty << 24);
+  }
+}
+
+// ---- second pass: stable by ty over column-aligned workgroups
+struct ColBlocks {
+  uint32_t col, base, end;   // this workgroup's column and element range [base, end)
+};
+
+// Every workgroup derives the block table from colstart: column tx owns max(1, ceil(cnt/4096)) workgroups.
+__device__ __forceinline__ ColBlocks col_blocks(const uint32_t* __restrict__ colstart, int gx, uint32_t cap,
+                                                uint32_t blk, uint32_t* sh_fb /*[257]*/, uint32_t* sh_tmp /*[8]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t cs = 0, ce = 0;
+  if (tid < gx) {
+    cs = min(colstart[tid], cap);
+    ce = min(colstart[tid + 1], cap);
+    if (ce < cs) ce = cs;
+  }
+  const uint32_t nb = tid < gx ? max(1u, (ce - cs + kPass2Block - 1) / kPass2Block) : 0u;
+  uint32_t inc = nb;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) sh_tmp[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wave; ++w) woff += sh_tmp[w];
+  const uint32_t fb = woff + inc - nb;
+  sh_fb[tid] = fb;
+  if (tid == 255) sh_fb[256] = fb + nb;
+  if (nb && blk >= fb && blk < fb + nb) {
+    sh_tmp[4] = (uint32_t)tid;
+    sh_tmp[5] = cs + (blk - fb) * kPass2Block;
+    sh_tmp[6] = ce;
+  }
+  __syncthreads();
+  ColBlocks cb;
+  const bool any = blk < sh_fb[256];
+  cb.col = any ? sh_tmp[4] : 0xFFFFFFFFu;
+  cb.base = any ? sh_tmp[5] : 0u;
+  cb.end = any ? min(sh_tmp[6], cb.base + kPass2Block) : 0u;
+  return cb;
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+k_row_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ colstart, const int gx, const uint32_t cap,
+           const int nbits, const uint32_t nblk, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[kRadix];
+  __shared__ uint32_t sh_fb[257];
+  __shared__ uint32_t sh_tmp[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  h[tid] = 0;
+  const ColBlocks cb = col_blocks(colstart, gx, cap, blockIdx.x, sh_fb, sh_tmp);
+  if (cb.base < cb.end) {
+    uint32_t kv[kPass2Items];
+#pragma unroll
+    for (int it = 0; it < kPass2Items; ++it) {   // all loads in flight before the first ballot
+      const uint32_t e = cb.base + (uint32_t)(wave * (64 * kPass2Items) + it * 64 + lane);
+      kv[it] = e < cb.end ? keys[e] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int it = 0; it < kPass2Items; ++it) {
+      const bool valid = kv[it] != 0xFFFFFFFFu;
+      const uint32_t d = valid ? kv[it] >> 24 : 0u;
+      const unsigned long long m = match_digit_n(d, valid, nbits);
+      if (valid && lane == __ffsll((long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
+    }
+  }
+  __syncthreads();
+  hist[(uint64_t)tid * nblk + blockIdx.x] = h[tid];
+}
+
+// Stable scatter by ty. The first workgroup of every column also writes the ranges of the column's tiles.
+__global__ void __launch_bounds__(kSortThreads)
+k_row_scatter(const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ colstart, const int gx, const int gy,
+              const uint32_t cap, const int nbits, const uint32_t nblk, const uint32_t* __restrict__ hist,
+              const uint32_t* __restrict__ totals, uint32_t* __restrict__ ranges) {
+  __shared__ uint32_t wh[4][kRadix];
+  __shared__ uint32_t dbase[kRadix];
+  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t sh_fb[257];
+  __shared__ uint32_t sh_tmp[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const ColBlocks cb = col_blocks(colstart, gx, cap, blockIdx.x, sh_fb, sh_tmp);
+  if (cb.col == 0xFFFFFFFFu) return;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
+  {
+    const uint32_t x = totals[tid];
+    uint32_t inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wtot[w];
+    dbase[tid] = woff + inc - x;
+  }
+  __syncthreads();
+  const uint32_t my_hist = hist[(uint64_t)tid * nblk + blockIdx.x];
+  if (blockIdx.x == sh_fb[cb.col] && tid < gy) {   // tile (ty = tid, tx = col): [first pair, first pair of tx + 1)
+    const uint32_t a = dbase[tid] + my_hist;
+    const uint32_t b = dbase[tid] + hist[(uint64_t)tid * nblk + sh_fb[cb.col + 1]];
+    uint2 rg = make_uint2(a, b);
+    if (a == b) rg = make_uint2(0u, 0u);
+    reinterpret_cast<uint2*>(ranges)[(uint32_t)tid * (uint32_t)gx + cb.col] = rg;
+  }
+  if (cb.base >= cb.end) return;
+  volatile uint32_t* mywh = wh[wave];
+  uint32_t val[kPass2Items];   // ty << 24 | Gaussian index; 0xFFFFFFFF = no element (index 0xFFFFFF never occurs)
+  uint32_t rank[kPass2Items];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int it = 0; it < kPass2Items; ++it) {
+    const uint32_t e = cb.base + (uint32_t)(wave * (64 * kPass2Items) + it * 64 + lane);
+    val[it] = e < cb.end ? vals_in[e] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int it = 0; it < kPass2Items; ++it) {
+    const bool valid = val[it] != 0xFFFFFFFFu;
+    const uint32_t d = val[it] >> 24;
+    const unsigned long long m = match_digit_n(d, valid, nbits);
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t old = 0;
+    if (valid && lane == leader) {
+      old = mywh[d];
+      mywh[d] = old + (uint32_t)__popcll(m);
+    }
+    old = (uint32_t)__shfl((int)old, valid ? leader : lane, 64);
+    rank[it] = old + (uint32_t)__popcll(m & lt);
+  }
+  __syncthreads();
+  {
+    uint32_t run = dbase[tid] + my_hist;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = wh[w][tid];
+      wh[w][tid] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kPass2Items; ++it) {
+    if (val[it] != 0xFFFFFFFFu) vals_out[wh[wave][val[it] >> 24] + rank[it]] = val[it] & 0xFFFFFFu;
+  }
+}
+
+// debug / parity: 64-bit keys of the reference formulation rebuilt from the ranges (one workgroup per tile)
+__global__ void __launch_bounds__(256)
+k_rebuild_keys_ranges(const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      const float* __restrict__ splat, uint64_t* __restrict__ keys64) {
+  const uint32_t t = blockIdx.x;
+  const uint32_t a = ranges[2 * t], b = ranges[2 * t + 1];
+  for (uint32_t j = a + threadIdx.x; j < b; j += 256) {
+    const uint32_t dbits = __float_as_uint(splat[12 * (size_t)point_list[j] + 6]);
+    keys64[j] = ((uint64_t)t << 32) | dbits;
+  }
+}
+
 }  // namespace
 
 extern "C" uint32_t gsr_num_tiles(int32_t H, int32_t W) {
@@ -168,21 +489,30 @@ extern "C" uint32_t gsr_num_tiles(int32_t H, int32_t W) {
 }
 extern "C" uint32_t gsr_num_blocks(int32_t P) { return (uint32_t)((P + 255) / 256); }
 
-// Scratch of the projection stage (depth sort): keys x2, values x2 (one of them becomes sorted_idx), histograms.
+// The column path packs (ty, Gaussian index) into one word: grids up to 256 x 256 tiles, fewer than 2^24 Gaussians.
+static bool use_columns(int32_t H, int32_t W, int32_t P) {
+  return (W + GSR_TILE - 1) / GSR_TILE <= 256 && (H + GSR_TILE - 1) / GSR_TILE <= 256 && P < (1 << 24);
+}
+static uint32_t col_runs(int32_t P) { return (uint32_t)(((P > 0 ? P : 1) + kColRun - 1) / kColRun); }
+
+// Scratch of the projection stage: depth-sort keys x2 / values x2 (one of them becomes sorted_idx), histograms,
+// packed tile rectangles and the per-run column histogram of the column path.
 extern "C" size_t gsr_project_scratch_bytes(int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
-  return 4 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4) + align256(kRadix * 4) + 1024;
+  return 5 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4) + align256(kRadix * 4) +
+         align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + align256(264 * 4) + 1024;
 }
 
-// Scratch of the binning stage: tile keys x2, one value ping buffer, histograms.
+// Scratch of the binning stage: tile keys x2, one value ping buffer, histograms (the column path needs less).
 extern "C" size_t gsr_sort_scratch_bytes(uint64_t n, uint32_t n_tiles) {
   (void)n_tiles;
   const uint64_t m = n ? n : 1;
-  return 3 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m, kItemsLarge) * 4) + align256(kRadix * 4) + 1024;
+  return 3 * align256(m * 4) + align256((size_t)kRadix * (sort_blocks(m, kItemsLarge) + 260) * 4) +
+         align256(kRadix * 4) + 1024;
 }
 
 struct ProjectScratch {
-  uint32_t *k0, *k1, *v0, *v1, *hist, *totals;
+  uint32_t *k0, *k1, *v0, *v1, *hist, *totals, *rects, *hist1, *totals1, *colstart;
 };
 static ProjectScratch carve_project(void* scratch, int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
@@ -193,32 +523,89 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
   s.v0 = (uint32_t*)b; b += align256(m * 4);
   s.v1 = (uint32_t*)b; b += align256(m * 4);
   s.hist = (uint32_t*)b; b += align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4);
-  s.totals = (uint32_t*)b;
+  s.totals = (uint32_t*)b; b += align256(kRadix * 4);
+  s.rects = (uint32_t*)b; b += align256(m * 4);
+  s.hist1 = (uint32_t*)b; b += align256((size_t)256 * col_runs((int32_t)m) * 4);
+  s.totals1 = (uint32_t*)b; b += align256(256 * 4);
+  s.colstart = (uint32_t*)b;
   return s;
 }
 
 uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).k0; }
+uint32_t* gsr_tile_rects(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).rects; }
 
-// After K1 (which wrote the depth keys into scratch.k0): depth sort, depth-ordered block sums, scan -> N.
-int gsr_launch_depth_order(GsrGeom& geom, int32_t P, uint64_t* n_pairs_dev, uint32_t depth_skip_mask, hipStream_t stream,
+// After K1 (which wrote the depth keys into scratch.k0): depth sort, depth-ordered counts, scan -> N.
+int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, uint64_t* n_pairs_dev, hipStream_t stream,
                            GsrProfile* prof) {
+  const int32_t P = v.P;
   if (geom.scratch_bytes < gsr_project_scratch_bytes(P) || !geom.scratch) return GSR_ESCRATCH;
   ProjectScratch s = carve_project(geom.scratch, P);
   uint64_t* n_vis_dev = n_pairs_dev + 1;     // number of visible Gaussians, next to the pair count (block_offsets tail)
+  int where;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    (void)depth_skip_mask;
-    const int where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev,
-                                                   s.hist, s.totals, stream);
+    where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
+                                        s.totals, stream);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SCAN);
     const uint32_t nb = gsr_num_blocks(P);
-    hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx, geom.tiles_touched,
-                       geom.block_offsets);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, geom.block_offsets, nb, n_pairs_dev);
+    if (use_columns(v.image_height, v.image_width, v.P)) {
+      const int gx = (v.image_width + GSR_TILE - 1) / GSR_TILE;
+      uint32_t* rect_sorted = where ? s.k0 : s.k1;   // the key buffer the sort result is NOT in
+      const uint32_t nrun = col_runs(P);
+      hipLaunchKernelGGL(k_col_hist, dim3(nb), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx, s.rects, rect_sorted, gx,
+                         nrun, s.hist1);
+      hipLaunchKernelGGL(k_radix_scan, dim3(gx), dim3(256), 0, stream, s.hist1, nrun, s.totals1, (const uint64_t*)n_vis_dev, (uint32_t)kColRun);
+      hipLaunchKernelGGL(k_col_plan, dim3(1), dim3(256), 0, stream, s.totals1, gx, s.colstart, n_pairs_dev);
+    } else {
+      hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx,
+                         geom.tiles_touched, geom.block_offsets);
+      hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, geom.block_offsets, nb, n_pairs_dev);
+    }
+    GSR_HIP(hipGetLastError());
+  }
+  return GSR_OK;
+}
+
+// Column path of gsr_launch_binning.
+static int launch_binning_columns(const GsrView& v, const GsrGeom& geom, uint64_t cap64, const uint64_t* n_dev_vis,
+                                  GsrBinning& b, hipStream_t stream, GsrProfile* prof) {
+  const int gx = (v.image_width + GSR_TILE - 1) / GSR_TILE, gy = (v.image_height + GSR_TILE - 1) / GSR_TILE;
+  const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
+  ProjectScratch s = carve_project(geom.scratch, v.P);
+  const uint32_t* rect_sorted = (geom.sorted_idx == s.v0) ? s.k1 : s.k0;
+  const uint32_t nrun = col_runs(v.P);
+  const uint32_t nblk = (uint32_t)((cap64 + kPass2Block - 1) / kPass2Block) + (uint32_t)gx + 2;
+  char* base = (char*)b.scratch;
+  uint32_t* vals1 = (uint32_t*)base; base += align256(cap64 * 4);
+  uint32_t* hist = (uint32_t*)base; base += align256((size_t)kRadix * nblk * 4);
+  uint32_t* totals = (uint32_t*)base;
+  int nbits = 1;
+  while ((1 << nbits) < gy) ++nbits;
+  {
+    GsrStageTimer t(prof, stream, GSR_STAGE_DUPLICATE);
+    int nbits_x = 1;
+    while ((1 << nbits_x) < gx) ++nbits_x;
+    hipLaunchKernelGGL(k_emit_cols, dim3(nrun), dim3(64), 0, stream, n_dev_vis, gx, nbits_x, rect_sorted,
+                       geom.sorted_idx, s.hist1, nrun, s.colstart, cap, vals1);
+    GSR_HIP(hipGetLastError());
+  }
+  {
+    GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
+    hipLaunchKernelGGL(k_row_hist, dim3(nblk), dim3(kSortThreads), 0, stream, vals1, s.colstart, gx, cap, nbits, nblk,
+                       hist);
+    hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u);
+    hipLaunchKernelGGL(k_row_scatter, dim3(nblk), dim3(kSortThreads), 0, stream, vals1, b.point_list, s.colstart,
+                       gx, gy, cap, nbits, nblk, hist, totals, b.ranges);
+    GSR_HIP(hipGetLastError());
+  }
+  if (b.keys_sorted) {
+    GsrStageTimer t(prof, stream, GSR_STAGE_RANGES);
+    hipLaunchKernelGGL(k_rebuild_keys_ranges, dim3(gx * gy), dim3(256), 0, stream, b.ranges, b.point_list, geom.splat,
+                       b.keys_sorted);
     GSR_HIP(hipGetLastError());
   }
   return GSR_OK;
@@ -235,6 +622,7 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
   }
   if (b.scratch_bytes < gsr_sort_scratch_bytes(cap, tiles) || !b.scratch) return GSR_ESCRATCH;
   if (!geom.sorted_idx) return GSR_EINVAL;
+  if (use_columns(v.image_height, v.image_width, v.P)) return launch_binning_columns(v, geom, cap, n_dev_vis, b, stream, prof);
   char* base = (char*)b.scratch;
   uint32_t* keys_a = (uint32_t*)base; base += align256(cap * 4);
   uint32_t* keys_b = (uint32_t*)base; base += align256(cap * 4);

@@ -229,7 +229,8 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64
 template <int KT>
 __global__ void __launch_bounds__(256)
 k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, int32_t* __restrict__ radii,
-             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_keys) {
+             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_keys,
+             uint32_t* __restrict__ rects) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int P = v.P, W = v.image_width, H = v.image_height, K = KT > 0 ? KT : v.sh_stride;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -248,6 +249,7 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
   float q0x = 0, q0y = 0, ca_ = 0, cb_ = 0, cc_ = 0, depth = 0, opac = 0, tau_ = -1.f;
   int32_t radius = 0;
   uint32_t ntiles = 0;
+  uint32_t rect = 0;   // x0 | y0 << 8 | (w-1) << 16 | (h-1) << 24 of the tile rectangle (grids up to 256 x 256 tiles)
   if (i < P) {
     px = g.means3D[3 * i]; py = g.means3D[3 * i + 1]; pz = g.means3D[3 * i + 2];
     const float tzq = ((vc.V[2] * px + vc.V[6] * py) + vc.V[10] * pz) + vc.V[14];
@@ -285,6 +287,7 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
         const int32_t x1 = min(gx, max(0, gsr_f2i_sat(((pxl + rf) + 15.0f) * 0.0625f)));
         const int32_t y1 = min(gy, max(0, gsr_f2i_sat(((pyl + rf) + 15.0f) * 0.0625f)));
         ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
+        rect = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)(x1 - x0 - 1) << 16) | ((uint32_t)(y1 - y0 - 1) << 24);
         if (ntiles != 0) {
           vis = true;
           q0x = pxl; q0y = pyl;
@@ -358,7 +361,8 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
   if (i < P) {
     radii[i] = radius;
     tiles_touched[i] = ntiles;
-    depth_keys[i] = vis ? __float_as_uint(depth) : 0xFFFFFFFFu;   // culled Gaussians sort to the end
+    depth_keys[i] = vis ? __float_as_uint(depth) : 0xFFFFFFFFu;   // culled Gaussians are dropped by the depth sort
+    rects[i] = rect;
     if (vis) {
       float4* o = reinterpret_cast<float4*>(splat + 12 * i);
       o[0] = make_float4(q0x, q0y, ca_, cb_);
@@ -686,6 +690,7 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
 }  // namespace
 
 uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P);   // binning.hip: first key buffer of the depth sort
+uint32_t* gsr_tile_rects(const GsrGeom& geom, int32_t P);   // binning.hip: packed tile rectangles, one per Gaussian
 
 size_t gsr_preprocess_lds_bytes(int K) { return (size_t)4 * 64 * sh_lds_stride(K) * sizeof(float); }
 
@@ -695,7 +700,7 @@ int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom
   // compile-time strides read their rows directly (no LDS); only the generic stride stages through LDS
 #define GSR_LAUNCH_K1(KT)                                                                                      \
   hipLaunchKernelGGL(k_preprocess<KT>, dim3(nb), dim3(256), (KT) > 0 ? 0 : lds, stream, v, g, geom.splat,     \
-                     geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P))
+                     geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P), gsr_tile_rects(geom, v.P))
   switch (g.shs ? v.sh_stride : 0) {
     case 16: GSR_LAUNCH_K1(16); break;
     case 9: GSR_LAUNCH_K1(9); break;

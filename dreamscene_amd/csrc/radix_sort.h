@@ -66,12 +66,19 @@ k_radix_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_d
 }
 
 // Workgroup d scans row d of hist[256][nblk] in place (exclusive) and writes the row total to totals[d].
-__global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblk,
-                                                    uint32_t* __restrict__ totals) {
+// n_items (device, may be NULL): only the first ceil(*n_items / per_block) entries of a row are in use.
+__global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblk_stride,
+                                                    uint32_t* __restrict__ totals,
+                                                    const uint64_t* __restrict__ n_items, uint32_t per_block) {
+  uint32_t nblk = nblk_stride;
+  if (n_items) {
+    const uint64_t used = (*n_items + per_block - 1) / per_block;
+    if (used < nblk) nblk = (uint32_t)used;
+  }
   __shared__ uint32_t wave_tot[4];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t* row = hist + (uint64_t)blockIdx.x * nblk;
+  uint32_t* row = hist + (uint64_t)blockIdx.x * nblk_stride;
   if (tid == 0) carry_s = 0;
   __syncthreads();
   constexpr uint32_t kPer = 4;
@@ -213,14 +220,14 @@ int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const
     if (iota && p == 0 && n_compact) {
       hipLaunchKernelGGL((k_radix_hist<ITEMS, true>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift,
                          nblk, hist);
-      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals);
+      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u);
       hipLaunchKernelGGL((k_radix_scatter<true, ITEMS, true>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb,
                          n_dev, cap, shift, nblk, hist, totals, n_compact);
       n_dev = n_compact;
     } else {
       hipLaunchKernelGGL((k_radix_hist<ITEMS, false>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift,
                          nblk, hist);
-      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals);
+      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u);
       if (iota && p == 0)
         hipLaunchKernelGGL((k_radix_scatter<true, ITEMS, false>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb,
                            vb, n_dev, cap, shift, nblk, hist, totals, (uint64_t*)nullptr);
