@@ -21,9 +21,32 @@ class GsrView(C.Structure):
                 ("bg", _f), ("viewmatrix", _f), ("projmatrix", _f), ("campos", _f)]
 
 
+GSR_MAX_MODELS = 16
+
+
+class GsrModel(C.Structure):
+    _fields_ = [("count", C.c_int32), ("reserved_", C.c_int32), ("xyz", _f), ("scaling", _f), ("rotation", _f),
+                ("opacity", _f), ("features_dc", _f), ("features_rest", _f)]
+
+
+class GsrScene(C.Structure):
+    _fields_ = [("n_models", C.c_int32), ("reserved_", C.c_int32), ("models", GsrModel * GSR_MAX_MODELS),
+                ("scale_noise", _f), ("sh_noise", _f), ("scales_out", _f), ("rotations_out", _f),
+                ("opacities_out", _f)]
+
+
+class GsrModelGrads(C.Structure):
+    _fields_ = [("xyz", _f), ("scaling", _f), ("rotation", _f), ("opacity", _f), ("features_dc", _f),
+                ("features_rest", _f)]
+
+
+class GsrSceneGrads(C.Structure):
+    _fields_ = [("models", GsrModelGrads * GSR_MAX_MODELS), ("dL_dscales_out", _f)]
+
+
 class GsrGaussians(C.Structure):
     _fields_ = [("means3D", _f), ("opacities", _f), ("shs", _f), ("colors_precomp", _f), ("scales", _f),
-                ("rotations", _f), ("cov3D_precomp", _f)]
+                ("rotations", _f), ("cov3D_precomp", _f), ("scene", C.POINTER(GsrScene))]
 
 
 class GsrGeom(C.Structure):
@@ -49,7 +72,8 @@ class GsrImageGrads(C.Structure):
 class GsrGrads(C.Structure):
     _fields_ = [("dL_dmeans3D", _f), ("dL_dmeans2D", _f), ("dL_dopacities", _f), ("dL_dshs", _f), ("dL_dcolors", _f),
                 ("dL_dscales", _f), ("dL_drotations", _f), ("dL_dcov3D", _f), ("dL_dview", _f), ("dL_dproj", _f),
-                ("dL_dcampos", _f), ("partials", _f), ("accumulate", C.c_int32), ("reserved_", C.c_int32)]
+                ("dL_dcampos", _f), ("partials", _f), ("accumulate", C.c_int32), ("reserved_", C.c_int32),
+                ("scene", C.POINTER(GsrSceneGrads))]
 
 
 # every symbol include/gsrast.h declares: (name, restype, argtypes)

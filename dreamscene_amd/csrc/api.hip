@@ -27,9 +27,32 @@ int check_view(const GsrView* v) {
   return GSR_OK;
 }
 
+int check_scene(const GsrView* v, const GsrGaussians* g) {
+  const GsrScene* sc = g->scene;
+  if (g->means3D || g->opacities || g->shs || g->colors_precomp || g->scales || g->rotations || g->cov3D_precomp)
+    return GSR_EINVAL;
+  if (sc->n_models < 1 || sc->n_models > GSR_MAX_MODELS) return GSR_EINVAL;
+  const int K = v->sh_stride, nb = (v->sh_degree + 1) * (v->sh_degree + 1);
+  if (K < nb || K < 1 || K > 64) return GSR_EINVAL;
+  int64_t total = 0;
+  for (int m = 0; m < sc->n_models; ++m) {
+    const GsrModel& md = sc->models[m];
+    if (md.count < 0) return GSR_EINVAL;
+    total += md.count;
+    if (md.count == 0) continue;
+    if (!md.xyz || !md.scaling || !md.rotation || !md.opacity || !md.features_dc) return GSR_EINVAL;
+    if (K > 1 && !md.features_rest) return GSR_EINVAL;
+    if (!aligned16(md.rotation)) return GSR_EINVAL;
+  }
+  if (total != (int64_t)v->P) return GSR_EINVAL;
+  if (sc->rotations_out && !aligned16(sc->rotations_out)) return GSR_EINVAL;
+  return GSR_OK;
+}
+
 int check_gaussians(const GsrView* v, const GsrGaussians* g) {
   if (!g) return GSR_EINVAL;
   if (v->P == 0) return GSR_OK;
+  if (g->scene) return check_scene(v, g);
   if (!g->means3D || !g->opacities) return GSR_EINVAL;
   if ((g->shs != nullptr) == (g->colors_precomp != nullptr)) return GSR_EINVAL;
   const bool sr = g->scales != nullptr && g->rotations != nullptr;
@@ -171,7 +194,14 @@ int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, c
   if (!ig->dL_dcolor || !ig->dL_ddepth_alpha || !img->final_T || !img->n_contrib || !b->ranges) return GSR_EINVAL;
   if (!b->tile_work || !img->tile_depth || !img->ckpt || !img->color || !img->depth_alpha) return GSR_EINVAL;
   if (!out->partials || !aligned16(out->partials)) return GSR_EINVAL;
-  if (!out->dL_dmeans3D || !out->dL_dmeans2D || !out->dL_dopacities) return GSR_EINVAL;
+  if (g->scene) {
+    if (!out->scene || !out->dL_dmeans2D) return GSR_EINVAL;
+    if (out->dL_dmeans3D || out->dL_dopacities || out->dL_dshs || out->dL_dcolors || out->dL_dscales ||
+        out->dL_drotations || out->dL_dcov3D)
+      return GSR_EINVAL;
+    for (int m = 0; m < g->scene->n_models; ++m)
+      if (out->scene->models[m].rotation && !aligned16(out->scene->models[m].rotation)) return GSR_EINVAL;
+  } else if (!out->dL_dmeans3D || !out->dL_dmeans2D || !out->dL_dopacities) return GSR_EINVAL;
   if (out->dL_dshs && (!g->shs || !aligned16(out->dL_dshs))) return GSR_EINVAL;
   if (out->dL_dcolors && !g->colors_precomp) return GSR_EINVAL;
   if ((out->dL_dscales || out->dL_drotations) && g->cov3D_precomp) return GSR_EINVAL;

@@ -29,6 +29,87 @@ __device__ __forceinline__ void load_view(const GsrView& v, ViewConst& c) {
   for (int i = 0; i < 3; ++i) c.cam[i] = v.campos[i];
 }
 
+// ---- multi-model ("scene") input: GsrScene flattened for the kernels (passed by value in the kernel arguments).
+// A workgroup never straddles two models: model m owns the workgroups [fblk[m], fblk[m+1]) and its Gaussians keep
+// their place first[m] + row in the concatenated index space every other kernel works in.
+struct SceneTab {
+  int32_t n;
+  int32_t first[GSR_MAX_MODELS + 1];
+  int32_t fblk[GSR_MAX_MODELS + 1];
+  const float* xyz[GSR_MAX_MODELS];
+  const float* scaling[GSR_MAX_MODELS];
+  const float* rotation[GSR_MAX_MODELS];
+  const float* opacity[GSR_MAX_MODELS];
+  const float* dc[GSR_MAX_MODELS];
+  const float* rest[GSR_MAX_MODELS];
+  const float* scale_noise;
+  const float* sh_noise;
+  float* scales_out;
+  float* rotations_out;
+  float* opacities_out;
+};
+struct SceneGradTab {
+  const float* dL_dscales_out;
+  float* xyz[GSR_MAX_MODELS];
+  float* scaling[GSR_MAX_MODELS];
+  float* rotation[GSR_MAX_MODELS];
+  float* opacity[GSR_MAX_MODELS];
+  float* dc[GSR_MAX_MODELS];
+  float* rest[GSR_MAX_MODELS];
+};
+struct NoScene {};
+
+// Which rows this thread / wave works on. Without a scene: row == concatenated index.
+struct Rows {
+  int m;               // model (0 without a scene)
+  int64_t i;           // concatenated Gaussian index
+  int64_t row;         // row inside the model's tensors
+  int64_t wave_row;    // row of the wave's first lane
+  int64_t wave_i;      // concatenated index of the wave's first lane
+  int n_valid;         // rows of this wave that exist
+  bool ok;             // this lane's row exists
+};
+template <bool SCENE, typename TAB>
+__device__ __forceinline__ Rows resolve_rows(const TAB& sc, int P) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  Rows r;
+  if constexpr (SCENE) {
+    int m = 0;
+    for (int k = 1; k < sc.n; ++k) m += ((int)blockIdx.x >= sc.fblk[k]) ? 1 : 0;
+    const int64_t cnt = (int64_t)sc.first[m + 1] - sc.first[m];
+    const int64_t b0 = ((int64_t)blockIdx.x - sc.fblk[m]) * 256;
+    r.m = m;
+    r.row = b0 + tid;
+    r.wave_row = b0 + wave * 64;
+    r.i = sc.first[m] + r.row;
+    r.wave_i = sc.first[m] + r.wave_row;
+    r.n_valid = (int)min((int64_t)64, max((int64_t)0, cnt - r.wave_row));
+    r.ok = r.row < cnt;
+  } else {
+    r.m = 0;
+    r.i = r.row = (int64_t)blockIdx.x * 256 + tid;
+    r.wave_i = r.wave_row = (int64_t)blockIdx.x * 256 + wave * 64;
+    r.n_valid = (int)min((int64_t)64, max((int64_t)0, (int64_t)P - r.wave_row));
+    r.ok = r.i < P;
+  }
+  return r;
+}
+
+// The activations of GaussianModel (gs_renderer.py:464-488) and scene_render's augmentations (scene_gaussian.py:844-852)
+constexpr float kSqrtPoint2 = 0.44721359549995793f;   // 0.2 ** 0.5
+struct ActScale { float act, pre, out; };              // exp(raw); after the noise; after the clamp
+__device__ __forceinline__ ActScale act_scale(float raw, bool noisy, float n) {
+  ActScale a;
+  a.act = expf(raw);
+  a.pre = noisy ? a.act + n * ((kSqrtPoint2 * a.act) / 4.0f) : a.act;
+  a.out = noisy ? fmaxf(a.pre, 0.0f) : a.act;
+  return a;
+}
+__device__ __forceinline__ float act_quat_norm(const float4 q) {
+  return fmaxf(sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w), 1e-12f);
+}
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
 __device__ __forceinline__ void quat_to_R(const float4 q, float R[9]) {
   const float r = q.x, x = q.y, y = q.z, z = q.w;
   R[0] = 1.0f - 2.0f * (y * y + z * z);
@@ -194,6 +275,28 @@ __device__ __forceinline__ void stage_sh_in(const float* __restrict__ shs, int64
   }
 }
 
+// Scene input: rows of F floats (features_dc: 3, features_rest: 3K-3) land at float offset o0 of the lanes' LDS rows.
+__device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int F, int o0, int lds_stride, int n_valid,
+                                              unsigned long long vis, float* lds_wave) {
+  const int total = n_valid * F;
+  const int lane = gsr_lane();
+  for (int f = lane; f < total; f += 64) {
+    const int g = f / F, o = f - g * F;
+    if ((vis >> g) & 1ull) lds_wave[g * lds_stride + o0 + o] = src[f];
+  }
+}
+__device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, int F, int o0, int lds_stride, int n_valid,
+                                               const float* lds_wave, bool accumulate, unsigned long long vis) {
+  const int total = n_valid * F;
+  const int lane = gsr_lane();
+  for (int f = lane; f < total; f += 64) {
+    const int g = f / F, o = f - g * F;
+    const float e = lds_wave[g * lds_stride + o0 + o];
+    if (!accumulate) dst[f] = e;
+    else if ((vis >> g) & 1ull) dst[f] += e;
+  }
+}
+
 // LDS -> global coalesced store of the wave's [n_valid, 3K] block.
 template <int KT>
 __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64_t wave_first, int n_valid, int K,
@@ -226,17 +329,21 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64
 }
 
 // --------------------------------------------------------------------------------------------------------- K1
-template <int KT>
+template <int KT, bool SCENE = false, typename TAB = NoScene>
 __global__ void __launch_bounds__(256)
-k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, int32_t* __restrict__ radii,
-             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_keys,
+k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restrict__ splat,
+             int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_keys,
              uint32_t* __restrict__ rects) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int P = v.P, W = v.image_width, H = v.image_height, K = KT > 0 ? KT : v.sh_stride;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
-  const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
-  const int n_valid = (int)min((int64_t)64, max((int64_t)0, (int64_t)P - wave_first));
+  const Rows rw = resolve_rows<SCENE>(sc, P);
+  const int64_t i = rw.i, row = rw.row, wave_first = rw.wave_row;
+  const int n_valid = rw.n_valid;
+  const float *p_xyz = g.means3D, *p_scale = g.scales, *p_rot = g.rotations, *p_opac = g.opacities;
+  if constexpr (SCENE) {
+    p_xyz = sc.xyz[rw.m]; p_scale = sc.scaling[rw.m]; p_rot = sc.rotation[rw.m]; p_opac = sc.opacity[rw.m];
+  }
   const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
   const float fx = (float)W / (2.0f * v.tanfovx), fy = (float)H / (2.0f * v.tanfovy);
   const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
@@ -250,8 +357,24 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
   int32_t radius = 0;
   uint32_t ntiles = 0;
   uint32_t rect = 0;   // x0 | y0 << 8 | (w-1) << 16 | (h-1) << 24 of the tile rectangle (grids up to 256 x 256 tiles)
-  if (i < P) {
-    px = g.means3D[3 * i]; py = g.means3D[3 * i + 1]; pz = g.means3D[3 * i + 2];
+  if (rw.ok) {
+    px = p_xyz[3 * row]; py = p_xyz[3 * row + 1]; pz = p_xyz[3 * row + 2];
+    if constexpr (SCENE) {
+      // activated values the caller gets back (scene_render returns the augmented scales, scene_gaussian.py:892)
+      if (sc.scales_out) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float n = sc.scale_noise ? sc.scale_noise[3 * i + k] : 0.f;
+          sc.scales_out[3 * i + k] = act_scale(p_scale[3 * row + k], sc.scale_noise != nullptr, n).out;
+        }
+      }
+      if (sc.rotations_out) {
+        const float4 q = *reinterpret_cast<const float4*>(p_rot + 4 * row);
+        const float nrm = act_quat_norm(q);
+        *reinterpret_cast<float4*>(sc.rotations_out + 4 * i) = make_float4(q.x / nrm, q.y / nrm, q.z / nrm, q.w / nrm);
+      }
+      if (sc.opacities_out) sc.opacities_out[i] = act_sigmoid(p_opac[row]);
+    }
     const float tzq = ((vc.V[2] * px + vc.V[6] * py) + vc.V[10] * pz) + vc.V[14];
     if (tzq > GSR_NEAR_Z) {
       const float* PV = vc.PV;
@@ -266,8 +389,18 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
         for (int k = 0; k < 6; ++k) c6[k] = g.cov3D_precomp[6 * i + k];
       } else {
         const float mod = v.scale_modifier;
-        const float s0 = mod * g.scales[3 * i], s1 = mod * g.scales[3 * i + 1], s2 = mod * g.scales[3 * i + 2];
-        const float4 q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
+        float sa[3] = {p_scale[3 * row], p_scale[3 * row + 1], p_scale[3 * row + 2]};
+        float4 q = *reinterpret_cast<const float4*>(p_rot + 4 * row);
+        if constexpr (SCENE) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float n = sc.scale_noise ? sc.scale_noise[3 * i + k] : 0.f;
+            sa[k] = act_scale(sa[k], sc.scale_noise != nullptr, n).out;
+          }
+          const float nrm = act_quat_norm(q);
+          q = make_float4(q.x / nrm, q.y / nrm, q.z / nrm, q.w / nrm);
+        }
+        const float s0 = mod * sa[0], s1 = mod * sa[1], s2 = mod * sa[2];
         float R[9];
         quat_to_R(q, R);
         cov3d_from(s0, s1, s2, R, c6);
@@ -293,7 +426,7 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
           q0x = pxl; q0y = pyl;
           ca_ = e.cc * inv; cb_ = -e.cb * inv; cc_ = e.ca * inv;
           depth = e.tz;
-          opac = g.opacities[i];
+          opac = SCENE ? act_sigmoid(p_opac[row]) : p_opac[row];
           // Level of the conic form below which this splat can pass the alpha >= 1/255 gate:
           // sigma exp(-q/2) >= 1/255  <=>  q = d^T Conic d <= 2 ln(255 sigma) =: tau (slightly inflated).
           // Used only to skip (pixel block, splat) pairs that cannot contribute (render.hip); negative = the
@@ -310,7 +443,7 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
 
   // ---- colour
   float rgb[3] = {0.f, 0.f, 0.f};
-  if (g.shs && KT > 0) {
+  if (!SCENE && g.shs && KT > 0) {
     // compile-time SH stride: every lane pulls its own 12*KT-byte row straight into registers (measured faster
     // than the coalesced-load + LDS-transpose path K8 uses for its read-modify-write of the same block: the rows
     // of a wave are contiguous, so L1/TA serve the 16-byte pieces of one line to successive loads)
@@ -336,10 +469,23 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
     }
-  } else if (g.shs) {
+  } else if (SCENE || g.shs) {
     const unsigned long long vmask = __ballot(vis);
     float* lw = lds + wave * (64 * sh_lds_stride(K));
-    if (vmask) stage_sh_in<KT>(g.shs, wave_first, n_valid, K, vmask, lw);
+    if constexpr (SCENE) {
+      // features_dc / features_rest rows of the wave, side by side in the lanes' LDS rows; then the SH noise
+      if (vmask) {
+        stage_rows_in(sc.dc[rw.m] + wave_first * 3, 3, 0, sh_lds_stride(K), n_valid, vmask, lw);
+        if (K > 1) stage_rows_in(sc.rest[rw.m] + wave_first * (3 * K - 3), 3 * K - 3, 3, sh_lds_stride(K), n_valid, vmask, lw);
+      }
+      if (sc.sh_noise && vis) {
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float* shw = lw + lane * sh_lds_stride(K);
+        const float* nz = sc.sh_noise + (size_t)i * (3 * K);
+        for (int k = 0; k < 3 * K; ++k) shw[k] = shw[k] + nz[k] * (kSqrtPoint2 * shw[k]);
+      }
+    } else if (vmask) stage_sh_in<KT>(g.shs, wave_first, n_valid, K, vmask, lw);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (vis) {
@@ -358,7 +504,7 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
     rgb[0] = g.colors_precomp[3 * i]; rgb[1] = g.colors_precomp[3 * i + 1]; rgb[2] = g.colors_precomp[3 * i + 2];
   }
 
-  if (i < P) {
+  if (rw.ok) {
     radii[i] = radius;
     tiles_touched[i] = ntiles;
     depth_keys[i] = vis ? __float_as_uint(depth) : 0xFFFFFFFFu;   // culled Gaussians are dropped by the depth sort
@@ -376,17 +522,19 @@ k_preprocess(const GsrView v, const GsrGaussians g, float* __restrict__ splat, i
 // --------------------------------------------------------------------------------------------------------- K8
 // partials [P,12] from K7: (S1 = sum q dx, S2 = sum q dy, S3 = sum q dx^2, S4 = sum q dx dy, S5 = sum q dy^2,
 //                          dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -), q = dL/dG * G
-template <int KT>
+template <int KT, bool SCENE = false, typename TAB = NoScene, typename GTAB = NoScene>
 __global__ void __launch_bounds__(256)
-k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restrict__ radii,
-                 const float* __restrict__ partials, const GsrGrads out) {
+k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB sg,
+                 const int32_t* __restrict__ radii, const float* __restrict__ partials, const GsrGrads out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float cam_red[4][32];
   const int P = v.P, W = v.image_width, H = v.image_height, K = KT > 0 ? KT : v.sh_stride, D = v.sh_degree;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
-  const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
-  const int n_valid = (int)min((int64_t)64, max((int64_t)0, (int64_t)P - wave_first));
+  const Rows rw = resolve_rows<SCENE>(sc, P);
+  const int64_t i = rw.i, row = rw.row, wave_first = rw.wave_row;
+  const int n_valid = rw.n_valid;
+  const float *p_xyz = g.means3D, *p_scale = g.scales, *p_rot = g.rotations;
+  if constexpr (SCENE) { p_xyz = sc.xyz[rw.m]; p_scale = sc.scaling[rw.m]; p_rot = sc.rotation[rw.m]; }
   const float fx = (float)W / (2.0f * v.tanfovx), fy = (float)H / (2.0f * v.tanfovy);
   const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
   const float mod = v.scale_modifier;
@@ -397,11 +545,11 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
   const float* V = vc.V;
   const float* PV = vc.PV;
 
-  const bool vis = (i < P) && (radii[i] > 0);
+  const bool vis = rw.ok && (radii[i] > 0);
   float px = 0, py = 0, pz = 0;
   float4 pa = make_float4(0, 0, 0, 0), pb = pa, pc = pa;
   if (vis) {
-    px = g.means3D[3 * i]; py = g.means3D[3 * i + 1]; pz = g.means3D[3 * i + 2];
+    px = p_xyz[3 * row]; py = p_xyz[3 * row + 1]; pz = p_xyz[3 * row + 2];
     const float4* pp = reinterpret_cast<const float4*>(partials + 12 * i);
     pa = pp[0]; pb = pp[1]; pc = pp[2];
   }
@@ -418,12 +566,23 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
   for (int k = 0; k < 12; ++k) { dview[k] = 0.f; dproj[k] = 0.f; }
 
   // ---- (1) colour -> SH coefficients, view direction
-  if (g.shs) {
+  if (SCENE || g.shs) {
     const unsigned long long vmask = __ballot(vis);
     const int stride = sh_lds_stride(K);
     float* lw = lds + wave * (64 * stride);
     float* sh = lw + lane * stride;
-    if constexpr (KT > 0 && (3 * KT) % 4 == 0) {
+    if constexpr (SCENE) {
+      if (vmask) {
+        stage_rows_in(sc.dc[rw.m] + wave_first * 3, 3, 0, stride, n_valid, vmask, lw);
+        if (K > 1) stage_rows_in(sc.rest[rw.m] + wave_first * (3 * K - 3), 3 * K - 3, 3, stride, n_valid, vmask, lw);
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (sc.sh_noise && vis) {   // the augmented coefficients K1 saw
+        const float* nz = sc.sh_noise + (size_t)i * (3 * K);
+        for (int k = 0; k < 3 * K; ++k) sh[k] = sh[k] + nz[k] * (kSqrtPoint2 * sh[k]);
+      }
+    } else if constexpr (KT > 0 && (3 * KT) % 4 == 0) {
       // compile-time stride: each lane pulls its own row (as K1 does) and parks it in its LDS row; LDS is still
       // needed for the coalesced write-back of dL/dSH
       if (vis) {
@@ -472,6 +631,12 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
       }
 #undef GSR_SH_BWD_BAND
       for (int k = 3 * nb; k < 3 * K; ++k) sh[k] = 0.f;
+      if constexpr (SCENE) {
+        if (sc.sh_noise) {   // d(sh + n c sh)/dsh = 1 + c n
+          const float* nz = sc.sh_noise + (size_t)i * (3 * K);
+          for (int k = 0; k < 3 * nb; ++k) sh[k] = sh[k] * (1.0f + kSqrtPoint2 * nz[k]);
+        }
+      }
       float ddx = 0.f, ddy = 0.f, ddz = 0.f;
       if (D > 0) {
         ddy += -GSR_SH_C1 * s[1]; ddz += GSR_SH_C1 * s[2]; ddx += -GSR_SH_C1 * s[3];
@@ -502,23 +667,48 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (out.dL_dshs) stage_sh_out<KT>(out.dL_dshs, wave_first, n_valid, K, lw, out.accumulate != 0);
+    // accumulating: a wave without a visible Gaussian adds nothing to its rows
+    if constexpr (SCENE) {
+      if (!(out.accumulate && vmask == 0ull)) {
+        if (sg.dc[rw.m]) stage_rows_out(sg.dc[rw.m] + wave_first * 3, 3, 0, stride, n_valid, lw, out.accumulate != 0, vmask);
+        if (K > 1 && sg.rest[rw.m])
+          stage_rows_out(sg.rest[rw.m] + wave_first * (3 * K - 3), 3 * K - 3, 3, stride, n_valid, lw, out.accumulate != 0, vmask);
+      }
+    } else if (out.dL_dshs && !(out.accumulate && vmask == 0ull))
+      stage_sh_out<KT>(out.dL_dshs, wave_first, n_valid, K, lw, out.accumulate != 0);
   }
 
   float dscale[3] = {0.f, 0.f, 0.f};
   float drot[4] = {0.f, 0.f, 0.f, 0.f};
   float dc6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] float dsc_draw[3] = {1.f, 1.f, 1.f};   // scene: d(returned scale)/d(raw scaling)
   if (vis) {
     float c6[6];
     float R[9];
     float s3[3] = {0.f, 0.f, 0.f};
     float4 q = make_float4(1, 0, 0, 0);
+    [[maybe_unused]] float4 qraw = q;
+    [[maybe_unused]] float qnorm = 1.0f;
     if (g.cov3D_precomp) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) c6[k] = g.cov3D_precomp[6 * i + k];
     } else {
-      s3[0] = mod * g.scales[3 * i]; s3[1] = mod * g.scales[3 * i + 1]; s3[2] = mod * g.scales[3 * i + 2];
-      q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
+      float sa[3] = {p_scale[3 * row], p_scale[3 * row + 1], p_scale[3 * row + 2]};
+      q = *reinterpret_cast<const float4*>(p_rot + 4 * row);
+      if constexpr (SCENE) {
+        qraw = q;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float n = sc.scale_noise ? sc.scale_noise[3 * i + k] : 0.f;
+          const ActScale a = act_scale(sa[k], sc.scale_noise != nullptr, n);
+          sa[k] = a.out;
+          // d out / d raw = exp(raw) * (1 + n sqrt(0.2)/4) where the clamp passes (torch.clamp: pre >= 0)
+          dsc_draw[k] = sc.scale_noise ? (a.pre >= 0.0f ? a.act * (1.0f + n * (kSqrtPoint2 / 4.0f)) : 0.0f) : a.act;
+        }
+        qnorm = act_quat_norm(q);
+        q = make_float4(q.x / qnorm, q.y / qnorm, q.z / qnorm, q.w / qnorm);
+      }
+      s3[0] = mod * sa[0]; s3[1] = mod * sa[1]; s3[2] = mod * sa[2];
       quat_to_R(q, R);
       cov3d_from(s3[0], s3[1], s3[2], R, c6);
     }
@@ -625,10 +815,71 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const int32_t* __restric
       drot[1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
       drot[2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
       drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+      if constexpr (SCENE) {
+        // through exp (+ noise, clamp) and through q = raw / |raw|:  d raw = (dq - q <q, dq>) / |raw|
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dscale[k] = dscale[k] * dsc_draw[k];
+        const float qd = ((q.x * drot[0] + q.y * drot[1]) + q.z * drot[2]) + q.w * drot[3];
+        drot[0] = (drot[0] - q.x * qd) / qnorm; drot[1] = (drot[1] - q.y * qd) / qnorm;
+        drot[2] = (drot[2] - q.z * qd) / qnorm; drot[3] = (drot[3] - q.w * qd) / qnorm;
+      }
     }
   }
 
-  if (i < P) {
+  if constexpr (SCENE) {
+    if (rw.ok) {
+      out.dL_dmeans2D[3 * i] = gndx; out.dL_dmeans2D[3 * i + 1] = gndy; out.dL_dmeans2D[3 * i + 2] = 0.f;
+      // gradient arriving through the RETURNED scales (the trainers' loss_scale, object_trainer.py:378-379): it
+      // reaches every Gaussian, visible or not
+      const bool has_gs = sg.dL_dscales_out != nullptr;
+      if (has_gs) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (!vis) {
+            const float n = sc.scale_noise ? sc.scale_noise[3 * i + k] : 0.f;
+            const ActScale a = act_scale(p_scale[3 * row + k], sc.scale_noise != nullptr, n);
+            dsc_draw[k] = sc.scale_noise ? (a.pre >= 0.0f ? a.act * (1.0f + n * (kSqrtPoint2 / 4.0f)) : 0.0f) : a.act;
+          }
+          dscale[k] += sg.dL_dscales_out[3 * i + k] * dsc_draw[k];
+        }
+      }
+      if (out.accumulate && !vis) {
+        float* o = sg.scaling[rw.m];
+        if (has_gs && o) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) o[3 * row + k] += dscale[k];
+        }
+      } else {
+        const bool acc = out.accumulate != 0;
+        float gop_raw = 0.f;
+        if (vis) {
+          const float sg_ = act_sigmoid(sc.opacity[rw.m][row]);
+          gop_raw = gop * (sg_ * (1.0f - sg_));
+        }
+        float* o;
+        if ((o = sg.xyz[rw.m])) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) o[3 * row + k] = acc ? o[3 * row + k] + dp[k] : dp[k];
+        }
+        if ((o = sg.scaling[rw.m])) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) o[3 * row + k] = acc ? o[3 * row + k] + dscale[k] : dscale[k];
+        }
+        if ((o = sg.rotation[rw.m])) {
+          float4 t = make_float4(drot[0], drot[1], drot[2], drot[3]);
+          if (acc) {
+            const float4 old = *reinterpret_cast<const float4*>(o + 4 * row);
+            t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w;
+          }
+          *reinterpret_cast<float4*>(o + 4 * row) = t;
+        }
+        if ((o = sg.opacity[rw.m])) o[row] = acc ? o[row] + gop_raw : gop_raw;
+      }
+    }
+  } else if (i < P && out.accumulate && !vis) {
+    // accumulating: a culled Gaussian adds nothing; only the per-view means2D gradient is (re)written
+    out.dL_dmeans2D[3 * i] = 0.f; out.dL_dmeans2D[3 * i + 1] = 0.f; out.dL_dmeans2D[3 * i + 2] = 0.f;
+  } else if (i < P) {
     float gop_o = gop;
     if (out.accumulate) {
       // sum over views on the device (the reference accumulates C_batch_size views per optimizer step,
@@ -694,12 +945,46 @@ uint32_t* gsr_tile_rects(const GsrGeom& geom, int32_t P);   // binning.hip: pack
 
 size_t gsr_preprocess_lds_bytes(int K) { return (size_t)4 * 64 * sh_lds_stride(K) * sizeof(float); }
 
+// GsrScene (host) -> the by-value kernel tables
+static uint32_t scene_tables(const GsrScene& sc, const GsrSceneGrads* sgr, SceneTab& t, SceneGradTab& gt) {
+  t = SceneTab{};
+  gt = SceneGradTab{};
+  t.n = sc.n_models;
+  gt.dL_dscales_out = sgr ? sgr->dL_dscales_out : nullptr;
+  int32_t first = 0, blk = 0;
+  for (int m = 0; m < sc.n_models; ++m) {
+    const GsrModel& md = sc.models[m];
+    t.first[m] = first; t.fblk[m] = blk;
+    first += md.count; blk += (md.count + 255) / 256;
+    t.xyz[m] = md.xyz; t.scaling[m] = md.scaling; t.rotation[m] = md.rotation; t.opacity[m] = md.opacity;
+    t.dc[m] = md.features_dc; t.rest[m] = md.features_rest;
+    if (sgr) {
+      const GsrModelGrads& mg = sgr->models[m];
+      gt.xyz[m] = mg.xyz; gt.scaling[m] = mg.scaling; gt.rotation[m] = mg.rotation; gt.opacity[m] = mg.opacity;
+      gt.dc[m] = mg.features_dc; gt.rest[m] = mg.features_rest;
+    }
+  }
+  for (int m = sc.n_models; m <= GSR_MAX_MODELS; ++m) { t.first[m] = first; t.fblk[m] = blk; }
+  t.scale_noise = sc.scale_noise; t.sh_noise = sc.sh_noise;
+  t.scales_out = sc.scales_out; t.rotations_out = sc.rotations_out; t.opacities_out = sc.opacities_out;
+  return (uint32_t)blk;
+}
+
 int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom, hipStream_t stream) {
+  if (g.scene) {
+    SceneTab t; SceneGradTab gt;
+    const uint32_t nbs = scene_tables(*g.scene, nullptr, t, gt);
+    const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
+    hipLaunchKernelGGL((k_preprocess<0, true, SceneTab>), dim3(nbs), dim3(256), lds, stream, v, g, t, geom.splat,
+                       geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P), gsr_tile_rects(geom, v.P));
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+  }
   const uint32_t nb = gsr_num_blocks(v.P);
   const size_t lds = g.shs ? gsr_preprocess_lds_bytes(v.sh_stride) : 0;
   // compile-time strides read their rows directly (no LDS); only the generic stride stages through LDS
-#define GSR_LAUNCH_K1(KT)                                                                                      \
-  hipLaunchKernelGGL(k_preprocess<KT>, dim3(nb), dim3(256), (KT) > 0 ? 0 : lds, stream, v, g, geom.splat,     \
+#define GSR_LAUNCH_K1(KT)                                                                                         \
+  hipLaunchKernelGGL(k_preprocess<KT>, dim3(nb), dim3(256), (KT) > 0 ? 0 : lds, stream, v, g, NoScene{}, geom.splat, \
                      geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P), gsr_tile_rects(geom, v.P))
   switch (g.shs ? v.sh_stride : 0) {
     case 16: GSR_LAUNCH_K1(16); break;
@@ -715,10 +1000,20 @@ int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom
 
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const GsrGeom& geom, const GsrGrads& out,
                               hipStream_t stream) {
+  if (g.scene) {
+    SceneTab t; SceneGradTab gt;
+    const uint32_t nbs = scene_tables(*g.scene, out.scene, t, gt);
+    const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
+    hipLaunchKernelGGL((k_preprocess_bwd<0, true, SceneTab, SceneGradTab>), dim3(nbs), dim3(256), lds, stream, v, g, t,
+                       gt, geom.radii, out.partials, out);
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+  }
   const uint32_t nb = gsr_num_blocks(v.P);
   const size_t lds = g.shs ? gsr_preprocess_lds_bytes(v.sh_stride) : 0;
-#define GSR_LAUNCH_K8(KT) \
-  hipLaunchKernelGGL(k_preprocess_bwd<KT>, dim3(nb), dim3(256), lds, stream, v, g, geom.radii, out.partials, out)
+#define GSR_LAUNCH_K8(KT)                                                                                          \
+  hipLaunchKernelGGL(k_preprocess_bwd<KT>, dim3(nb), dim3(256), lds, stream, v, g, NoScene{}, NoScene{}, geom.radii, \
+                     out.partials, out)
   switch (g.shs ? v.sh_stride : 0) {
     case 16: GSR_LAUNCH_K8(16); break;
     case 9: GSR_LAUNCH_K8(9); break;

@@ -81,7 +81,7 @@ def _view_struct(s: GaussianRasterizationSettings, P: int, K: int, bg, vm, pm, c
 
 class _State:
     """Everything the backward needs; tensors are kept alive here (the C side owns nothing)."""
-    __slots__ = ("view", "gauss", "geom", "binning", "images", "keep", "P", "K", "N", "dev", "cam_grads")
+    __slots__ = ("view", "gauss", "geom", "binning", "images", "keep", "P", "K", "N", "dev", "cam_grads", "scene")
 
 
 class _Workspace:
@@ -128,14 +128,57 @@ def _align(n: int, a: int = 256) -> int:
 
 def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
                           rotations, cov3D_precomp, want_keys: bool = False, want_aux: bool = True,
-                          mode: Optional[str] = None):
-    """Forward through the C ABI. Returns (outputs dict, _State). Used by the autograd Function and by tests."""
+                          mode: Optional[str] = None, scene: Optional[dict] = None):
+    """Forward through the C ABI. Returns (outputs dict, _State). Used by the autograd Function and by tests.
+    scene (SURVEY.md 8f rank 2): {"models": [(xyz, scaling, rotation, opacity, features_dc, features_rest), ...] raw
+    leaf tensors, "scale_noise": [P,3] | None, "sh_noise": [P,K,3] | None, "want_act": bool}; the per-Gaussian
+    tensor arguments must then be None."""
     lib = L.load()
-    dev = means3D.device
+    dev = (scene["models"][0][0] if scene is not None else means3D).device
     if dev.type != "cuda":
         raise L.GsrError("the HIP rasterizer needs tensors on a cuda (ROCm) device; there is no CPU fallback")
-    P = int(means3D.shape[0])
     H, W = int(s.image_height), int(s.image_width)
+    sc_struct, sc_keep, sc_out = None, None, {}
+    if scene is not None:
+        if any(t is not None for t in (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)):
+            raise ValueError("with scene= the per-Gaussian tensor arguments must be None")
+        models = scene["models"]
+        if not 1 <= len(models) <= L.GSR_MAX_MODELS:
+            raise ValueError(f"1..{L.GSR_MAX_MODELS} models per call, got {len(models)}")
+        sc_struct = L.GsrScene()
+        sc_struct.n_models = len(models)
+        sc_keep = []
+        P, K_scene = 0, None
+        for m, md in enumerate(models):
+            xyz, scaling, rotation, opacity, f_dc, f_rest = [_prep(t, "model tensor", dev) for t in md]
+            n = int(xyz.shape[0])
+            k = 1 + (int(f_rest.shape[1]) if f_rest is not None and f_rest.numel() > 0 else 0)
+            if n > 0:
+                if K_scene is not None and k != K_scene:
+                    raise ValueError("all models of a scene must have the same number of SH coefficients")
+                K_scene = k
+            ms = sc_struct.models[m]
+            ms.count = n
+            ms.xyz, ms.scaling, ms.rotation, ms.opacity = _ptr(xyz), _ptr(scaling), _ptr(rotation), _ptr(opacity)
+            ms.features_dc, ms.features_rest = _ptr(f_dc), (_ptr(f_rest) if k > 1 else None)
+            sc_keep.append((xyz, scaling, rotation, opacity, f_dc, f_rest))
+            P += n
+        K_scene = K_scene or 1
+        sn, hn = _prep(scene.get("scale_noise"), "scale_noise", dev), _prep(scene.get("sh_noise"), "sh_noise", dev)
+        if sn is not None and tuple(sn.shape) != (P, 3):
+            raise ValueError(f"scale_noise must be [P,3], got {tuple(sn.shape)}")
+        if hn is not None and tuple(hn.shape) != (P, K_scene, 3):
+            raise ValueError(f"sh_noise must be [P,K,3], got {tuple(hn.shape)}")
+        sc_struct.scale_noise, sc_struct.sh_noise = _ptr(sn), _ptr(hn)
+        sc_out["scales"] = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        sc_struct.scales_out = sc_out["scales"].data_ptr()
+        if scene.get("want_act"):
+            sc_out["rotations"] = torch.empty((P, 4), dtype=torch.float32, device=dev)
+            sc_out["opacities"] = torch.empty((P,), dtype=torch.float32, device=dev)
+            sc_struct.rotations_out, sc_struct.opacities_out = sc_out["rotations"].data_ptr(), sc_out["opacities"].data_ptr()
+        sc_keep.append((sn, hn))
+    else:
+        P = int(means3D.shape[0])
     means3D = _prep(means3D, "means3D", dev)
     opacities = _prep(opacities, "opacities", dev)
     shs, colors_precomp = _prep(shs, "shs", dev), _prep(colors_precomp, "colors_precomp", dev)
@@ -145,7 +188,7 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     vm = _prep(s.viewmatrix.reshape(-1), "viewmatrix", dev)
     pm = _prep(s.projmatrix.reshape(-1), "projmatrix", dev)
     cp = _prep(s.campos.reshape(-1), "campos", dev)
-    K = int(shs.shape[1]) if shs is not None else 0
+    K = int(shs.shape[1]) if shs is not None else (K_scene if scene is not None else 0)
     if shs is not None and (shs.dim() != 3 or shs.shape[0] != P or shs.shape[2] != 3):
         raise ValueError(f"shs must be [P,K,3], got {tuple(shs.shape)}")
 
@@ -155,7 +198,10 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     g = L.GsrGaussians()
     g.means3D, g.opacities, g.shs, g.colors_precomp = _ptr(means3D), _ptr(opacities), _ptr(shs), _ptr(colors_precomp)
     g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp)
+    if sc_struct is not None:
+        g.scene = C.pointer(sc_struct)
     st.gauss = g
+    st.scene = (sc_struct, sc_keep) if sc_struct is not None else None
 
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = _workspace(dev, stream)
@@ -283,7 +329,7 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     # ^ backward re-reads the output image (suffix sums from checkpoints). DETACHED aliases on purpose: the objects
     #   returned to autograd acquire grad_fn -> ctx -> this state; keeping them here would close a reference cycle
     #   and defer every free to Python's cyclic GC (measured: memory bloat and 5x slowdown after ~500 views).
-    out = dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, N=N)
+    out = dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, N=N, **{"act_" + k: v for k, v in sc_out.items()})
     if want_aux:
         def view(name, dtype, count, shape=None):
             bufk, off = view_src[name]
@@ -298,12 +344,67 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     return out, st
 
 
+def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, model_grads, accumulate: bool,
+                    dL_dscales_out=None) -> dict:
+    """Backward of a scene forward: the parameter gradients are written (or, with accumulate, ADDED) straight into
+    per-model tensors shaped like the raw leaves. model_grads: list of 6-tuples (None entries are allocated here)."""
+    lib = L.load()
+    dev, P, K = st.dev, st.P, st.K
+    f32 = torch.float32
+    sc_struct, sc_keep = st.scene
+    sg = L.GsrSceneGrads()
+    outs = []
+    for m in range(sc_struct.n_models):
+        leaves = sc_keep[m]
+        given = model_grads[m] if model_grads is not None else (None,) * 6
+        row = []
+        for t, gt in zip(leaves, given):
+            if t is None or (t.numel() == 0 and gt is None):
+                row.append(None if t is None else torch.zeros_like(t))
+                continue
+            if gt is None:
+                if accumulate:
+                    raise ValueError("accumulate=True needs the gradient tensors to add to")
+                gt = torch.empty_like(t)
+            elif gt.shape != t.shape or gt.dtype != f32 or not gt.is_contiguous() or gt.device != dev:
+                raise ValueError("model gradient tensors must match the raw leaves (shape, fp32, contiguous, device)")
+            row.append(gt)
+        mg = sg.models[m]
+        mg.xyz, mg.scaling, mg.rotation, mg.opacity = _ptr(row[0]), _ptr(row[1]), _ptr(row[2]), _ptr(row[3])
+        mg.features_dc, mg.features_rest = _ptr(row[4]), (_ptr(row[5]) if K > 1 else None)
+        outs.append(tuple(row))
+    o = dict(dL_dmeans2D=torch.empty((P, 3), dtype=f32, device=dev), model_grads=outs,
+             dL_dview=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
+             dL_dproj=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
+             dL_dcampos=torch.zeros(3, dtype=f32, device=dev) if cam_grads else None)
+    partials = torch.empty((max(P, 1), 12), dtype=f32, device=dev)
+    gr = L.GsrGrads()
+    gr.dL_dmeans2D = o["dL_dmeans2D"].data_ptr()
+    gr.dL_dview, gr.dL_dproj, gr.dL_dcampos = _ptr(o["dL_dview"]), _ptr(o["dL_dproj"]), _ptr(o["dL_dcampos"])
+    gr.partials = partials.data_ptr()
+    gr.accumulate = int(bool(accumulate))
+    dL_dscales_out = _prep(dL_dscales_out, "dL_dscales_out", dev)
+    sg.dL_dscales_out = _ptr(dL_dscales_out)
+    gr.scene = C.pointer(sg)
+    ig = L.GsrImageGrads()
+    ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    prof = PROFILE.handle if PROFILE is not None else None
+    with torch.cuda.device(dev):
+        L.check(lib.gsr_backward(C.byref(st.view), C.byref(st.gauss), C.byref(st.geom), C.byref(st.binning),
+                                 C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
+    o["partials"] = partials
+    return o
+
+
 def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool = False, arena=None,
-                           accumulate: bool = False) -> dict:
+                           accumulate: bool = False, model_grads=None, dL_dscales_out=None) -> dict:
     lib = L.load()
     dev, P, K = st.dev, st.P, st.K
     dL_dcolor = _prep(dL_dcolor, "dL_dcolor", dev)
     dL_ddepth_alpha = _prep(dL_ddepth_alpha, "dL_ddepth_alpha", dev)
+    if st.scene is not None:
+        return _backward_scene(st, dL_dcolor, dL_ddepth_alpha, cam_grads, model_grads, accumulate, dL_dscales_out)
     g = st.gauss
     f32 = torch.float32
     av = {}

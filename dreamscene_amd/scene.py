@@ -1,0 +1,126 @@
+"""Gather-free multi-model rendering with the activations fused into the rasterizer.
+
+`SceneGaussian.scene_render` (scene_gaussian.py:673-893) builds the rasterizer inputs of a view by running the
+activations of every visible GaussianModel (gs_renderer.py:464-488: exp / normalize / sigmoid / cat(f_dc, f_rest)),
+`torch.cat`-ing the results of all models (:753-843) and, when training, adding noise to the SH coefficients and the
+scales (:844-852) -- about forty elementwise / copy kernels and ~1 GB of HBM traffic per view at 2.3 M Gaussians,
+as much as the rasterizer itself. Here the RAW leaf tensors go to the HIP kernels as a table of models
+(include/gsrast.h, GsrScene): K1 applies the activations while it reads, culled Gaussians never touch their SH
+rows, and K8 writes the gradients of the raw leaves directly (no cat / split / activation backward kernels).
+
+    image, radii, depth_alpha, scales = rasterize_models(settings, models, means2D, scale_noise=None, sh_noise=None)
+
+`models` is a list of objects with `_xyz, _scaling, _rotation, _opacity, _features_dc, _features_rest` (GaussianModel's
+own attribute names) or of 6-tuples in that order. Index i of every per-Gaussian result (radii, means2D.grad, scales)
+is the index torch.cat over the models would give. `scene_render` below restates the reference's glue on top of it.
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import rasterizer as R
+
+LEAVES = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
+# Optional: per-model tuples of 6 tensors the backward ADDS this view's gradients to (device-side accumulation over
+# the views of one optimizer step, like rasterizer.GRAD_ARENA); the autograd outputs are then None for the leaves.
+MODEL_GRAD_BUFFERS: Optional[List[tuple]] = None
+
+
+def _leaves(model) -> tuple:
+    if isinstance(model, (tuple, list)):
+        if len(model) != 6:
+            raise ValueError("a model tuple is (xyz, scaling, rotation, opacity, features_dc, features_rest)")
+        return tuple(model)
+    return tuple(getattr(model, n) for n in LEAVES)
+
+
+class _RasterizeModels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, settings, scale_noise, sh_noise, means2D, *leaves):
+        models = [tuple(leaves[6 * m:6 * m + 6]) for m in range(len(leaves) // 6)]
+        out, st = R.rasterize_forward_raw(settings, None, None, None, None, None, None, None, want_aux=False,
+                                          scene=dict(models=models, scale_noise=scale_noise, sh_noise=sh_noise))
+        ctx.st = st
+        ctx.n_leaves = len(leaves)
+        ctx.mark_non_differentiable(out["radii"])
+        if settings.score_flag:
+            ctx.mark_non_differentiable(out["score"])
+            return out["score"], out["color"], out["radii"], out["depth_alpha"], out["act_scales"]
+        return out["color"], out["radii"], out["depth_alpha"], out["act_scales"]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        st = ctx.st
+        g_color, _, g_da, g_scales = grads[-4:]
+        H, W = st.view.image_height, st.view.image_width
+        if g_color is None:
+            g_color = torch.zeros((3, H, W), dtype=torch.float32, device=st.dev)
+        if g_da is None:
+            g_da = torch.zeros((2, H, W), dtype=torch.float32, device=st.dev)
+        bufs = MODEL_GRAD_BUFFERS
+        o = R.rasterize_backward_raw(st, g_color, g_da, model_grads=bufs, accumulate=bufs is not None,
+                                     dL_dscales_out=g_scales)
+        flat = []
+        for row in o["model_grads"]:
+            flat.extend([None] * 6 if bufs is not None else row)
+        return (None, None, None, o["dL_dmeans2D"], *flat)
+
+
+def rasterize_models(settings, models: Sequence, means2D: torch.Tensor, scale_noise: Optional[torch.Tensor] = None,
+                     sh_noise: Optional[torch.Tensor] = None):
+    """One view of several GaussianModels through the fused path. Returns what GaussianRasterizer returns, plus the
+    activated (and augmented) scales [P,3] (differentiable: the trainers put a loss on them)."""
+    flat = []
+    for m in models:
+        flat.extend(_leaves(m))
+    return _RasterizeModels.apply(settings, scale_noise, sh_noise, means2D, *flat)
+
+
+def scene_render(models: Sequence, camera, bg_color: torch.Tensor, active_sh_degree: int,
+                 scaling_modifier: float = 1.0, black_video: bool = False, sh_deg_aug_ratio: float = 0.1,
+                 bg_aug_ratio: float = 0.3, shs_aug_ratio: float = 1.0, scale_aug_ratio: float = 1.0,
+                 test: bool = False, no_grad: bool = False, rng: random.Random = random):
+    """SceneGaussian.scene_render (scene_gaussian.py:673-893) over the fused path: same random augmentation decisions
+    in the same order, same output dict. The noise samples are drawn with torch.randn in the concatenated index space
+    (the reference draws them with randn_like on the concatenated tensors)."""
+    from .rasterizer import GaussianRasterizationSettings
+    first = _leaves(models[0])[0]
+    dev = first.device
+    P = sum(int(_leaves(m)[0].shape[0]) for m in models)
+    K = 1 + int(_leaves(models[0])[5].shape[1])
+    screenspace_points = torch.zeros((P, 3), dtype=first.dtype, requires_grad=True, device=dev) + 0
+    if not no_grad:
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+    if black_video:
+        bg_color = torch.zeros_like(bg_color)
+    act_SH = 0 if (rng.random() < sh_deg_aug_ratio and not test) else active_sh_degree
+    if rng.random() < bg_aug_ratio and not test:
+        bg_color = torch.rand_like(bg_color) if rng.random() < 0.5 else torch.zeros_like(bg_color)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+    settings = GaussianRasterizationSettings(
+        image_height=int(camera.image_height), image_width=int(camera.image_width),
+        tanfovx=math.tan(camera.FoVx * 0.5), tanfovy=math.tan(camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=t(camera.world_view_transform),
+        projmatrix=t(camera.full_proj_transform), sh_degree=act_SH, campos=t(camera.camera_center),
+        prefiltered=False, score_flag=False)
+    sh_noise = torch.randn((P, K, 3), dtype=torch.float32, device=dev) if (rng.random() < shs_aug_ratio and not test) else None
+    scale_noise = torch.randn((P, 3), dtype=torch.float32, device=dev) if (rng.random() < scale_aug_ratio and not test) else None
+    rendered_image, radii, depth_alpha, scales = rasterize_models(settings, models, screenspace_points, scale_noise,
+                                                                  sh_noise)
+    depth, alpha = torch.chunk(depth_alpha, 2)
+    focal = 1 / (2 * math.tan(camera.FoVx / 2))
+    disp = focal / (depth + (alpha * 10) + 1e-5)
+    try:
+        min_d = disp[alpha <= 0.1].min()
+    except Exception:
+        min_d = disp.min()
+    disp = torch.clamp((disp - min_d) / (disp.max() - min_d), 0.0, 1.0)
+    return {"image": rendered_image, "depth": disp, "alpha": alpha, "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0, "radii": radii, "scales": scales}

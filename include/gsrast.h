@@ -60,8 +60,45 @@ typedef struct GsrView {
   const float* campos;     /* device f32[3]  */
 } GsrView;
 
+/* ---- gather-free multi-model input with the activations fused into K1 / K8 -------
+ * `scene_render` (scene_gaussian.py:673-893) concatenates the leaf tensors of every visible GaussianModel with
+ * torch.cat on every call (:753-843), after running their activations (gs_renderer.py:464-488: exp, normalize,
+ * sigmoid, cat(features_dc, features_rest)) and, when training, the noise augmentations (:844-852). A GsrScene hands
+ * the RAW leaf tensors of up to GSR_MAX_MODELS models to K1 / K8 instead: Gaussian i of the concatenated index space
+ * is row i - first(m) of model m, nothing is copied, and culled Gaussians never touch their SH rows. */
+#define GSR_MAX_MODELS 16
+typedef struct GsrModel {      /* leaf tensors of one GaussianModel (gs_renderer.py:185-203), all on the device */
+  int32_t count;               /* Gaussians in this model                                                   */
+  int32_t reserved_;
+  const float* xyz;            /* [count,3]      _xyz                                                      */
+  const float* scaling;        /* [count,3]      _scaling  (log scale;   activation exp,       :465-466)    */
+  const float* rotation;       /* [count,4]      _rotation (raw w,x,y,z; activation normalize, :469-470)    */
+  const float* opacity;        /* [count,1]      _opacity  (logit;       activation sigmoid,   :487-488)    */
+  const float* features_dc;    /* [count,1,3]    _features_dc                                               */
+  const float* features_rest;  /* [count,K-1,3]  _features_rest (NULL if K == 1)                            */
+} GsrModel;
+typedef struct GsrScene {
+  int32_t n_models;            /* 1..GSR_MAX_MODELS; GsrView.P must equal the sum of the counts, sh_stride = K */
+  int32_t reserved_;
+  GsrModel models[GSR_MAX_MODELS];
+  const float* scale_noise;    /* NULL or [P,3]   N(0,1) samples: scales <- max(0, s + n * (sqrt(0.2) * s / 4)) (:849-852) */
+  const float* sh_noise;       /* NULL or [P,K,3] N(0,1) samples: shs <- shs + n * (sqrt(0.2) * shs)           (:844-847) */
+  float* scales_out;           /* NULL or [P,3]: the activated (and augmented) scales scene_render returns (:892) */
+  float* rotations_out;        /* NULL or [P,4]: normalised quaternions (parity tests)                        */
+  float* opacities_out;        /* NULL or [P]:   sigmoid(opacity)        (parity tests)                        */
+} GsrScene;
+/* Gradients w.r.t. the RAW leaf tensors of each model (same shapes). NULL entries are skipped. */
+typedef struct GsrModelGrads {
+  float *xyz, *scaling, *rotation, *opacity, *features_dc, *features_rest;
+} GsrModelGrads;
+typedef struct GsrSceneGrads {
+  GsrModelGrads models[GSR_MAX_MODELS];
+  const float* dL_dscales_out; /* NULL or [P,3]: gradient arriving through GsrScene.scales_out (the trainers put a loss
+                                  on the returned scales, object_trainer.py:378-379); chained into `scaling` */
+} GsrSceneGrads;
+
 /* Inputs of GaussianRasterizer.forward (scene_gaussian.py:1012-1021). Exactly one of shs / colors_precomp and
- * exactly one of (scales, rotations) / cov3D_precomp is non-NULL. */
+ * exactly one of (scales, rotations) / cov3D_precomp is non-NULL -- or `scene` is set and all of them are NULL. */
 typedef struct GsrGaussians {
   const float* means3D;        /* [P,3]                                            */
   const float* opacities;      /* [P] (the reference passes [P,1])                  */
@@ -70,6 +107,7 @@ typedef struct GsrGaussians {
   const float* scales;         /* [P,3] post-activation                            */
   const float* rotations;      /* [P,4] (w,x,y,z), already normalised              */
   const float* cov3D_precomp;  /* [P,6] [xx,xy,xz,yy,yz,zz] (gs_renderer.py:79-88)  */
+  const GsrScene* scene;       /* host pointer or NULL: raw multi-model input (see GsrScene) */
 } GsrGaussians;
 
 /* Projected per-Gaussian state: written by gsr_forward_project, read by render and backward (save it).
@@ -154,6 +192,8 @@ typedef struct GsrGrads {
                            hold (device-side sum over the views of one optimizer step). dL_dmeans2D is per view
                            and always overwritten; dL_dview/proj/campos always accumulate                     */
   int32_t reserved_;
+  const GsrSceneGrads* scene; /* host pointer; required iff GsrGaussians.scene was given: the parameter gradients go
+                                 to the models' raw leaves and dL_dmeans3D/scales/rotations/opacities/shs must be NULL */
 } GsrGrads;
 
 /* Optional per-stage timing with HIP events on the caller's stream (bench.py uses it for `roofline`). */

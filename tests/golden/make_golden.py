@@ -7,6 +7,8 @@ plain input/output arrays. What each fixture pins:
                                                               gs_renderer.py:79-88, 124-172
   cameras.npz        RCamera matrices for GenSingleCam poses  utils/cam_utils.py:148-217, 1894-1911
   projection.npz     geom_transform_points (+1e-7 on w)       utils/graphics_utils.py:29-36
+  scene_render.npz   the reference's UNCHANGED SceneGaussian.scene_render (scene_gaussian.py:673-893) over the same
+                     oracle, three models, test=True: activation + torch.cat glue and gradient landing sites
   object_render.npz  the reference's UNCHANGED SceneGaussian.object_render (scene_gaussian.py:895-1044) driven over
                      this repo's CPU oracle registered as `diff_gaussian_rasterization` (BASELINE.json config 1,
                      "plumbing"): settings construction, output dict, disp post-processing, where .grad lands.
@@ -188,6 +190,49 @@ def main():
              vsp_grad=out["viewspace_points"].grad.numpy(), g_xyz=gm._xyz.grad.numpy(), g_scaling=gm._scaling.grad.numpy(),
              g_rotation=gm._rotation.grad.numpy(), g_opacity=gm._opacity.grad.numpy(), g_f_dc=gm._features_dc.grad.numpy(),
              g_f_rest=gm._features_rest.grad.numpy())
+    # ---- the reference's scene_render (scene_gaussian.py:673-893) over the oracle: three models of different sizes,
+    # test=True (no random augmentation). Pins the activation + concatenation glue the fused multi-model path replaces.
+    random.seed(1)
+    torch.manual_seed(1)
+    sizes = [300, 517, 130]
+    models = []
+    for mi, n in enumerate(sizes):
+        gg = synth.g_object(n, seed=11 + mi, K=16)
+        gg["scales"] = (gg["scales"] * 5).astype(np.float32)
+        m = G.GaussianModel({"sh_degree": 3}, "scene")
+        m.active_sh_degree = 2
+        off = np.array([[0.35 * (mi - 1), 0.1 * mi, 0.0]], dtype=np.float32)
+        m._xyz = torch.nn.Parameter(torch.tensor(gg["means3D"] * 0.8 + off))
+        m._scaling = torch.nn.Parameter(torch.log(torch.tensor(gg["scales"])))
+        m._rotation = torch.nn.Parameter(torch.tensor(gg["rotations"]) * (0.7 + 0.4 * mi))
+        opm = np.clip(gg["opacities"], 1e-4, 1 - 1e-4)
+        m._opacity = torch.nn.Parameter(torch.tensor(np.log(opm / (1 - opm))))
+        m._features_dc = torch.nn.Parameter(torch.tensor(gg["shs"][:, :1, :]))
+        m._features_rest = torch.nn.Parameter(torch.tensor(gg["shs"][:, 1:, :]))
+        models.append(m)
+    names = ["env", "obj_a", "obj_b"]
+    sg.gaussians_collection = {nm: SG.ObjectGaussian(id=nm, step=0, model=m, text={}, image={}, cam_pose_method="")
+                               for nm, m in zip(names, models)}
+    sg.env_gaussian = models[0]
+    out = sg.scene_render(names, cam, bg, test=True)
+    gi = torch.tensor(rng.normal(size=(3, 64, 64)).astype(np.float32))
+    gd = torch.tensor(rng.normal(size=(1, 64, 64)).astype(np.float32))
+    ga = torch.tensor(rng.normal(size=(1, 64, 64)).astype(np.float32))
+    loss = (out["image"] * gi).sum() + (out["depth"] * gd).sum() + (out["alpha"] * ga).sum() + \
+        0.01 * torch.mean(out["scales"], dim=-1).mean()
+    loss.backward()
+    rec = dict(sizes=np.array(sizes), active_sh_degree=np.int64(2), wvt=cam.world_view_transform.numpy(),
+               full=cam.full_proj_transform.numpy(), center=cam.camera_center.numpy(), FoVx=np.float64(cam.FoVx),
+               FoVy=np.float64(cam.FoVy), bg=bg.numpy(), gi=gi.numpy(), gd=gd.numpy(), ga=ga.numpy(),
+               image=out["image"].detach().numpy(), depth=out["depth"].detach().numpy(),
+               alpha=out["alpha"].detach().numpy(), radii=out["radii"].numpy(),
+               visibility_filter=out["visibility_filter"].numpy(), scales_out=out["scales"].detach().numpy(),
+               keys=np.array(sorted(out.keys())), vsp_grad=out["viewspace_points"].grad.numpy())
+    for mi, m in enumerate(models):
+        for leaf in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
+            rec[f"m{mi}{leaf}"] = getattr(m, leaf).detach().numpy()
+            rec[f"g{mi}{leaf}"] = getattr(m, leaf).grad.numpy()
+    np.savez(os.path.join(HERE, "scene_render.npz"), **rec)
     print("fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

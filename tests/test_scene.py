@@ -1,0 +1,202 @@
+"""the fused multi-model path (dreamscene_amd/scene.py, GsrScene in include/gsrast.h).
+
+CPU: the oracle's restatement of the scene_render glue against the reference's own scene_render (golden fixture).
+GPU: the HIP fused path against that fixture and against the oracle with noise augmentation / accumulation."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_golden import _cam_from_fixture, load
+
+LEAVES = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
+
+
+def _models_from_fixture(d, device="cpu", dtype=torch.float32):
+    n = len(d["sizes"])
+    return [tuple(torch.tensor(d[f"m{m}{leaf}"], dtype=dtype, device=device, requires_grad=True) for leaf in LEAVES)
+            for m in range(n)]
+
+
+def _loss(out, d, dev="cpu"):
+    g = lambda k: torch.tensor(d[k], device=dev)
+    return (out["image"] * g("gi")).sum() + (out["depth"] * g("gd")).sum() + (out["alpha"] * g("ga")).sum() + \
+        0.01 * torch.mean(out["scales"], dim=-1).mean()
+
+
+def test_scene_oracle_glue_matches_reference_scene_render():
+    from oracle import scene_oracle as SO, torch_oracle as TO
+    d = load("scene_render.npz")
+    models = _models_from_fixture(d)
+    cam = _cam_from_fixture(d)
+    rast = lambda raster_settings: TO.GaussianRasterizer(raster_settings, dtype=torch.float64)
+    out = SO.scene_render(models, cam, torch.tensor(d["bg"]), int(d["active_sh_degree"]), rast,
+                          TO.GaussianRasterizationSettings)
+    assert sorted(out.keys()) == list(d["keys"])
+    np.testing.assert_allclose(out["image"].detach().numpy(), d["image"], atol=1e-6)
+    np.testing.assert_allclose(out["alpha"].detach().numpy(), d["alpha"], atol=1e-6)
+    np.testing.assert_allclose(out["depth"].detach().numpy(), d["depth"], atol=1e-5)
+    assert np.array_equal(out["radii"].numpy(), d["radii"])
+    np.testing.assert_allclose(out["scales"].detach().numpy(), d["scales_out"], rtol=1e-6)
+    _loss(out, d).backward()
+    np.testing.assert_allclose(out["viewspace_points"].grad.numpy(), d["vsp_grad"],
+                               atol=1e-5 * max(1.0, np.abs(d["vsp_grad"]).max()))
+    for m, leaves in enumerate(models):
+        for leaf, t in zip(LEAVES, leaves):
+            ref = d[f"g{m}{leaf}"]
+            np.testing.assert_allclose(t.grad.numpy(), ref, atol=1e-5 * max(1.0, float(np.abs(ref).max())),
+                                       err_msg=f"model {m} {leaf}")
+
+
+@pytest.mark.gpu
+def test_fused_scene_render_vs_reference_fixture(built_lib):
+    """HIP fused path (raw leaves of three models straight into K1 / K8) == the reference's scene_render."""
+    from dreamscene_amd import scene
+    d = load("scene_render.npz")
+    dev = torch.device("cuda:0")
+    models = _models_from_fixture(d, device=dev)
+    cam = _cam_from_fixture(d)
+    out = scene.scene_render(models, cam, torch.tensor(d["bg"], device=dev), int(d["active_sh_degree"]), test=True)
+    assert sorted(out.keys()) == list(d["keys"])
+    np.testing.assert_allclose(out["image"].detach().cpu().numpy(), d["image"], atol=1e-5)
+    np.testing.assert_allclose(out["alpha"].detach().cpu().numpy(), d["alpha"], atol=1e-5)
+    np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), d["depth"], atol=2e-4)
+    np.testing.assert_allclose(out["scales"].detach().cpu().numpy(), d["scales_out"], rtol=4e-7)   # expf: <= 2 ulp
+    assert np.mean(out["radii"].cpu().numpy() != d["radii"]) <= 2e-3      # 1-ulp scales may move a ceil()
+    _loss(out, d, dev).backward()
+    vg = out["viewspace_points"].grad.cpu().numpy()
+    np.testing.assert_allclose(vg, d["vsp_grad"], atol=3e-3 * max(1.0, np.abs(d["vsp_grad"]).max()))
+    for m, leaves in enumerate(models):
+        for leaf, t in zip(LEAVES, leaves):
+            ref = d[f"g{m}{leaf}"]
+            # disp post-processing in fp32 vs the float64 capture: 1e-3 relative on the largest entries (as in the
+            # object_render plumbing test)
+            np.testing.assert_allclose(t.grad.cpu().numpy(), ref, atol=3e-3 * max(1.0, float(np.abs(ref).max())),
+                                       err_msg=f"model {m} {leaf}")
+
+
+def _random_models(sizes, K, seed, dev):
+    from dreamscene_amd import synth
+    models = []
+    for mi, n in enumerate(sizes):
+        g = synth.g_object(max(n, 64), seed=seed + mi, K=K)     # (kNN scales need neighbours)
+        g = {k: v[:n] for k, v in g.items()}
+        sc = (g["scales"] * 6).astype(np.float32)
+        op = np.clip(g["opacities"], 1e-4, 1 - 1e-4)
+        off = np.array([[0.4 * (mi - 1), 0.15 * mi, 0.0]], dtype=np.float32)
+        raw = (g["means3D"] * 0.8 + off, np.log(sc), g["rotations"] * (0.6 + 0.5 * mi), np.log(op / (1 - op)),
+               g["shs"][:, :1, :], g["shs"][:, 1:, :])
+        models.append(tuple(torch.tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev, requires_grad=True)
+                            for a in raw))
+    return models
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,D,noise", [(16, 3, True), (4, 1, True), (16, 2, False), (1, 0, True)])
+def test_fused_scene_vs_oracle(built_lib, K, D, noise):
+    """Raw forward / backward of the fused path against the C oracle fed with the oracle glue's activations.
+    Integer artefacts are compared bit-exactly by giving the oracle the activated values the kernel exported
+    (exp / sigmoid differ by an ulp between libm and the GPU); the activations themselves are checked to 2 ulp."""
+    from dreamscene_amd import rasterizer as R
+    from oracle import c_oracle as CO, scene_oracle as SO
+    from tests.util import oracle_view, settings_for, tol_ok
+    from dreamscene_amd import synth
+    dev = torch.device("cuda:0")
+    sizes = [257, 0, 700, 64, 1]          # a block boundary, an empty model, a one-Gaussian model
+    H, W = 112, 96
+    models = _random_models(sizes, K, 21, dev)
+    P = sum(sizes)
+    cam = synth.object_cameras(2, H, W, radius=3.0)[1]
+    bg = [0.3, 0.6, 0.9]
+    s = settings_for(cam, bg, D, dev)
+    gen = torch.Generator().manual_seed(5)
+    sn = torch.randn((P, 3), generator=gen).to(dev) if noise else None
+    hn = torch.randn((P, K, 3), generator=gen).to(dev) if noise else None
+    out, st = R.rasterize_forward_raw(s, None, None, None, None, None, None, None,
+                                      scene=dict(models=models, scale_noise=sn, sh_noise=hn, want_act=True))
+    # --- activations vs the oracle glue (CPU torch)
+    cpu_models = [tuple(t.detach().cpu().requires_grad_(True) for t in m) for m in models]
+    a = SO.activate_and_cat(cpu_models, None if sn is None else sn.cpu(), None if hn is None else hn.cpu())
+    np.testing.assert_allclose(out["act_scales"].cpu().numpy(), a["scales"].detach().numpy(), rtol=4e-7)
+    np.testing.assert_allclose(out["act_rotations"].cpu().numpy(), a["rotations"].detach().numpy(), rtol=0, atol=2.5e-7)
+    np.testing.assert_allclose(out["act_opacities"].cpu().numpy(), a["opacities"].detach().numpy().reshape(-1), rtol=4e-7)
+    # --- the rasterizer proper: oracle on the exported activations => bit-exact integer artefacts
+    act = dict(means3D=a["means3D"].detach().numpy(), shs=a["shs"].detach().numpy(),
+               scales=out["act_scales"].cpu().numpy(), rotations=out["act_rotations"].cpu().numpy(),
+               opacities=out["act_opacities"].cpu().numpy())
+    ov = oracle_view(CO, cam, P, K, D, bg)
+    ref = CO.forward(ov, act["means3D"], act["opacities"], shs=act["shs"], scales=act["scales"],
+                     rotations=act["rotations"])
+    assert np.array_equal(out["radii"].cpu().numpy(), ref["radii"])
+    assert np.array_equal(out["point_list"].cpu().numpy(), ref["point_list"][:out["N"]])
+    assert tol_ok(out["color"].cpu().numpy(), ref["image"])
+    assert tol_ok(out["depth_alpha"].cpu().numpy(), ref["depth_alpha"])
+    # --- backward: C oracle w.r.t. the activated inputs, then autograd through the oracle glue to the raw leaves
+    gi_np, gda_np = synth.upstream_grads(H, W, seed=4)
+    gs = (torch.randn((P, 3), generator=gen) * 1e-3)
+    o = R.rasterize_backward_raw(st, torch.tensor(gi_np, device=dev), torch.tensor(gda_np, device=dev),
+                                 dL_dscales_out=gs.to(dev))
+    rb = CO.backward(ov, ref, gi_np, gda_np, act["means3D"], shs=act["shs"], scales=act["scales"],
+                     rotations=act["rotations"])
+    torch.autograd.backward(
+        [a["means3D"], a["scales"], a["rotations"], a["opacities"], a["shs"]],
+        [torch.tensor(rb["dL_dmeans3D"]), torch.tensor(rb["dL_dscales"]) + gs, torch.tensor(rb["dL_drotations"]),
+         torch.tensor(rb["dL_dopacity"]).reshape(a["opacities"].shape), torch.tensor(rb["dL_dshs"])])
+    assert tol_ok(o["dL_dmeans2D"].cpu().numpy(), rb["dL_dmeans2D"])
+    for m, (hip_row, cpu_row) in enumerate(zip(o["model_grads"], cpu_models)):
+        for leaf, hg, ct in zip(LEAVES, hip_row, cpu_row):
+            if ct.numel() == 0:
+                continue
+            refg = ct.grad.numpy() if ct.grad is not None else np.zeros(ct.shape, np.float32)
+            assert tol_ok(hg.cpu().numpy(), refg), f"model {m} {leaf}: {np.abs(hg.cpu().numpy() - refg).max()}"
+
+
+@pytest.mark.gpu
+def test_fused_scene_accumulates_into_model_buffers(built_lib):
+    """MODEL_GRAD_BUFFERS: two views added on the device == sum of the two separately computed gradients; the fused
+    autograd path equals the unfused one (torch activations + cat + GaussianRasterizer) on the same leaves."""
+    from dreamscene_amd import scene, synth
+    from dreamscene_amd.rasterizer import GaussianRasterizer
+    from oracle import scene_oracle as SO      # glue only (torch ops on the GPU tensors), as the reference would run it
+    from tests.util import settings_for, tol_ok
+    dev = torch.device("cuda:0")
+    K, D, H, W = 16, 3, 96, 96
+    models = _random_models([300, 500], K, 31, dev)
+    P = 800
+    cams = synth.object_cameras(3, H, W, radius=3.0)
+    gi_np, gda_np = synth.upstream_grads(H, W, seed=2)
+    gi, gda = torch.tensor(gi_np, device=dev), torch.tensor(gda_np, device=dev)
+
+    def fused(cam, bufs):
+        scene.MODEL_GRAD_BUFFERS = bufs
+        try:
+            s = settings_for(cam, [1, 1, 1], D, dev)
+            m2d = torch.zeros((P, 3), device=dev, requires_grad=True)
+            img, radii, da, scales = scene.rasterize_models(s, models, m2d)
+            leaves = [t for m in models for t in m]
+            loss = (img * gi).sum() + (da * gda).sum() + 0.01 * scales.mean()
+            if bufs is None:
+                return torch.autograd.grad(loss, leaves)
+            loss.backward(inputs=[m2d])
+            return None
+        finally:
+            scene.MODEL_GRAD_BUFFERS = None
+
+    g1, g2 = fused(cams[1], None), fused(cams[2], None)
+    bufs = [tuple(torch.zeros_like(t) for t in m) for m in models]
+    fused(cams[1], bufs)
+    fused(cams[2], bufs)
+    flat = [t for row in bufs for t in row]
+    for a_, b_, acc in zip(g1, g2, flat):
+        assert tol_ok(acc.cpu().numpy(), (a_ + b_).cpu().numpy())
+    # unfused reference on the GPU: torch glue + the drop-in rasterizer
+    s = settings_for(cams[1], [1, 1, 1], D, dev)
+    a = SO.activate_and_cat(models)
+    m2d = torch.zeros((P, 3), device=dev, requires_grad=True)
+    img, radii, da = GaussianRasterizer(s)(means3D=a["means3D"], means2D=m2d, shs=a["shs"], opacities=a["opacities"],
+                                            scales=a["scales"], rotations=a["rotations"])
+    loss = (img * gi).sum() + (da * gda).sum() + 0.01 * a["scales"].mean()
+    gu = torch.autograd.grad(loss, [t for m in models for t in m])
+    for x, y in zip(g1, gu):
+        assert tol_ok(x.cpu().numpy(), y.cpu().numpy(), atol=2e-5)
