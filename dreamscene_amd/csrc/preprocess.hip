@@ -285,15 +285,52 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int
     if ((vis >> g) & 1ull) lds_wave[g * lds_stride + o0 + o] = src[f];
   }
 }
-__device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, int F, int o0, int lds_stride, int n_valid,
+// 16-byte vector with dword alignment: rows of 3K-3 floats start on 4-byte boundaries; gfx950 global loads / stores of
+// dwordx4 only need dword alignment
+typedef float gsr_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// One lane's row of F floats straight from global memory (dst may be registers or the lane's LDS row).
+template <int F>
+__device__ __forceinline__ void load_row(const float* __restrict__ src, float* dst) {
+#pragma unroll
+  for (int q = 0; q + 3 < F; q += 4) {
+    const gsr_f4u t = *reinterpret_cast<const gsr_f4u*>(src + q);
+    dst[q] = t.x; dst[q + 1] = t.y; dst[q + 2] = t.z; dst[q + 3] = t.w;
+  }
+#pragma unroll
+  for (int q = F & ~3; q < F; ++q) dst[q] = src[q];
+}
+
+// LDS rows (float offset o0, F floats each) -> the wave's contiguous [n_valid, F] block in global memory, 16 bytes
+// per lane and step. F == 0: runtime row length Fr. Rows of culled Gaussians hold zeros (the caller cleared them), so
+// accumulating adds nothing there; 16-byte pieces that only cover culled rows are skipped when accumulating.
+template <int F>
+__device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, int Fr, int o0, int lds_stride, int n_valid,
                                                const float* lds_wave, bool accumulate, unsigned long long vis) {
-  const int total = n_valid * F;
+  const int FF = F > 0 ? F : Fr;
+  const int total = n_valid * FF;
   const int lane = gsr_lane();
-  for (int f = lane; f < total; f += 64) {
-    const int g = f / F, o = f - g * F;
-    const float e = lds_wave[g * lds_stride + o0 + o];
-    if (!accumulate) dst[f] = e;
-    else if ((vis >> g) & 1ull) dst[f] += e;
+  for (int q = lane * 4; q < total; q += 64 * 4) {
+    const int g0 = q / FF, g1 = min(n_valid - 1, (q + 3) / FF);
+    if (accumulate && !(((vis >> g0) | (vis >> g1)) & 1ull)) continue;
+    float e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int f = q + k;
+      const int g = f / FF, o = f - g * FF;
+      e[k] = (f < total) ? lds_wave[g * lds_stride + o0 + o] : 0.f;
+    }
+    if (q + 3 < total) {
+      float4 o = make_float4(e[0], e[1], e[2], e[3]);
+      if (accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(dst + q);
+        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+      }
+      *reinterpret_cast<float4*>(dst + q) = o;
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (q + k < total) dst[q + k] = accumulate ? dst[q + k] + e[k] : e[k];
+    }
   }
 }
 
@@ -443,7 +480,30 @@ k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restr
 
   // ---- colour
   float rgb[3] = {0.f, 0.f, 0.f};
-  if (!SCENE && g.shs && KT > 0) {
+  if constexpr (SCENE && KT > 0) {
+    // raw leaves, compile-time K: each lane pulls its features_dc / features_rest rows straight into registers
+    if (vis) {
+      constexpr int F = 3 * KT;
+      float shr[F];
+      load_row<3>(sc.dc[rw.m] + row * 3, shr);
+      if constexpr (KT > 1) load_row<F - 3>(sc.rest[rw.m] + row * (F - 3), shr + 3);
+      if (sc.sh_noise) {
+        float nz[F];
+        load_row<F>(sc.sh_noise + (size_t)i * F, nz);
+#pragma unroll
+        for (int k = 0; k < F; ++k) shr[k] = shr[k] + nz[k] * (kSqrtPoint2 * shr[k]);
+      }
+      float dx = px - vc.cam[0], dy = py - vc.cam[1], dz = pz - vc.cam[2];
+      const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+      dx = dx / len; dy = dy / len; dz = dz / len;
+      float b[16];
+      sh_basis(v.sh_degree, dx, dy, dz, b);
+      float acc[3];
+      sh_colour_n<KT>(v.sh_degree, shr, b, acc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
+    }
+  } else if (!SCENE && g.shs && KT > 0) {
     // compile-time SH stride: every lane pulls its own 12*KT-byte row straight into registers (measured faster
     // than the coalesced-load + LDS-transpose path K8 uses for its read-modify-write of the same block: the rows
     // of a wave are contiguous, so L1/TA serve the 16-byte pieces of one line to successive loads)
@@ -572,12 +632,19 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
     float* lw = lds + wave * (64 * stride);
     float* sh = lw + lane * stride;
     if constexpr (SCENE) {
-      if (vmask) {
-        stage_rows_in(sc.dc[rw.m] + wave_first * 3, 3, 0, stride, n_valid, vmask, lw);
-        if (K > 1) stage_rows_in(sc.rest[rw.m] + wave_first * (3 * K - 3), 3 * K - 3, 3, stride, n_valid, vmask, lw);
+      if constexpr (KT > 0) {
+        if (vis) {   // each lane parks its own rows in its LDS row
+          load_row<3>(sc.dc[rw.m] + row * 3, sh);
+          if constexpr (KT > 1) load_row<3 * KT - 3>(sc.rest[rw.m] + row * (3 * KT - 3), sh + 3);
+        }
+      } else {
+        if (vmask) {
+          stage_rows_in(sc.dc[rw.m] + wave_first * 3, 3, 0, stride, n_valid, vmask, lw);
+          if (K > 1) stage_rows_in(sc.rest[rw.m] + wave_first * (3 * K - 3), 3 * K - 3, 3, stride, n_valid, vmask, lw);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (sc.sh_noise && vis) {   // the augmented coefficients K1 saw
         const float* nz = sc.sh_noise + (size_t)i * (3 * K);
         for (int k = 0; k < 3 * K; ++k) sh[k] = sh[k] + nz[k] * (kSqrtPoint2 * sh[k]);
@@ -670,9 +737,11 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
     // accumulating: a wave without a visible Gaussian adds nothing to its rows
     if constexpr (SCENE) {
       if (!(out.accumulate && vmask == 0ull)) {
-        if (sg.dc[rw.m]) stage_rows_out(sg.dc[rw.m] + wave_first * 3, 3, 0, stride, n_valid, lw, out.accumulate != 0, vmask);
+        if (sg.dc[rw.m])
+          stage_rows_out<3>(sg.dc[rw.m] + wave_first * 3, 3, 0, stride, n_valid, lw, out.accumulate != 0, vmask);
         if (K > 1 && sg.rest[rw.m])
-          stage_rows_out(sg.rest[rw.m] + wave_first * (3 * K - 3), 3 * K - 3, 3, stride, n_valid, lw, out.accumulate != 0, vmask);
+          stage_rows_out<(KT > 1 ? 3 * KT - 3 : 0)>(sg.rest[rw.m] + wave_first * (3 * K - 3), 3 * K - 3, 3, stride, n_valid,
+                                                   lw, out.accumulate != 0, vmask);
       }
     } else if (out.dL_dshs && !(out.accumulate && vmask == 0ull))
       stage_sh_out<KT>(out.dL_dshs, wave_first, n_valid, K, lw, out.accumulate != 0);
@@ -975,8 +1044,17 @@ int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom
     SceneTab t; SceneGradTab gt;
     const uint32_t nbs = scene_tables(*g.scene, nullptr, t, gt);
     const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
-    hipLaunchKernelGGL((k_preprocess<0, true, SceneTab>), dim3(nbs), dim3(256), lds, stream, v, g, t, geom.splat,
-                       geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P), gsr_tile_rects(geom, v.P));
+#define GSR_LAUNCH_K1S(KT)                                                                                         \
+  hipLaunchKernelGGL((k_preprocess<KT, true, SceneTab>), dim3(nbs), dim3(256), (KT) > 0 ? 0 : lds, stream, v, g, t, \
+                     geom.splat, geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P), gsr_tile_rects(geom, v.P))
+    switch (v.sh_stride) {
+      case 16: GSR_LAUNCH_K1S(16); break;
+      case 9: GSR_LAUNCH_K1S(9); break;
+      case 4: GSR_LAUNCH_K1S(4); break;
+      case 1: GSR_LAUNCH_K1S(1); break;
+      default: GSR_LAUNCH_K1S(0); break;
+    }
+#undef GSR_LAUNCH_K1S
     GSR_HIP(hipGetLastError());
     return GSR_OK;
   }
@@ -1004,8 +1082,17 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const Gsr
     SceneTab t; SceneGradTab gt;
     const uint32_t nbs = scene_tables(*g.scene, out.scene, t, gt);
     const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
-    hipLaunchKernelGGL((k_preprocess_bwd<0, true, SceneTab, SceneGradTab>), dim3(nbs), dim3(256), lds, stream, v, g, t,
-                       gt, geom.radii, out.partials, out);
+#define GSR_LAUNCH_K8S(KT)                                                                                         \
+  hipLaunchKernelGGL((k_preprocess_bwd<KT, true, SceneTab, SceneGradTab>), dim3(nbs), dim3(256), lds, stream, v, g, t, \
+                     gt, geom.radii, out.partials, out)
+    switch (v.sh_stride) {
+      case 16: GSR_LAUNCH_K8S(16); break;
+      case 9: GSR_LAUNCH_K8S(9); break;
+      case 4: GSR_LAUNCH_K8S(4); break;
+      case 1: GSR_LAUNCH_K8S(1); break;
+      default: GSR_LAUNCH_K8S(0); break;
+    }
+#undef GSR_LAUNCH_K8S
     GSR_HIP(hipGetLastError());
     return GSR_OK;
   }
