@@ -73,11 +73,21 @@ class GsrGrads(C.Structure):
     _fields_ = [("dL_dmeans3D", _f), ("dL_dmeans2D", _f), ("dL_dopacities", _f), ("dL_dshs", _f), ("dL_dcolors", _f),
                 ("dL_dscales", _f), ("dL_drotations", _f), ("dL_dcov3D", _f), ("dL_dview", _f), ("dL_dproj", _f),
                 ("dL_dcampos", _f), ("partials", _f), ("accumulate", C.c_int32), ("reserved_", C.c_int32),
+                ("stat_max_radii2D", _f), ("stat_xyz_gradient_accum", _f), ("stat_denom", _f),
                 ("scene", C.POINTER(GsrSceneGrads))]
 
 
+class GsrAdamGroup(C.Structure):
+    _fields_ = [("param", _f), ("grad", _f), ("exp_avg", _f), ("exp_avg_sq", _f), ("numel", C.c_int64),
+                ("lr", C.c_float), ("reserved_", C.c_float)]
+
+
+GSR_MAX_ADAM_GROUPS = 32
+
 # every symbol include/gsrast.h declares: (name, restype, argtypes)
 SYMBOLS = [
+    ("gsr_adam_step", C.c_int, [C.POINTER(GsrAdamGroup), C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                C.c_int32, C.c_void_p]),
     ("gsr_version", C.c_int, []),
     ("gsr_strerror", C.c_char_p, [C.c_int]),
     ("gsr_last_hip_error", C.c_int, []),

@@ -21,6 +21,7 @@ SOURCES = {
     "binning.hip": ["-ffp-contract=off"],
     "render.hip": [],
     "knn.hip": ["-ffp-contract=off"],
+    "optim.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-fno-gpu-rdc",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]

@@ -194,6 +194,11 @@ int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, c
   if (!ig->dL_dcolor || !ig->dL_ddepth_alpha || !img->final_T || !img->n_contrib || !b->ranges) return GSR_EINVAL;
   if (!b->tile_work || !img->tile_depth || !img->ckpt || !img->color || !img->depth_alpha) return GSR_EINVAL;
   if (!out->partials || !aligned16(out->partials)) return GSR_EINVAL;
+  {
+    const int n_stat = (out->stat_max_radii2D != nullptr) + (out->stat_xyz_gradient_accum != nullptr) +
+                       (out->stat_denom != nullptr);
+    if (n_stat != 0 && n_stat != 3) return GSR_EINVAL;
+  }
   if (g->scene) {
     if (!out->scene || !out->dL_dmeans2D) return GSR_EINVAL;
     if (out->dL_dmeans3D || out->dL_dopacities || out->dL_dshs || out->dL_dcolors || out->dL_dscales ||

@@ -895,6 +895,11 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
     }
   }
 
+  if (vis && out.stat_denom) {   // densification statistics of this view (gs_renderer.py:1061-1065)
+    out.stat_xyz_gradient_accum[i] += sqrtf(gndx * gndx + gndy * gndy);
+    out.stat_denom[i] += 1.0f;
+    out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)radii[i]);
+  }
   if constexpr (SCENE) {
     if (rw.ok) {
       out.dL_dmeans2D[3 * i] = gndx; out.dL_dmeans2D[3 * i + 1] = gndy; out.dL_dmeans2D[3 * i + 2] = 0.f;

@@ -46,6 +46,10 @@ PROFILE: Optional[L.Profile] = None
 # optional multiview.GradArena: when set, the autograd backward writes the parameter gradients of the view
 # straight into the arena's flat buffer (zero-copy hand-off to the RCCL all-reduce) and returns views of it
 GRAD_ARENA = None
+# Optional (max_radii2D, xyz_gradient_accum, denom) fp32 tensors with P elements: the backward of the NEXT rasterized
+# view updates them for its visible Gaussians inside K8 (what the trainers do with radii / visibility_filter /
+# viewspace_points.grad after backward, object_trainer.py:386-390). Set it for the view whose statistics count.
+DENSIFY_STATS = None
 # with a GRAD_ARENA: False = this view's gradients overwrite the arena, True = they are ADDED to it on the device
 # (sum over the views of one optimizer step before a single all-reduce)
 ACCUMULATE = False
@@ -344,6 +348,17 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     return out, st
 
 
+def _bind_stats(gr, P: int, dev) -> None:
+    if DENSIFY_STATS is None:
+        return
+    ptrs = []
+    for t in DENSIFY_STATS:
+        if t.numel() != P or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise ValueError("DENSIFY_STATS tensors must be contiguous fp32 with P elements on the view's device")
+        ptrs.append(t.data_ptr())
+    gr.stat_max_radii2D, gr.stat_xyz_gradient_accum, gr.stat_denom = ptrs
+
+
 def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, model_grads, accumulate: bool,
                     dL_dscales_out=None) -> dict:
     """Backward of a scene forward: the parameter gradients are written (or, with accumulate, ADDED) straight into
@@ -385,6 +400,7 @@ def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, mod
     gr.accumulate = int(bool(accumulate))
     dL_dscales_out = _prep(dL_dscales_out, "dL_dscales_out", dev)
     sg.dL_dscales_out = _ptr(dL_dscales_out)
+    _bind_stats(gr, P, dev)
     gr.scene = C.pointer(sg)
     ig = L.GsrImageGrads()
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
@@ -430,6 +446,7 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
         setattr(gr, k, _ptr(t))
     gr.partials = partials.data_ptr()
     gr.accumulate = int(bool(accumulate and arena is not None))
+    _bind_stats(gr, P, dev)
     ig = L.GsrImageGrads()
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
     stream = torch.cuda.current_stream(dev).cuda_stream

@@ -192,6 +192,13 @@ typedef struct GsrGrads {
                            hold (device-side sum over the views of one optimizer step). dL_dmeans2D is per view
                            and always overwritten; dL_dview/proj/campos always accumulate                     */
   int32_t reserved_;
+  /* SURVEY.md section 8(f) rank 3, densification statistics fused into K8 (all three NULL or all three set, [P] fp32):
+   * what the trainers do after backward with the view's radii / visibility_filter / viewspace_points.grad
+   * (object_trainer.py:386-390, gs_renderer.py:1061-1065), for the visible Gaussians (radii > 0) of THIS view:
+   *   max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += ||dL_dmeans2D[:2]||; denom += 1              */
+  float* stat_max_radii2D;
+  float* stat_xyz_gradient_accum;
+  float* stat_denom;
   const GsrSceneGrads* scene; /* host pointer; required iff GsrGaussians.scene was given: the parameter gradients go
                                  to the models' raw leaves and dL_dmeans3D/scales/rotations/opacities/shs must be NULL */
 } GsrGrads;
@@ -244,6 +251,24 @@ int gsr_backward(const GsrView*, const GsrGaussians*, const GsrGeom*, const GsrB
  * gsr_knn_scratch_bytes(n) bytes, 256-byte aligned. Enqueued on `stream`, no host synchronisation. */
 size_t gsr_knn_scratch_bytes(int32_t n);
 int gsr_knn_mean_dist2(const float* points, int32_t n, float* out, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- the optimizer of the post-raster epilogue ----------------------------------
+ * One launch of torch.optim.Adam's update (no amsgrad / weight decay) over all parameter groups of a model
+ * (gs_renderer.py:615-653: Adam(l, lr=0.0, eps=1e-15), six groups with their own lr). All pointers are device fp32,
+ * 16-byte aligned; `step` is the 1-based step count (bias correction); zero_grad != 0 clears the gradients in the same
+ * pass. The densification statistics of that epilogue are fused into K8 (GsrGrads.stat_*). */
+#define GSR_MAX_ADAM_GROUPS 32
+typedef struct GsrAdamGroup {
+  float* param;        /* [numel] updated in place        */
+  float* grad;         /* [numel] (cleared if zero_grad)   */
+  float* exp_avg;      /* [numel] first moment             */
+  float* exp_avg_sq;   /* [numel] second moment            */
+  int64_t numel;
+  float lr;
+  float reserved_;
+} GsrAdamGroup;
+int gsr_adam_step(const GsrAdamGroup* groups, int32_t n_groups, int32_t step, double beta1, double beta2, double eps,
+                  int32_t zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

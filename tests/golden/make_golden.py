@@ -9,6 +9,7 @@ plain input/output arrays. What each fixture pins:
   projection.npz     geom_transform_points (+1e-7 on w)       utils/graphics_utils.py:29-36
   scene_render.npz   the reference's UNCHANGED SceneGaussian.scene_render (scene_gaussian.py:673-893) over the same
                      oracle, three models, test=True: activation + torch.cat glue and gradient landing sites
+  prune.npz          calculate_v_imp_score + GaussianModel.prune_gaussians' mask (importance filtering threshold)
   object_render.npz  the reference's UNCHANGED SceneGaussian.object_render (scene_gaussian.py:895-1044) driven over
                      this repo's CPU oracle registered as `diff_gaussian_rasterization` (BASELINE.json config 1,
                      "plumbing"): settings construction, output dict, disp post-processing, where .grad lands.
@@ -233,6 +234,16 @@ def main():
             rec[f"m{mi}{leaf}"] = getattr(m, leaf).detach().numpy()
             rec[f"g{mi}{leaf}"] = getattr(m, leaf).grad.numpy()
     np.savez(os.path.join(HERE, "scene_render.npz"), **rec)
+    # ---- 3D Gaussian filtering threshold: calculate_v_imp_score (scene_gaussian.py:1046-1061) + the mask of
+    # GaussianModel.prune_gaussians (gs_renderer.py:1082-1087), captured by intercepting prune_points
+    pm = models[1]
+    imp = torch.tensor(rng.gamma(2.0, 30.0, size=pm._xyz.shape[0]).astype(np.float32))
+    captured = {}
+    pm.prune_points = lambda mask: captured.setdefault("mask", mask.clone())
+    v_list = SG.calculate_v_imp_score(pm, imp, 0.1)
+    pm.prune_gaussians(0.8 * 0.5, v_list)
+    np.savez(os.path.join(HERE, "prune.npz"), scaling=pm._scaling.detach().numpy(), imp=imp.numpy(), v_pow=np.float64(0.1),
+             percent=np.float64(0.8 * 0.5), v_list=v_list.detach().numpy(), mask=captured["mask"].numpy())
     print("fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
