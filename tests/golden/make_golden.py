@@ -9,6 +9,7 @@ plain input/output arrays. What each fixture pins:
   projection.npz     geom_transform_points (+1e-7 on w)       utils/graphics_utils.py:29-36
   scene_render.npz   the reference's UNCHANGED SceneGaussian.scene_render (scene_gaussian.py:673-893) over the same
                      oracle, three models, test=True: activation + torch.cat glue and gradient landing sites
+  ply_elements.npz   the vertex table GaussianModel.save_ply (gs_renderer.py:728-744) hands to plyfile
   prune.npz          calculate_v_imp_score + GaussianModel.prune_gaussians' mask (importance filtering threshold)
   object_render.npz  the reference's UNCHANGED SceneGaussian.object_render (scene_gaussian.py:895-1044) driven over
                      this repo's CPU oracle registered as `diff_gaussian_rasterization` (BASELINE.json config 1,
@@ -244,6 +245,40 @@ def main():
     pm.prune_gaussians(0.8 * 0.5, v_list)
     np.savez(os.path.join(HERE, "prune.npz"), scaling=pm._scaling.detach().numpy(), imp=imp.numpy(), v_pow=np.float64(0.1),
              percent=np.float64(0.8 * 0.5), v_list=v_list.detach().numpy(), mask=captured["mask"].numpy())
+    # ---- PLY wire format: what GaussianModel.save_ply (gs_renderer.py:728-744) hands to plyfile -- the structured
+    # vertex array (property names in order, all f4) -- captured at PlyElement.describe; plyfile itself is not in the image
+    import gs_renderer as GR
+    cap = {}
+
+    class _El:
+        @staticmethod
+        def describe(elements, name):
+            cap["elements"], cap["name"] = elements.copy(), name
+            return None
+
+    class _Pd:
+        def __init__(self, els):
+            pass
+
+        def write(self, path):
+            cap["path"] = path
+    old = GR.PlyElement, GR.PlyData
+    GR.PlyElement, GR.PlyData = _El, _Pd
+    try:
+        models[2].save_ply(os.path.join(HERE, "_unused", "m.ply"))
+    finally:
+        GR.PlyElement, GR.PlyData = old
+        try:
+            os.rmdir(os.path.join(HERE, "_unused"))
+        except OSError:
+            pass
+    el = cap["elements"]
+    m2 = models[2]
+    np.savez(os.path.join(HERE, "ply_elements.npz"), names=np.array(el.dtype.names), element=np.array(cap["name"]),
+             kinds=np.array([el.dtype[n].str for n in el.dtype.names]),
+             table=np.stack([el[n] for n in el.dtype.names], axis=1),
+             **{leaf: getattr(m2, leaf).detach().numpy() for leaf in
+                ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")})
     print("fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
