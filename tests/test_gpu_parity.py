@@ -321,10 +321,11 @@ def test_state_is_freed_without_cyclic_gc(built_lib):
 
 
 @pytest.mark.parametrize("P,K,D,H,W", [(1, 16, 3, 32, 32), (255, 1, 0, 48, 64), (257, 9, 2, 64, 48), (513, 25, 3, 40, 40),
-                                       (300, 4, 1, 17, 250)])
+                                       (300, 4, 1, 17, 250), (700, 4, 1, 48, 4096), (700, 4, 1, 4090, 40)])
 def test_odd_sizes_and_sh_strides(built_lib, c_oracle, P, K, D, H, W):
     """Block-boundary Gaussian counts, every SH stride path (templated 1/4/9/16 and the generic stride), ragged
-    images: forward artefacts bit-exact, gradients within tolerance."""
+    images, the widest / tallest grids of the column binning path (256 tile columns / rows): forward artefacts
+    bit-exact, gradients within tolerance."""
     g, cam = small_scene(P=P, H=H, W=W, K=K, seed=100 + P)
     bg = np.array([0.5, 0.5, 0.5], np.float32)
     out, _ = _run_hip(g, cam, bg, D)
