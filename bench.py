@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--unbatched", action="store_true",
+                    help="render the views of a step one call at a time (GaussianRasterizer) instead of through "
+                         "GaussianRasterizerViews (same kernels; the depth sorts of all views share their launches)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +108,24 @@ def main():
     R.GRAD_ARENA = arena
     leaves = [params[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
 
+    from dreamscene_amd.views import GaussianRasterizerViews
+    rast_views = GaussianRasterizerViews([r.raster_settings for r in rasts])
+
+    def step_batched():
+        means2D = torch.zeros((V,) + tuple(params["means3D"].shape), device=dev, requires_grad=True)
+        outs = rast_views(means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
+                          opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"],
+                          cov3D_precomp=None)
+        R.ACCUMULATE = False             # view 0 overwrites the arena, views 1..V-1 are added on the device
+        grads = torch.autograd.grad([t for (img, _, da) in outs for t in (img, da)], leaves + [means2D], [gi, gda] * V)
+        multiview.allreduce_grads(arena)
+        img, radii, da = outs[0]
+        g0 = list(grads[:-1]) + [grads[-1][0]]
+        return (img, da, radii, g0)
+
     def step():
+        if V > 1 and not args.unbatched and not capture[0]:   # (the parity capture wants view 0's own gradients)
+            return step_batched()
         out0 = None
         for j, rast in enumerate(rasts):
             means2D = torch.zeros_like(params["means3D"], requires_grad=True)

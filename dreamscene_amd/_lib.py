@@ -103,6 +103,8 @@ SYMBOLS = [
                                       C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
     ("gsr_forward_project_async", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom),
                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("gsr_forward_project_batch", C.c_int, [C.c_int32, C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom),
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gsr_forward_render", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGeom), C.c_uint64, C.POINTER(GsrBinning),
                                      C.POINTER(GsrImages), C.c_void_p, C.c_void_p]),
     ("gsr_knn_scratch_bytes", C.c_size_t, [C.c_int32]),

@@ -6,8 +6,9 @@ thread_local int gsr_tls_hip_error = 0;
 // stage launchers (preprocess.hip, binning.hip, render.hip)
 int gsr_launch_preprocess(const GsrView&, const GsrGaussians&, GsrGeom&, hipStream_t);
 int gsr_launch_preprocess_bwd(const GsrView&, const GsrGaussians&, const GsrGeom&, const GsrGrads&, hipStream_t);
-int gsr_launch_depth_order(GsrGeom&, const GsrView&, uint64_t* n_pairs_dev, hipStream_t,
-                           GsrProfile*);
+int gsr_launch_depth_order(GsrGeom&, const GsrView&, hipStream_t, GsrProfile*, int batch, size_t bstride,
+                           uint64_t* n_pairs_all);
+uint64_t* gsr_pair_counts(const GsrGeom&, int32_t P);
 int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint64_t* n_dev, const uint64_t* n_dev_vis,
                        GsrBinning&, hipStream_t, GsrProfile*);
 int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, GsrImages&, hipStream_t);
@@ -114,11 +115,7 @@ int gsr_profile_collect(GsrProfile* p, double* ms, int64_t* counts) {
   return GSR_OK;
 }
 
-static uint64_t* n_pairs_device(const GsrGeom* geom, int32_t P) {
-  // the device-side u64 total lives right after the u32 offsets (block_offsets has nb+1 entries + 3 spare)
-  const uint32_t nb = gsr_num_blocks(P);
-  return reinterpret_cast<uint64_t*>(geom->block_offsets + ((nb + 1 + 1) & ~1u));
-}
+static uint64_t* n_pairs_device(const GsrGeom* geom, int32_t P) { return gsr_pair_counts(*geom, P); }
 
 static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geom, uint64_t* n_pairs_host,
                            void* stream_, GsrProfile* prof, bool sync) {
@@ -139,13 +136,55 @@ static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geo
     if (rc) return rc;
   }
   uint64_t* n_dev = n_pairs_device(geom, v->P);
-  rc = gsr_launch_depth_order(*geom, *v, n_dev, stream, prof);
+  rc = gsr_launch_depth_order(*geom, *v, stream, prof, 1, 0, nullptr);
   if (rc) return rc;
   GSR_HIP(hipMemcpyAsync(n_pairs_host, n_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   if (sync) {
     GSR_HIP(hipStreamSynchronize(stream));
     if (*n_pairs_host >= (1ull << 32)) return GSR_ECAPACITY;
   }
+  return GSR_OK;
+}
+
+int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGaussians* g, GsrGeom* geoms,
+                              uint64_t* n_pairs_pinned, void* stream_, GsrProfile* prof) {
+  if (n_views < 1 || n_views > GSR_MAX_BATCH_VIEWS || !views || !geoms || !n_pairs_pinned) return GSR_EINVAL;
+  const GsrView& v0 = views[0];
+  size_t bstride = 0;
+  for (int k = 0; k < n_views; ++k) {
+    int rc = check_view(&views[k]);
+    if (rc) return rc;
+    rc = check_gaussians(&views[k], g);
+    if (rc) return rc;
+    if (views[k].P != v0.P || views[k].image_height != v0.image_height || views[k].image_width != v0.image_width ||
+        views[k].sh_stride != v0.sh_stride)
+      return GSR_EINVAL;
+    const GsrGeom& ge = geoms[k];
+    n_pairs_pinned[k] = 0;
+    if (v0.P == 0) continue;
+    if (!ge.splat || !ge.radii || !ge.tiles_touched || !ge.block_offsets || !ge.scratch || !aligned16(ge.splat))
+      return GSR_EINVAL;
+    if (ge.scratch_bytes < gsr_project_scratch_bytes(v0.P)) return GSR_ESCRATCH;
+    if (k == 1) bstride = (size_t)((char*)ge.scratch - (char*)geoms[0].scratch);
+    if (k >= 1 && ((char*)ge.scratch != (char*)geoms[0].scratch + (size_t)k * bstride || bstride < geoms[0].scratch_bytes ||
+                   (bstride & 255u)))
+      return GSR_EINVAL;   // the views' projection scratch buffers must be equally spaced
+  }
+  if (v0.P == 0) return GSR_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  {
+    GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS);
+    for (int k = 0; k < n_views; ++k) {
+      const int rc = gsr_launch_preprocess(views[k], *g, geoms[k], stream);
+      if (rc) return rc;
+    }
+  }
+  uint64_t* n_all = n_pairs_device(&geoms[0], v0.P) + 2;   // spare words of view 0's count block
+  int rc = gsr_launch_depth_order(geoms[0], v0, stream, prof, n_views, bstride, n_all);
+  if (rc) return rc;
+  for (int k = 1; k < n_views; ++k)
+    geoms[k].sorted_idx = reinterpret_cast<uint32_t*>((char*)geoms[0].sorted_idx + (size_t)k * bstride);
+  GSR_HIP(hipMemcpyAsync(n_pairs_pinned, n_all, sizeof(uint64_t) * (size_t)n_views, hipMemcpyDeviceToHost, stream));
   return GSR_OK;
 }
 
@@ -168,6 +207,7 @@ int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, 
   if (!b->tile_work || !img->tile_depth || !img->ckpt) return GSR_EINVAL;
   if ((uint64_t)b->bwd_items_cap < n_pairs / 256 + gsr_num_tiles(v->image_height, v->image_width)) return GSR_EINVAL;
   if (n_pairs && (!b->point_list || !geom->splat)) return GSR_EINVAL;
+  if (v->P > 0 && (!geom->scratch || geom->scratch_bytes < gsr_project_scratch_bytes(v->P))) return GSR_ESCRATCH;
   if (n_pairs >= (1ull << 32)) return GSR_ECAPACITY;
   hipStream_t stream = (hipStream_t)stream_;
   if (v->P == 0) n_pairs = 0;

@@ -197,7 +197,9 @@ __device__ __forceinline__ uint32_t rect_h(uint32_t r) { return (r >> 24) + 1u; 
 __global__ void __launch_bounds__(256)
 k_col_hist(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sorted_idx,
            const uint32_t* __restrict__ rects, uint32_t* __restrict__ rect_sorted, const int gx, const uint32_t nrun,
-           uint32_t* __restrict__ hist1) {
+           uint32_t* __restrict__ hist1, size_t bstride) {
+  n_vis = batch_ptr(n_vis, bstride); sorted_idx = batch_ptr(sorted_idx, bstride); rects = batch_ptr(rects, bstride);
+  rect_sorted = batch_ptr(rect_sorted, bstride); hist1 = batch_ptr(hist1, bstride);
   __shared__ uint32_t bins[4][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -236,7 +238,8 @@ k_col_hist(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sort
 // colstart[0..gx] = exclusive scan of the column totals (saturating u32), *n_pairs = N (64-bit).
 __global__ void __launch_bounds__(256)
 k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restrict__ colstart,
-           uint64_t* __restrict__ n_pairs) {
+           uint64_t* __restrict__ n_pairs, size_t bstride, uint64_t* __restrict__ n_pairs_all) {
+  totals1 = batch_ptr(totals1, bstride); colstart = batch_ptr(colstart, bstride); n_pairs = batch_ptr(n_pairs, bstride);
   __shared__ uint64_t wtot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t x = tid < gx ? (uint64_t)totals1[tid] : 0ull;
@@ -256,6 +259,7 @@ k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restr
     const uint64_t n = woff + inc;
     colstart[gx] = n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n;
     *n_pairs = n;
+    if (n_pairs_all) n_pairs_all[blockIdx.y] = n;   // batched: the counts of all views side by side (one copy to the host)
   }
 }
 
@@ -500,7 +504,7 @@ static uint32_t col_runs(int32_t P) { return (uint32_t)(((P > 0 ? P : 1) + kColR
 extern "C" size_t gsr_project_scratch_bytes(int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
   return 5 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4) + align256(kRadix * 4) +
-         align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + align256(264 * 4) + 1024;
+         align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + align256(264 * 4) + 256 + 1024;
 }
 
 // Scratch of the binning stage: tile keys x2, one value ping buffer, histograms (the column path needs less).
@@ -513,6 +517,7 @@ extern "C" size_t gsr_sort_scratch_bytes(uint64_t n, uint32_t n_tiles) {
 
 struct ProjectScratch {
   uint32_t *k0, *k1, *v0, *v1, *hist, *totals, *rects, *hist1, *totals1, *colstart;
+  uint64_t* counts;   // [0] = N (pairs), [1] = visible Gaussians
 };
 static ProjectScratch carve_project(void* scratch, int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
@@ -527,39 +532,50 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
   s.rects = (uint32_t*)b; b += align256(m * 4);
   s.hist1 = (uint32_t*)b; b += align256((size_t)256 * col_runs((int32_t)m) * 4);
   s.totals1 = (uint32_t*)b; b += align256(256 * 4);
-  s.colstart = (uint32_t*)b;
+  s.colstart = (uint32_t*)b; b += align256(264 * 4);
+  s.counts = (uint64_t*)b;
   return s;
 }
 
 uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).k0; }
 uint32_t* gsr_tile_rects(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).rects; }
+// device words [0] = N (pairs), [1] = number of visible Gaussians; they live in the projection scratch
+uint64_t* gsr_pair_counts(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).counts; }
 
 // After K1 (which wrote the depth keys into scratch.k0): depth sort, depth-ordered counts, scan -> N.
-int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, uint64_t* n_pairs_dev, hipStream_t stream,
-                           GsrProfile* prof) {
+// batch > 1: `batch` views whose projection scratch buffers are `bstride` bytes apart (geom = the first view's) go
+// through every launch together (blockIdx.y = view); n_pairs_all (device, may be NULL) receives the N of all views.
+int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, GsrProfile* prof, int batch,
+                           size_t bstride, uint64_t* n_pairs_all) {
   const int32_t P = v.P;
   if (geom.scratch_bytes < gsr_project_scratch_bytes(P) || !geom.scratch) return GSR_ESCRATCH;
   ProjectScratch s = carve_project(geom.scratch, P);
-  uint64_t* n_vis_dev = n_pairs_dev + 1;     // number of visible Gaussians, next to the pair count (block_offsets tail)
+  uint64_t* n_pairs_dev = s.counts;
+  uint64_t* n_vis_dev = s.counts + 1;
+  const bool columns = use_columns(v.image_height, v.image_width, v.P);
+  if (batch > 1 && !columns) return GSR_EINVAL;
   int where;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
     where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
-                                        s.totals, stream);
+                                        s.totals, stream, batch, bstride);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SCAN);
     const uint32_t nb = gsr_num_blocks(P);
-    if (use_columns(v.image_height, v.image_width, v.P)) {
+    if (columns) {
       const int gx = (v.image_width + GSR_TILE - 1) / GSR_TILE;
       uint32_t* rect_sorted = where ? s.k0 : s.k1;   // the key buffer the sort result is NOT in
       const uint32_t nrun = col_runs(P);
-      hipLaunchKernelGGL(k_col_hist, dim3(nb), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx, s.rects, rect_sorted, gx,
-                         nrun, s.hist1);
-      hipLaunchKernelGGL(k_radix_scan, dim3(gx), dim3(256), 0, stream, s.hist1, nrun, s.totals1, (const uint64_t*)n_vis_dev, (uint32_t)kColRun);
-      hipLaunchKernelGGL(k_col_plan, dim3(1), dim3(256), 0, stream, s.totals1, gx, s.colstart, n_pairs_dev);
+      const uint32_t nby = (uint32_t)batch;
+      hipLaunchKernelGGL(k_col_hist, dim3(nb, nby), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx, s.rects, rect_sorted,
+                         gx, nrun, s.hist1, bstride);
+      hipLaunchKernelGGL(k_radix_scan, dim3(gx, nby), dim3(256), 0, stream, s.hist1, nrun, s.totals1,
+                         (const uint64_t*)n_vis_dev, (uint32_t)kColRun, bstride);
+      hipLaunchKernelGGL(k_col_plan, dim3(1, nby), dim3(256), 0, stream, s.totals1, gx, s.colstart, n_pairs_dev, bstride,
+                         n_pairs_all);
     } else {
       hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx,
                          geom.tiles_touched, geom.block_offsets);
@@ -597,7 +613,8 @@ static int launch_binning_columns(const GsrView& v, const GsrGeom& geom, uint64_
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
     hipLaunchKernelGGL(k_row_hist, dim3(nblk), dim3(kSortThreads), 0, stream, vals1, s.colstart, gx, cap, nbits, nblk,
                        hist);
-    hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u);
+    hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u,
+                       (size_t)0);
     hipLaunchKernelGGL(k_row_scatter, dim3(nblk), dim3(kSortThreads), 0, stream, vals1, b.point_list, s.colstart,
                        gx, gy, cap, nbits, nblk, hist, totals, b.ranges);
     GSR_HIP(hipGetLastError());
@@ -647,8 +664,8 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
   uint32_t* sorted_keys;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    const int where = radix_sort_u32<kItemsLarge>(keys_a, va, keys_b, vb, n_dev, cap, tile_bits, false, 0u, hist, totals,
-                                                   stream);
+    const int where = radix_sort_u32<kItemsLarge>(keys_a, va, keys_b, vb, n_dev, cap, tile_bits, false, nullptr, hist,
+                                                   totals, stream);
     sorted_keys = where ? keys_b : keys_a;
     GSR_HIP(hipGetLastError());
   }

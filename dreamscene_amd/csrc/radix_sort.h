@@ -11,6 +11,12 @@ constexpr int kItemsSmall = 4;    // ... for the P-sized depth sort: 4x more wor
 constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 
+// Batched launches (several views at once): blockIdx.y selects the view, whose buffers sit `bstride` bytes further.
+template <typename T>
+__device__ __forceinline__ T* batch_ptr(T* p, size_t bstride) {
+  return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.y * bstride) : p;
+}
+
 __device__ __forceinline__ uint64_t eff_count(const uint64_t* n_dev, uint64_t cap) {
   if (!n_dev) return cap;
   const uint64_t n = *n_dev;
@@ -42,7 +48,8 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
 template <int ITEMS, bool DROP>
 __global__ void __launch_bounds__(kSortThreads)
 k_radix_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev, uint64_t cap, int shift,
-             uint32_t nblk, uint32_t* __restrict__ hist) {
+             uint32_t nblk, uint32_t* __restrict__ hist, size_t bstride) {
+  keys = batch_ptr(keys, bstride); n_dev = batch_ptr(n_dev, bstride); hist = batch_ptr(hist, bstride);
   __shared__ uint32_t h[kRadix];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t n = eff_count(n_dev, cap);
@@ -69,7 +76,9 @@ k_radix_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_d
 // n_items (device, may be NULL): only the first ceil(*n_items / per_block) entries of a row are in use.
 __global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblk_stride,
                                                     uint32_t* __restrict__ totals,
-                                                    const uint64_t* __restrict__ n_items, uint32_t per_block) {
+                                                    const uint64_t* __restrict__ n_items, uint32_t per_block,
+                                                    size_t bstride) {
+  hist = batch_ptr(hist, bstride); totals = batch_ptr(totals, bstride); n_items = batch_ptr(n_items, bstride);
   uint32_t nblk = nblk_stride;
   if (n_items) {
     const uint64_t used = (*n_items + per_block - 1) / per_block;
@@ -121,7 +130,11 @@ __global__ void __launch_bounds__(kSortThreads)
 k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint64_t* __restrict__ n_dev,
                 uint64_t cap, int shift, uint32_t nblk, const uint32_t* __restrict__ hist,
-                const uint32_t* __restrict__ totals, uint64_t* __restrict__ n_out) {
+                const uint32_t* __restrict__ totals, uint64_t* __restrict__ n_out, size_t bstride) {
+  keys_in = batch_ptr(keys_in, bstride); vals_in = batch_ptr(vals_in, bstride);
+  keys_out = batch_ptr(keys_out, bstride); vals_out = batch_ptr(vals_out, bstride);
+  n_dev = batch_ptr(n_dev, bstride); hist = batch_ptr(hist, bstride); totals = batch_ptr(totals, bstride);
+  n_out = batch_ptr(n_out, bstride);
   __shared__ uint32_t wh[4][kRadix];   // running per-wave digit counters, then per-wave global bases
   __shared__ uint32_t dbase[kRadix];   // exclusive scan of the 256 digit totals
   __shared__ uint32_t wtot[4];
@@ -211,29 +224,33 @@ uint32_t sort_blocks(uint64_t n, int items) {
 // stores the number of survivors there; the remaining passes (and the caller) work on that many elements.
 template <int ITEMS>
 int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
-                   int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream) {
+                   int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream,
+                   int batch = 1, size_t bstride = 0) {
   const uint32_t nblk = sort_blocks(cap, ITEMS);
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
+  const dim3 grid(nblk, (uint32_t)batch), grid_scan(kRadix, (uint32_t)batch);
   uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
   for (int p = 0; p < passes; ++p) {
     const int shift = p * kRadixBits;
     if (iota && p == 0 && n_compact) {
-      hipLaunchKernelGGL((k_radix_hist<ITEMS, true>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift,
-                         nblk, hist);
-      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u);
-      hipLaunchKernelGGL((k_radix_scatter<true, ITEMS, true>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb, vb,
-                         n_dev, cap, shift, nblk, hist, totals, n_compact);
+      hipLaunchKernelGGL((k_radix_hist<ITEMS, true>), grid, dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift, nblk,
+                         hist, bstride);
+      hipLaunchKernelGGL(k_radix_scan, grid_scan, dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u,
+                         bstride);
+      hipLaunchKernelGGL((k_radix_scatter<true, ITEMS, true>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev,
+                         cap, shift, nblk, hist, totals, n_compact, bstride);
       n_dev = n_compact;
     } else {
-      hipLaunchKernelGGL((k_radix_hist<ITEMS, false>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift,
-                         nblk, hist);
-      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u);
+      hipLaunchKernelGGL((k_radix_hist<ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, n_dev, cap, shift, nblk,
+                         hist, bstride);
+      hipLaunchKernelGGL(k_radix_scan, grid_scan, dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u,
+                         bstride);
       if (iota && p == 0)
-        hipLaunchKernelGGL((k_radix_scatter<true, ITEMS, false>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb,
-                           vb, n_dev, cap, shift, nblk, hist, totals, (uint64_t*)nullptr);
+        hipLaunchKernelGGL((k_radix_scatter<true, ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb,
+                           n_dev, cap, shift, nblk, hist, totals, (uint64_t*)nullptr, bstride);
       else
-        hipLaunchKernelGGL((k_radix_scatter<false, ITEMS, false>), dim3(nblk), dim3(kSortThreads), 0, stream, ka, va, kb,
-                           vb, n_dev, cap, shift, nblk, hist, totals, (uint64_t*)nullptr);
+        hipLaunchKernelGGL((k_radix_scatter<false, ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb,
+                           n_dev, cap, shift, nblk, hist, totals, (uint64_t*)nullptr, bstride);
     }
     uint32_t* t = ka; ka = kb; kb = t;
     t = va; va = vb; vb = t;

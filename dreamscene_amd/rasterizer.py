@@ -97,7 +97,9 @@ class _Workspace:
         self.n_pinned = torch.zeros(1, dtype=torch.int64).pin_memory()
         self.stats_pinned = torch.zeros(2, dtype=torch.int32).pin_memory()   # [0]: non-empty tiles of the last view
         self.event = torch.cuda.Event()
+        self.batch_pinned = None     # pinned int64 [GSR_MAX_BATCH_VIEWS]: pair counts of a batched projection
         self.proj_scratch = None
+        self.proj_scratch_batch = None
         self.sort_scratch = None
         self.hint = {}           # (P, H, W) -> decaying max of recent pair counts
         self.last_stats = {}     # (P, H, W) -> (non-empty tiles or None = read the pinned word, pair count)
@@ -133,6 +135,21 @@ def _align(n: int, a: int = 256) -> int:
 def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
                           rotations, cov3D_precomp, want_keys: bool = False, want_aux: bool = True,
                           mode: Optional[str] = None, scene: Optional[dict] = None):
+    gen = _forward_steps(s, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, want_keys,
+                         want_aux, mode, scene, None)
+    try:
+        next(gen)
+    except StopIteration as e:
+        return e.value
+    raise RuntimeError("unreachable: a non-batched forward does not yield")
+
+
+def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
+                   rotations, cov3D_precomp, want_keys, want_aux, mode, scene, batch):
+    """Generator behind rasterize_forward_raw. With batch = dict(scratch=<this view's slice of the batch's projection
+    scratch>, pinned=<pinned int64 [V]>, index=k, event=<Event>) it allocates and binds, YIELDS (view struct, geom struct)
+    for the caller to run gsr_forward_project_batch over all views, and continues with the render when resumed.
+    Returns (outputs, state) through StopIteration.value."""
     """Forward through the C ABI. Returns (outputs dict, _State). Used by the autograd Function and by tests.
     scene (SURVEY.md 8f rank 2): {"models": [(xyz, scaling, rotation, opacity, features_dc, features_rest), ...] raw
     leaf tensors, "scale_noise": [P,3] | None, "sh_noise": [P,K,3] | None, "want_act": bool}; the per-Gaussian
@@ -216,6 +233,8 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     tiles = lib.gsr_num_tiles(H, W)
     mode = mode or FORWARD_MODE
     hint = ws.hint.get((P, H, W)) if mode == "auto" else None
+    if batch is not None and hint is None:
+        raise RuntimeError("batched forward needs a capacity hint (render the views once unbatched first)")
 
     with torch.cuda.device(dev):
         radii = torch.empty(Pm, dtype=i32, device=dev)
@@ -223,7 +242,7 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
         depth_alpha = torch.empty((2, H, W), dtype=torch.float32, device=dev)
         score = torch.zeros(P, dtype=torch.float32, device=dev) if s.score_flag else None
         proj_bytes = int(lib.gsr_project_scratch_bytes(P))
-        proj_scratch = ws.scratch("proj_scratch", proj_bytes)
+        proj_scratch = batch["scratch"] if batch is not None else ws.scratch("proj_scratch", proj_bytes)
 
         def alloc_state(cap):
             """One allocation for everything the backward re-reads (splat, tile counts, offsets, lists, ranges,
@@ -295,14 +314,20 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
             cap = (want + q - 1) // q * q
             buf, ptrs, offs = alloc_state(cap)
             bind(ptrs, cap, True)
-            pinned = ws.n_pinned
-            L.check(lib.gsr_forward_project_async(C.byref(st.view), C.byref(g), C.byref(geom), pinned.data_ptr(),
-                                                  stream, prof), "gsr_forward_project_async")
-            ws.event.record(torch.cuda.current_stream(dev))
+            if batch is not None:
+                yield st.view, geom, g       # the caller projects all views of the batch in one go
+                pinned, pidx, event = batch["pinned"], batch["index"], batch["event"]
+            else:
+                pinned, pidx, event = ws.n_pinned, 0, ws.event
+                L.check(lib.gsr_forward_project_async(C.byref(st.view), C.byref(g), C.byref(geom), pinned.data_ptr(),
+                                                      stream, prof), "gsr_forward_project_async")
+                event.record(torch.cuda.current_stream(dev))
             L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), cap, C.byref(b), C.byref(im), stream, prof),
                     "gsr_forward_render")
-            ws.event.synchronize()           # projection finished long before the render was even enqueued
-            N = int(pinned[0].item()) if P > 0 else 0
+            if batch is not None:
+                yield None                   # every view's render is enqueued before anybody waits for the counts
+            event.synchronize()              # projection finished long before the render was even enqueued
+            N = int(pinned[pidx].item()) if P > 0 else 0
             keep_bufs = (buf,)
             view_src = {k: (buf, offs[k]) for k in offs}
             if N >= (1 << 32):

@@ -1,0 +1,147 @@
+"""Several views of the SAME Gaussians in one call (the C_batch_size views of an optimizer step,
+training/object_trainer.py:302-382; new functionality, no reference counterpart).
+
+The reference renders its 4 views per step one after the other. Everything between K1 and the render of a view is a
+chain of ~20 small, launch-latency-bound kernels (depth sort, column counts); `gsr_forward_project_batch` pushes the
+chains of all views through each launch together (blockIdx.y = view). The per-view results are exactly those of
+`GaussianRasterizer` (same kernels, same order of operations inside a view); the backward runs per view and sums the
+parameter gradients on the device (K8 accumulate mode).
+
+    rast = GaussianRasterizerViews([settings_0, ..., settings_3])
+    outs = rast(means3D, means2D, opacities, shs=shs, scales=scales, rotations=rotations)   # means2D: [V,P,3] zeros
+    (image_k, radii_k, depth_alpha_k) = outs[k]
+"""
+from __future__ import annotations
+
+import ctypes as C
+import types
+from typing import List, Sequence
+
+import torch
+
+from . import _lib as L
+from . import rasterizer as R
+
+MAX_VIEWS = 16
+
+
+def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs, colors_precomp, scales, rotations,
+                                cov3D_precomp, want_aux: bool = False):
+    """Forward of V views. Returns [(outputs, state)] like rasterize_forward_raw per view."""
+    lib = L.load()
+    V = len(settings_list)
+    s0 = settings_list[0]
+    dev = means3D.device
+    P, H, W = int(means3D.shape[0]), int(s0.image_height), int(s0.image_width)
+    same = all(int(s.image_height) == H and int(s.image_width) == W and s.sh_degree == s0.sh_degree for s in settings_list)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = R._workspace(dev, stream)
+    batched = (1 < V <= MAX_VIEWS and same and P > 0 and R.FORWARD_MODE == "auto" and ws.hint.get((P, H, W)) is not None
+               and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24) and not any(s.score_flag for s in settings_list))
+    if not batched:
+        return [R.rasterize_forward_raw(s, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                                        want_aux=want_aux) for s in settings_list]
+    prof = R.PROFILE.handle if R.PROFILE is not None else None
+    stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
+    with torch.cuda.device(dev):
+        big = ws.scratch("proj_scratch_batch", stride * V)
+        if ws.batch_pinned is None:
+            ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
+        gens = [R._forward_steps(s, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, False,
+                                 want_aux, None, None,
+                                 dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
+                                      event=ws.event))
+                for k, s in enumerate(settings_list)]
+        heads = [next(g) for g in gens]                       # allocated + bound; waiting for the projection
+        views = (L.GsrView * V)(*[h[0] for h in heads])
+        geoms = (L.GsrGeom * V)(*[h[1] for h in heads])
+        L.check(lib.gsr_forward_project_batch(V, views, C.byref(heads[0][2]), geoms, ws.batch_pinned.data_ptr(), stream,
+                                              prof), "gsr_forward_project_batch")
+        for k, h in enumerate(heads):
+            h[1].sorted_idx = geoms[k].sorted_idx
+        ws.event.record(torch.cuda.current_stream(dev))
+        for g in gens:
+            next(g)                                           # renders of all views enqueued
+        results = []
+        for g in gens:
+            try:
+                next(g)
+                raise RuntimeError("forward generator did not finish")
+            except StopIteration as e:
+                results.append(e.value)
+    return results
+
+
+class _RasterizeViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list):
+        res = rasterize_views_forward_raw(settings_list, means3D, opacities, shs, colors_precomp, scales, rotations,
+                                          cov3D_precomp)
+        ctx.states = [st for _, st in res]
+        ctx.opac_shape = opacities.shape
+        outs = []
+        for o, _ in res:
+            ctx.mark_non_differentiable(o["radii"])
+            outs += [o["color"], o["radii"], o["depth_alpha"]]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        sts = ctx.states
+        V = len(sts)
+        st0 = sts[0]
+        H, W, dev, P, K = st0.view.image_height, st0.view.image_width, st0.dev, st0.P, st0.K
+        arena, acc0 = R.GRAD_ARENA, R.ACCUMULATE
+        m2d = []
+        first = None
+        for k, st in enumerate(sts):
+            g_color, g_da = grads[3 * k], grads[3 * k + 2]
+            if g_color is None:
+                g_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+            if g_da is None:
+                g_da = torch.zeros((2, H, W), dtype=torch.float32, device=dev)
+            if arena is not None:
+                o = R.rasterize_backward_raw(st, g_color, g_da, arena=arena, accumulate=(acc0 or k > 0))
+            elif k == 0:
+                o = R.rasterize_backward_raw(st, g_color, g_da)
+                # later views are ADDED to view 0's gradient tensors on the device
+                names = dict(means3D="dL_dmeans3D", opacities="dL_dopacities", shs="dL_dshs", scales="dL_dscales",
+                             rotations="dL_drotations")
+                local = types.SimpleNamespace(P=P, K=K, flat=o["dL_dmeans3D"],
+                                              views={n: o[k_] for n, k_ in names.items() if o.get(k_) is not None})
+                first = o
+            else:
+                if first.get("dL_dcolors") is not None or first.get("dL_dcov3D") is not None:
+                    o = R.rasterize_backward_raw(st, g_color, g_da)     # precomputed colours / covariances: plain sum
+                    for key in ("dL_dmeans3D", "dL_dopacities", "dL_dcolors", "dL_dcov3D", "dL_dshs", "dL_dscales",
+                                "dL_drotations"):
+                        if first.get(key) is not None:
+                            first[key] += o[key]
+                else:
+                    o = R.rasterize_backward_raw(st, g_color, g_da, arena=local, accumulate=True)
+            if first is None:
+                first = o
+            m2d.append(o["dL_dmeans2D"])
+        o = first
+        return (o["dL_dmeans3D"], torch.stack(m2d), o["dL_dshs"], o["dL_dcolors"],
+                o["dL_dopacities"].reshape(ctx.opac_shape), o["dL_dscales"], o["dL_drotations"], o["dL_dcov3D"], None)
+
+
+class GaussianRasterizerViews(torch.nn.Module):
+    def __init__(self, raster_settings_list):
+        super().__init__()
+        self.raster_settings_list = list(raster_settings_list)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None) -> List[tuple]:
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        V = len(self.raster_settings_list)
+        if means2D.shape[0] != V:
+            raise ValueError(f"means2D must be [V,P,3] with V = {V} views")
+        flat = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                     tuple(self.raster_settings_list))
+        return [tuple(flat[3 * k:3 * k + 3]) for k in range(V)]

@@ -120,11 +120,11 @@ typedef struct GsrGeom {
   float* splat;            /* [P,12], 16-byte aligned */
   int32_t* radii;          /* [P]  screen radius in pixels, 0 = culled (output `radii`)            */
   uint32_t* tiles_touched; /* [P]  number of 16x16 tiles overlapped                               */
-  uint32_t* block_offsets; /* [gsr_num_blocks(P)+8], 8-byte aligned: exclusive scan of the tile counts of each
-                              run of 256 Gaussians IN DEPTH ORDER, entry [nb] = N (low 32 bits); the tail holds
-                              the 64-bit N and the 64-bit count of visible Gaussians on the device */
-  void* scratch;           /* gsr_project_scratch_bytes(P) bytes, 256-byte aligned: depth-sort buffers. Must stay
-                              alive until gsr_forward_render has been enqueued; not needed for backward          */
+  uint32_t* block_offsets; /* [gsr_num_blocks(P)+8], 8-byte aligned; grids of more than 256 x 256 tiles only: exclusive
+                              scan of the tile counts of each run of 256 Gaussians IN DEPTH ORDER, [nb] = N (low 32 bits) */
+  void* scratch;           /* gsr_project_scratch_bytes(P) bytes, 256-byte aligned: depth-sort buffers, column counts
+                              and the device-side counts (N, visible Gaussians). Must stay alive until
+                              gsr_forward_render has been enqueued; not needed for backward                       */
   size_t scratch_bytes;
   uint32_t* sorted_idx;    /* OUT (set by gsr_forward_project*): [P] Gaussian indices in (depth bits, index) order,
                               culled ones last; points into scratch                                              */
@@ -236,6 +236,16 @@ int gsr_forward_project(const GsrView*, const GsrGaussians*, GsrGeom*, uint64_t*
  * (GsrBinning.count_on_device) so that a whole forward is enqueued without draining the GPU. */
 int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uint64_t* n_pairs_pinned, void* stream,
                               GsrProfile* prof);
+
+/* The same for n_views views of the SAME Gaussians (the C_batch_size views of one optimizer step,
+ * object_trainer.py:302-382): the launch-latency-bound depth sorts and column counts of all views go through each
+ * launch together. Requirements: equal P / image size / sh_stride, image at most 4096 x 4096, and the views'
+ * GsrGeom.scratch buffers equally spaced (geoms[k].scratch == geoms[0].scratch + k * stride, stride a multiple of 256).
+ * No host synchronisation: n_pairs_pinned[n_views] (page-locked) is valid once the work enqueued so far has finished.
+ * Each view then continues with its own gsr_forward_render. */
+#define GSR_MAX_BATCH_VIEWS 16
+int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGaussians*, GsrGeom* geoms,
+                              uint64_t* n_pairs_pinned, void* stream, GsrProfile* prof);
 
 /* K3 pair emission in depth order, K4 stable tile sort, K5 tile ranges, K6 front-to-back compositing. */
 int gsr_forward_render(const GsrView*, const GsrGeom*, uint64_t n_pairs, GsrBinning*, GsrImages*, void* stream,

@@ -1,0 +1,75 @@
+"""Several views of the same Gaussians through one call (dreamscene_amd/views.py, gsr_forward_project_batch): per-view
+results identical to GaussianRasterizer, gradients = the sum over the views."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import settings_for, small_scene, tol_ok
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,D,use_arena", [(16, 3, False), (4, 1, True)])
+def test_batched_views_match_sequential(built_lib, K, D, use_arena):
+    from dreamscene_amd import multiview, rasterizer as R, synth
+    from dreamscene_amd.rasterizer import GaussianRasterizer
+    from dreamscene_amd.views import GaussianRasterizerViews
+    dev = torch.device("cuda:0")
+    P, H, W, V = 1500, 112, 144, 4
+    g, _ = small_scene(P=P, H=H, W=W, K=K, seed=17)
+    cams = synth.object_cameras(V + 1, H, W, radius=3.0)[1:]
+    sets = [settings_for(c, [0.2, 0.4, 0.6], D, dev) for c in cams]
+    t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items()}
+    leaves = [t[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    gis = [torch.tensor(synth.upstream_grads(H, W, seed=k)[0], device=dev) for k in range(V)]
+    gdas = [torch.tensor(synth.upstream_grads(H, W, seed=k)[1], device=dev) for k in range(V)]
+
+    def sequential():
+        outs, tot, m2ds = [], None, []
+        for k, s in enumerate(sets):
+            m2d = torch.zeros((P, 3), device=dev, requires_grad=True)
+            img, radii, da = GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2d, shs=t["shs"],
+                                                    opacities=t["opacities"], scales=t["scales"],
+                                                    rotations=t["rotations"])
+            gr = torch.autograd.grad([img, da], leaves + [m2d], [gis[k], gdas[k]])
+            outs.append((img, radii, da))
+            m2ds.append(gr[-1])
+            tot = [a.clone() for a in gr[:-1]] if tot is None else [a + b for a, b in zip(tot, gr[:-1])]
+        return outs, tot, torch.stack(m2ds)
+
+    ref_outs, ref_grads, ref_m2d = sequential()         # also leaves the capacity hint the batched path needs
+    rast = GaussianRasterizerViews(sets)
+    arena = multiview.GradArena(P, K, dev) if use_arena else None
+    R.GRAD_ARENA = arena
+    try:
+        for rep in range(2):
+            m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+            outs = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
+                        rotations=t["rotations"])
+            grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [m2d],
+                                        [y for k in range(V) for y in (gis[k], gdas[k])])
+    finally:
+        R.GRAD_ARENA = None
+    for (img, radii, da), (rimg, rradii, rda) in zip(outs, ref_outs):
+        assert torch.equal(radii, rradii)
+        assert torch.equal(img, rimg) and torch.equal(da, rda)      # same kernels, same order inside a view
+    assert tol_ok(grads[-1].cpu().numpy(), ref_m2d.cpu().numpy(), atol=2e-6)    # (fp32 atomics: order varies run to run)
+    got = [arena.views[n] for n in ("means3D", "shs", "opacities", "scales", "rotations")] if use_arena else grads[:-1]
+    for a, b in zip(got, ref_grads):
+        assert tol_ok(a.reshape(b.shape).cpu().numpy(), b.cpu().numpy(), atol=2e-6)   # fp32 summation order over views
+
+
+@pytest.mark.gpu
+def test_batched_views_fall_back_without_hint_or_on_big_grids(built_lib):
+    """First call (no capacity hint yet) and mixed image sizes run view by view; results still correct."""
+    from dreamscene_amd import rasterizer as R, synth
+    from dreamscene_amd.views import rasterize_views_forward_raw
+    dev = torch.device("cuda:0")
+    P, K, D = 700, 4, 1
+    g, _ = small_scene(P=P, H=80, W=80, K=K, seed=23)
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    cams_a = synth.object_cameras(3, 83, 91, radius=3.0)[1:]            # a size nobody rendered before: no hint
+    sets = [settings_for(c, [1, 1, 1], D, dev) for c in cams_a]
+    res1 = rasterize_views_forward_raw(sets, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None)
+    res2 = rasterize_views_forward_raw(sets, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None)
+    for (o1, _), (o2, _) in zip(res1, res2):
+        assert torch.equal(o1["color"], o2["color"]) and torch.equal(o1["radii"], o2["radii"]) and o1["N"] == o2["N"]
