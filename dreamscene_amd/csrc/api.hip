@@ -6,6 +6,9 @@ thread_local int gsr_tls_hip_error = 0;
 // stage launchers (preprocess.hip, binning.hip, render.hip)
 int gsr_launch_preprocess(const GsrView&, const GsrGaussians&, GsrGeom&, hipStream_t);
 int gsr_launch_preprocess_bwd(const GsrView&, const GsrGaussians&, const GsrGeom&, const GsrGrads&, hipStream_t);
+bool gsr_preprocess_bwd_views_supported(const GsrView&, const GsrGaussians&, const GsrGrads&);
+int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians&, const GsrGeom* geoms,
+                                    const GsrGrads* outs, hipStream_t);
 int gsr_launch_depth_order(GsrGeom&, const GsrView&, hipStream_t, GsrProfile*, int batch, size_t bstride,
                            uint64_t* n_pairs_all);
 uint64_t* gsr_pair_counts(const GsrGeom&, int32_t P);
@@ -223,8 +226,8 @@ int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, 
   return GSR_OK;
 }
 
-int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, const GsrBinning* b,
-                 const GsrImages* img, const GsrImageGrads* ig, GsrGrads* out, void* stream_, GsrProfile* prof) {
+static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, const GsrBinning* b,
+                          const GsrImages* img, const GsrImageGrads* ig, const GsrGrads* out) {
   int rc = check_view(v);
   if (rc) return rc;
   rc = check_gaussians(v, g);
@@ -252,16 +255,65 @@ int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, c
   if ((out->dL_dscales || out->dL_drotations) && g->cov3D_precomp) return GSR_EINVAL;
   if (out->dL_dcov3D && !g->cov3D_precomp) return GSR_EINVAL;
   if (out->dL_drotations && !aligned16(out->dL_drotations)) return GSR_EINVAL;
-  hipStream_t stream = (hipStream_t)stream_;
+  return GSR_OK;
+}
+
+static int backward_render(const GsrView* v, const GsrGeom* geom, const GsrBinning* b, const GsrImages* img,
+                           const GsrImageGrads* ig, GsrGrads* out, hipStream_t stream, GsrProfile* prof) {
   GSR_HIP(hipMemsetAsync(out->partials, 0, (size_t)v->P * 12 * sizeof(float), stream));
-  {
-    GsrStageTimer t(prof, stream, GSR_STAGE_RENDER_BWD);
-    rc = gsr_launch_render_bwd(*v, *geom, *b, *img, *ig, *out, stream);
-    if (rc) return rc;
-  }
+  GsrStageTimer t(prof, stream, GSR_STAGE_RENDER_BWD);
+  return gsr_launch_render_bwd(*v, *geom, *b, *img, *ig, *out, stream);
+}
+
+int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, const GsrBinning* b,
+                 const GsrImages* img, const GsrImageGrads* ig, GsrGrads* out, void* stream_, GsrProfile* prof) {
+  int rc = check_backward(v, g, geom, b, img, ig, out);
+  if (rc) return rc;
+  if (v->P == 0) return GSR_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  rc = backward_render(v, geom, b, img, ig, out, stream, prof);
+  if (rc) return rc;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
     rc = gsr_launch_preprocess_bwd(*v, *g, *geom, *out, stream);
+    if (rc) return rc;
+  }
+  return GSR_OK;
+}
+
+int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians* g, const GsrGeom* geoms,
+                       const GsrBinning* bs, const GsrImages* imgs, const GsrImageGrads* igs, GsrGrads* outs,
+                       void* stream_, GsrProfile* prof) {
+  if (n_views < 1 || n_views > GSR_MAX_BATCH_VIEWS || !views || !geoms || !bs || !imgs || !igs || !outs) return GSR_EINVAL;
+  for (int k = 0; k < n_views; ++k) {
+    const int rc = check_backward(&views[k], g, &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k]);
+    if (rc) return rc;
+    if (views[k].P != views[0].P || views[k].image_height != views[0].image_height ||
+        views[k].image_width != views[0].image_width || views[k].sh_stride != views[0].sh_stride ||
+        views[k].sh_degree != views[0].sh_degree || views[k].scale_modifier != views[0].scale_modifier)
+      return GSR_EINVAL;
+  }
+  if (views[0].P == 0) return GSR_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool fused = n_views > 1 && gsr_preprocess_bwd_views_supported(views[0], *g, outs[0]);
+  for (int k = 0; k < n_views; ++k) {
+    const int rc = backward_render(&views[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k], stream, prof);
+    if (rc) return rc;
+    if (!fused) {   // unsupported combination: K8 view by view, views 1.. added to what view 0 wrote
+      GsrGrads o = outs[k];
+      const GsrGrads& o0 = outs[0];
+      o.dL_dmeans3D = o0.dL_dmeans3D; o.dL_dopacities = o0.dL_dopacities; o.dL_dshs = o0.dL_dshs;
+      o.dL_dcolors = o0.dL_dcolors; o.dL_dscales = o0.dL_dscales; o.dL_drotations = o0.dL_drotations;
+      o.dL_dcov3D = o0.dL_dcov3D; o.scene = o0.scene;
+      o.accumulate = (k > 0) ? 1 : o0.accumulate;
+      GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
+      const int rc2 = gsr_launch_preprocess_bwd(views[k], *g, geoms[k], o, stream);
+      if (rc2) return rc2;
+    }
+  }
+  if (fused) {
+    GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
+    const int rc = gsr_launch_preprocess_bwd_views(n_views, views, *g, geoms, outs, stream);
     if (rc) return rc;
   }
   return GSR_OK;

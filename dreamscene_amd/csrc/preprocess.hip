@@ -579,6 +579,139 @@ k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restr
 
 }
 
+// d colour / d (unit view direction), contracted with s_k = <sh_k, dL/dcolour>: the derivative of the SH basis
+__device__ __forceinline__ void sh_ddir(int D, float x, float y, float z, const float s[16], float& ddx, float& ddy,
+                                        float& ddz) {
+  ddx = 0.f; ddy = 0.f; ddz = 0.f;
+  if (D > 0) {
+    ddy += -GSR_SH_C1 * s[1]; ddz += GSR_SH_C1 * s[2]; ddx += -GSR_SH_C1 * s[3];
+    if (D > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      ddx += GSR_SH_C2_0 * y * s[4] + GSR_SH_C2_2 * (-2.0f * x) * s[6] + GSR_SH_C2_3 * z * s[7] + GSR_SH_C2_4 * 2.0f * x * s[8];
+      ddy += GSR_SH_C2_0 * x * s[4] + GSR_SH_C2_1 * z * s[5] + GSR_SH_C2_2 * (-2.0f * y) * s[6] + GSR_SH_C2_4 * (-2.0f * y) * s[8];
+      ddz += GSR_SH_C2_1 * y * s[5] + GSR_SH_C2_2 * 4.0f * z * s[6] + GSR_SH_C2_3 * x * s[7];
+      if (D > 2) {
+        ddx += GSR_SH_C3_0 * 6.0f * xy * s[9] + GSR_SH_C3_1 * yz * s[10] + GSR_SH_C3_2 * (-2.0f * xy) * s[11] +
+               GSR_SH_C3_3 * (-6.0f * xz) * s[12] + GSR_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy) * s[13] +
+               GSR_SH_C3_5 * 2.0f * xz * s[14] + GSR_SH_C3_6 * 3.0f * (xx - yy) * s[15];
+        ddy += GSR_SH_C3_0 * 3.0f * (xx - yy) * s[9] + GSR_SH_C3_1 * xz * s[10] +
+               GSR_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy) * s[11] + GSR_SH_C3_3 * (-6.0f * yz) * s[12] +
+               GSR_SH_C3_4 * (-2.0f * xy) * s[13] + GSR_SH_C3_5 * (-2.0f * yz) * s[14] + GSR_SH_C3_6 * (-6.0f * xy) * s[15];
+        ddz += GSR_SH_C3_1 * xy * s[10] + GSR_SH_C3_2 * 8.0f * yz * s[11] +
+               GSR_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy) * s[12] + GSR_SH_C3_4 * 8.0f * xz * s[13] +
+               GSR_SH_C3_5 * (xx - yy) * s[14];
+      }
+    }
+  }
+}
+
+// Steps (2a)-(5) of K8 for one view: K7's moments -> dL/d(ndc xy), dL/dconic -> cov2D -> dL/dSigma (dS, assigned) and
+// the position terms (added to dp); camera gradients (assigned) when want_cam.
+__device__ __forceinline__ void geom_backward(const ViewConst& vc, const Ewa& e, float fx, float fy, int W, int H,
+                                              float px, float py, float pz, float S1, float S2, float S3, float S4,
+                                              float S5, float gdep, bool want_cam, float& gndx, float& gndy,
+                                              float dS[9], float dp[3], float dview[12], float dproj[12]) {
+  const float* V = vc.V;
+  const float* PV = vc.PV;
+  // (2a) moments -> dL/d(ndc xy) and dL/dconic: power = -1/2 (A dx^2 + C dy^2) - B dx dy, dG/ddx = -G (A dx + B dy)
+  const float ca = e.ca, cb = e.cb, cc = e.cc;
+  {
+    const float inv = 1.0f / e.det;
+    const float A = cc * inv, B = -cb * inv, C = ca * inv;
+    gndx = -(A * S1 + B * S2) * (0.5f * (float)W);
+    gndy = -(C * S2 + B * S1) * (0.5f * (float)H);
+  }
+  const float gca = -0.5f * S3, gcb = -S4, gcc = -0.5f * S5;
+  // (2b) conic -> cov2D (lineage denominator det^2 + 1e-7)
+  const float d2i = 1.0f / (e.det * e.det + 0.0000001f);
+  const float dca = d2i * ((-cc * cc * gca + cb * cc * gcb) - cb * cb * gcc);
+  const float dcc = d2i * ((-cb * cb * gca + cb * ca * gcb) - ca * ca * gcc);
+  const float dcb = d2i * ((2.0f * cb * cc * gca - (e.det + 2.0f * cb * cb) * gcb) + 2.0f * cb * ca * gcc);
+  // (3) cov2D = M Sigma M^T
+  const float h = 0.5f * dcb;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      dS[3 * r + c] = (e.M0[r] * (dca * e.M0[c] + h * e.M1[c])) + (e.M1[r] * (h * e.M0[c] + dcc * e.M1[c]));
+  float dM0[3], dM1[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    dM0[j] = 2.0f * (dca * e.U0[j] + h * e.U1[j]);
+    dM1[j] = 2.0f * (h * e.U0[j] + dcc * e.U1[j]);
+  }
+  const float dJ00 = (dM0[0] * V[0] + dM0[1] * V[4]) + dM0[2] * V[8];
+  const float dJ02 = (dM0[0] * V[2] + dM0[1] * V[6]) + dM0[2] * V[10];
+  const float dJ11 = (dM1[0] * V[1] + dM1[1] * V[5]) + dM1[2] * V[9];
+  const float dJ12 = (dM1[0] * V[2] + dM1[1] * V[6]) + dM1[2] * V[10];
+  const float tzi = 1.0f / e.tz, tz2 = tzi * tzi, tz3 = tz2 * tzi;
+  float dt[3];
+  dt[0] = e.clx ? 0.0f : (-fx * tz2 * dJ02);
+  dt[1] = e.cly ? 0.0f : (-fy * tz2 * dJ12);
+  dt[2] = ((-fx * tz2 * dJ00 - fy * tz2 * dJ11) + (2.0f * fx * e.txc) * tz3 * dJ02) + (2.0f * fy * e.tyc) * tz3 * dJ12;
+  dt[2] += gdep;                                                               // (5) depth
+#pragma unroll
+  for (int r = 0; r < 3; ++r) dp[r] += (V[4 * r] * dt[0] + V[4 * r + 1] * dt[1]) + V[4 * r + 2] * dt[2];
+  // (4) ndc -> p
+  const float hx = ((PV[0] * px + PV[4] * py) + PV[8] * pz) + PV[12];
+  const float hy = ((PV[1] * px + PV[5] * py) + PV[9] * pz) + PV[13];
+  const float hw = ((PV[3] * px + PV[7] * py) + PV[11] * pz) + PV[15];
+  const float pw = 1.0f / (hw + 0.0000001f);
+  const float dh[3] = {pw * gndx, pw * gndy, -(pw * pw) * (hx * gndx + hy * gndy)};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) dp[r] += (PV[4 * r] * dh[0] + PV[4 * r + 1] * dh[1]) + PV[4 * r + 3] * dh[2];
+
+  if (want_cam) {
+    const float p4[4] = {px, py, pz, 1.0f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dview[3 * r + c] = p4[r] * dt[c];
+      dproj[3 * r + 0] = p4[r] * dh[0];
+      dproj[3 * r + 1] = p4[r] * dh[1];
+      dproj[3 * r + 2] = p4[r] * dh[2];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      dview[3 * r + 0] += e.J00 * dM0[r];
+      dview[3 * r + 1] += e.J11 * dM1[r];
+      dview[3 * r + 2] += e.J02 * dM0[r] + e.J12 * dM1[r];
+    }
+  }
+}
+
+// Step (6) of K8: dL/dSigma -> dL/dscale (of the scales as given) and dL/dquaternion (of the quaternion as given).
+__device__ __forceinline__ void sigma_backward(const float dS[9], const float R[9], const float s3[3], float mod,
+                                               const float4 q, float dscale[3], float drot[4]) {
+  float L[9], dL[9], dR[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 3; ++b2) L[3 * a + b2] = R[3 * a + b2] * s3[b2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 3; ++b2) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc += (dS[3 * a + k] + dS[3 * k + a]) * L[3 * k + b2];
+      dL[3 * a + b2] = acc;
+    }
+#pragma unroll
+  for (int b2 = 0; b2 < 3; ++b2) {
+    const float ds = (dL[b2] * R[b2] + dL[3 + b2] * R[3 + b2]) + dL[6 + b2] * R[6 + b2];
+    dscale[b2] = mod * ds;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b2 = 0; b2 < 3; ++b2) dR[3 * a + b2] = dL[3 * a + b2] * s3[b2];
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  drot[0] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+  drot[1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
+  drot[2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
+  drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+}
 // --------------------------------------------------------------------------------------------------------- K8
 // partials [P,12] from K7: (S1 = sum q dx, S2 = sum q dy, S3 = sum q dx^2, S4 = sum q dx dy, S5 = sum q dy^2,
 //                          dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -), q = dL/dG * G
@@ -602,8 +735,6 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
 
   ViewConst vc;
   load_view(v, vc);
-  const float* V = vc.V;
-  const float* PV = vc.PV;
 
   const bool vis = rw.ok && (radii[i] > 0);
   float px = 0, py = 0, pz = 0;
@@ -704,27 +835,8 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
           for (int k = 0; k < 3 * nb; ++k) sh[k] = sh[k] * (1.0f + kSqrtPoint2 * nz[k]);
         }
       }
-      float ddx = 0.f, ddy = 0.f, ddz = 0.f;
-      if (D > 0) {
-        ddy += -GSR_SH_C1 * s[1]; ddz += GSR_SH_C1 * s[2]; ddx += -GSR_SH_C1 * s[3];
-        if (D > 1) {
-          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-          ddx += GSR_SH_C2_0 * y * s[4] + GSR_SH_C2_2 * (-2.0f * x) * s[6] + GSR_SH_C2_3 * z * s[7] + GSR_SH_C2_4 * 2.0f * x * s[8];
-          ddy += GSR_SH_C2_0 * x * s[4] + GSR_SH_C2_1 * z * s[5] + GSR_SH_C2_2 * (-2.0f * y) * s[6] + GSR_SH_C2_4 * (-2.0f * y) * s[8];
-          ddz += GSR_SH_C2_1 * y * s[5] + GSR_SH_C2_2 * 4.0f * z * s[6] + GSR_SH_C2_3 * x * s[7];
-          if (D > 2) {
-            ddx += GSR_SH_C3_0 * 6.0f * xy * s[9] + GSR_SH_C3_1 * yz * s[10] + GSR_SH_C3_2 * (-2.0f * xy) * s[11] +
-                   GSR_SH_C3_3 * (-6.0f * xz) * s[12] + GSR_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy) * s[13] +
-                   GSR_SH_C3_5 * 2.0f * xz * s[14] + GSR_SH_C3_6 * 3.0f * (xx - yy) * s[15];
-            ddy += GSR_SH_C3_0 * 3.0f * (xx - yy) * s[9] + GSR_SH_C3_1 * xz * s[10] +
-                   GSR_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy) * s[11] + GSR_SH_C3_3 * (-6.0f * yz) * s[12] +
-                   GSR_SH_C3_4 * (-2.0f * xy) * s[13] + GSR_SH_C3_5 * (-2.0f * yz) * s[14] + GSR_SH_C3_6 * (-6.0f * xy) * s[15];
-            ddz += GSR_SH_C3_1 * xy * s[10] + GSR_SH_C3_2 * 8.0f * yz * s[11] +
-                   GSR_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy) * s[12] + GSR_SH_C3_4 * 8.0f * xz * s[13] +
-                   GSR_SH_C3_5 * (xx - yy) * s[14];
-          }
-        }
-      }
+      float ddx, ddy, ddz;
+      sh_ddir(D, x, y, z, s, ddx, ddy, ddz);
       const float dot = (x * ddx + y * ddy) + z * ddz;
       const float dvx = (ddx - x * dot) / len, dvy = (ddy - y * dot) / len, dvz = (ddz - z * dot) / len;
       dp[0] += dvx; dp[1] += dvy; dp[2] += dvz;
@@ -784,106 +896,15 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
     Ewa e;
     ewa_forward(vc, px, py, pz, c6, fx, fy, limx, limy, e);
 
-    // (2a) moments -> dL/d(ndc xy) and dL/dconic: power = -1/2 (A dx^2 + C dy^2) - B dx dy, dG/ddx = -G (A dx + B dy)
-    const float ca = e.ca, cb = e.cb, cc = e.cc;
-    {
-      const float inv = 1.0f / e.det;
-      const float A = cc * inv, B = -cb * inv, C = ca * inv;
-      gndx = -(A * S1 + B * S2) * (0.5f * (float)W);
-      gndy = -(C * S2 + B * S1) * (0.5f * (float)H);
-    }
-    const float gca = -0.5f * S3, gcb = -S4, gcc = -0.5f * S5;
-    // (2b) conic -> cov2D (lineage denominator det^2 + 1e-7)
-    const float d2i = 1.0f / (e.det * e.det + 0.0000001f);
-    const float dca = d2i * ((-cc * cc * gca + cb * cc * gcb) - cb * cb * gcc);
-    const float dcc = d2i * ((-cb * cb * gca + cb * ca * gcb) - ca * ca * gcc);
-    const float dcb = d2i * ((2.0f * cb * cc * gca - (e.det + 2.0f * cb * cb) * gcb) + 2.0f * cb * ca * gcc);
-    // (3) cov2D = M Sigma M^T
-    const float h = 0.5f * dcb;
     float dS[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        dS[3 * r + c] = (e.M0[r] * (dca * e.M0[c] + h * e.M1[c])) + (e.M1[r] * (h * e.M0[c] + dcc * e.M1[c]));
-    float dM0[3], dM1[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      dM0[j] = 2.0f * (dca * e.U0[j] + h * e.U1[j]);
-      dM1[j] = 2.0f * (h * e.U0[j] + dcc * e.U1[j]);
-    }
-    const float dJ00 = (dM0[0] * V[0] + dM0[1] * V[4]) + dM0[2] * V[8];
-    const float dJ02 = (dM0[0] * V[2] + dM0[1] * V[6]) + dM0[2] * V[10];
-    const float dJ11 = (dM1[0] * V[1] + dM1[1] * V[5]) + dM1[2] * V[9];
-    const float dJ12 = (dM1[0] * V[2] + dM1[1] * V[6]) + dM1[2] * V[10];
-    const float tzi = 1.0f / e.tz, tz2 = tzi * tzi, tz3 = tz2 * tzi;
-    float dt[3];
-    dt[0] = e.clx ? 0.0f : (-fx * tz2 * dJ02);
-    dt[1] = e.cly ? 0.0f : (-fy * tz2 * dJ12);
-    dt[2] = ((-fx * tz2 * dJ00 - fy * tz2 * dJ11) + (2.0f * fx * e.txc) * tz3 * dJ02) + (2.0f * fy * e.tyc) * tz3 * dJ12;
-    dt[2] += gdep;                                                               // (5) depth
-#pragma unroll
-    for (int r = 0; r < 3; ++r) dp[r] += (V[4 * r] * dt[0] + V[4 * r + 1] * dt[1]) + V[4 * r + 2] * dt[2];
-    // (4) ndc -> p
-    const float hx = ((PV[0] * px + PV[4] * py) + PV[8] * pz) + PV[12];
-    const float hy = ((PV[1] * px + PV[5] * py) + PV[9] * pz) + PV[13];
-    const float hw = ((PV[3] * px + PV[7] * py) + PV[11] * pz) + PV[15];
-    const float pw = 1.0f / (hw + 0.0000001f);
-    const float dh[3] = {pw * gndx, pw * gndy, -(pw * pw) * (hx * gndx + hy * gndy)};
-#pragma unroll
-    for (int r = 0; r < 3; ++r) dp[r] += (PV[4 * r] * dh[0] + PV[4 * r + 1] * dh[1]) + PV[4 * r + 3] * dh[2];
-
-    if (want_cam) {
-      const float p4[4] = {px, py, pz, 1.0f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dview[3 * r + c] = p4[r] * dt[c];
-        dproj[3 * r + 0] = p4[r] * dh[0];
-        dproj[3 * r + 1] = p4[r] * dh[1];
-        dproj[3 * r + 2] = p4[r] * dh[2];
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        dview[3 * r + 0] += e.J00 * dM0[r];
-        dview[3 * r + 1] += e.J11 * dM1[r];
-        dview[3 * r + 2] += e.J02 * dM0[r] + e.J12 * dM1[r];
-      }
-    }
+    geom_backward(vc, e, fx, fy, W, H, px, py, pz, S1, S2, S3, S4, S5, gdep, want_cam, gndx, gndy, dS, dp, dview, dproj);
 
     // (6) Sigma -> its parameters
     if (g.cov3D_precomp) {
       dc6[0] = dS[0]; dc6[1] = dS[1] + dS[3]; dc6[2] = dS[2] + dS[6];
       dc6[3] = dS[4]; dc6[4] = dS[5] + dS[7]; dc6[5] = dS[8];
     } else {
-      float L[9], dL[9], dR[9];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) L[3 * a + b2] = R[3 * a + b2] * s3[b2];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) {
-          float acc = 0.f;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) acc += (dS[3 * a + k] + dS[3 * k + a]) * L[3 * k + b2];
-          dL[3 * a + b2] = acc;
-        }
-#pragma unroll
-      for (int b2 = 0; b2 < 3; ++b2) {
-        const float ds = (dL[b2] * R[b2] + dL[3 + b2] * R[3 + b2]) + dL[6 + b2] * R[6 + b2];
-        dscale[b2] = mod * ds;
-      }
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) dR[3 * a + b2] = dL[3 * a + b2] * s3[b2];
-      const float r = q.x, x = q.y, y = q.z, z = q.w;
-      drot[0] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
-      drot[1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
-      drot[2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
-      drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+      sigma_backward(dS, R, s3, mod, q, dscale, drot);
       if constexpr (SCENE) {
         // through exp (+ noise, clamp) and through q = raw / |raw|:  d raw = (dq - q <q, dq>) / |raw|
 #pragma unroll
@@ -1012,6 +1033,168 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
   }
 }
 
+
+// ------------------------------------------------------------------------------------------- K8 over several views
+// The views of one optimizer step share their Gaussians (object_trainer.py:302-382): one pass reads every
+// parameter row once, loops over the views' cameras / K7 partials, sums the gradients in registers and writes them
+// once -- 4 views: ~185 B per Gaussian and view instead of ~700 (the SH rows dominate both the reads and the writes).
+// dL/dSigma is summed over the views before the (view-independent) step to scales / quaternion.
+struct K8Views {
+  int32_t nv;
+  const float* viewmatrix[GSR_MAX_BATCH_VIEWS];
+  const float* projmatrix[GSR_MAX_BATCH_VIEWS];
+  const float* campos[GSR_MAX_BATCH_VIEWS];
+  float tanfovx[GSR_MAX_BATCH_VIEWS];
+  float tanfovy[GSR_MAX_BATCH_VIEWS];
+  const int32_t* radii[GSR_MAX_BATCH_VIEWS];
+  const float* partials[GSR_MAX_BATCH_VIEWS];
+  float* dL_dmeans2D[GSR_MAX_BATCH_VIEWS];
+};
+
+template <int KT>
+__global__ void __launch_bounds__(256)
+k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, const GsrGrads out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int F = 3 * KT;
+  const int P = v.P, W = v.image_width, H = v.image_height, D = v.sh_degree;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
+  const int n_valid = (int)min((int64_t)64, max((int64_t)0, (int64_t)P - wave_first));
+  const float mod = v.scale_modifier;
+  const bool ok = i < P;
+  constexpr int stride = F | 1;
+  float* lw = lds + wave * (64 * stride);
+  float* sh = lw + lane * stride;
+
+  bool any = false;
+  for (int vv = 0; vv < vb.nv; ++vv) any = any || (ok && vb.radii[vv][i] > 0);
+  const unsigned long long amask = __ballot(any);
+
+  float px = 0, py = 0, pz = 0;
+  float R[9], c6[6], s3[3] = {0.f, 0.f, 0.f};
+  float4 q = make_float4(1, 0, 0, 0);
+  if (any) {
+    px = g.means3D[3 * i]; py = g.means3D[3 * i + 1]; pz = g.means3D[3 * i + 2];
+    s3[0] = mod * g.scales[3 * i]; s3[1] = mod * g.scales[3 * i + 1]; s3[2] = mod * g.scales[3 * i + 2];
+    q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
+    quat_to_R(q, R);
+    cov3d_from(s3[0], s3[1], s3[2], R, c6);
+    load_row<F>(g.shs + (size_t)i * F, sh);      // the lane's own SH row, kept (read only) in its LDS row
+  }
+
+  float dsh[F];
+#pragma unroll
+  for (int k = 0; k < F; ++k) dsh[k] = 0.f;
+  float dp[3] = {0.f, 0.f, 0.f}, dS[9], gop = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dS[k] = 0.f;
+
+  for (int vv = 0; vv < vb.nv; ++vv) {
+    const bool vis = ok && (vb.radii[vv][i] > 0);
+    float gndx = 0.f, gndy = 0.f;
+    if (vis) {
+      ViewConst vc;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
+      const float tfx = vb.tanfovx[vv], tfy = vb.tanfovy[vv];
+      const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
+      const float limx = 1.3f * tfx, limy = 1.3f * tfy;
+      const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
+      const float4 pa = pp[0], pb = pp[1], pc = pp[2];
+      gop += pb.y;
+      const float grgb[3] = {pb.z, pb.w, pc.x};
+      // (1) colour -> SH coefficients, view direction
+      {
+        const float vx = px - vc.cam[0], vy = py - vc.cam[1], vz = pz - vc.cam[2];
+        const float len = sqrtf((vx * vx + vy * vy) + vz * vz);
+        const float x = vx / len, y = vy / len, z = vz / len;
+        float b[16];
+        sh_basis(D, x, y, z, b);
+        float acc[3];
+        sh_colour_n<KT>(D, sh, b, acc);
+        float gch[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gch[c] = (acc[c] + 0.5f < 0.0f) ? 0.0f : grgb[c];   // K1's clamp decision
+        float s[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] = 0.f;
+#define GSR_SH_ACC_BAND(K0, K1)                                                                      \
+  _Pragma("unroll") for (int k = K0; k <= K1; ++k) {                                                 \
+    s[k] = (sh[3 * k] * gch[0] + sh[3 * k + 1] * gch[1]) + sh[3 * k + 2] * gch[2];                   \
+    dsh[3 * k] += b[k] * gch[0]; dsh[3 * k + 1] += b[k] * gch[1]; dsh[3 * k + 2] += b[k] * gch[2];   \
+  }
+        GSR_SH_ACC_BAND(0, 0)
+        if constexpr (KT >= 4) {
+          if (D > 0) {
+            GSR_SH_ACC_BAND(1, 3)
+            if constexpr (KT >= 9) {
+              if (D > 1) {
+                GSR_SH_ACC_BAND(4, 8)
+                if constexpr (KT >= 16) {
+                  if (D > 2) { GSR_SH_ACC_BAND(9, 15) }
+                }
+              }
+            }
+          }
+        }
+#undef GSR_SH_ACC_BAND
+        float ddx, ddy, ddz;
+        sh_ddir(D, x, y, z, s, ddx, ddy, ddz);
+        const float dot = (x * ddx + y * ddy) + z * ddz;
+        dp[0] += (ddx - x * dot) / len; dp[1] += (ddy - y * dot) / len; dp[2] += (ddz - z * dot) / len;
+      }
+      // (2)-(5) geometry of this view
+      Ewa e;
+      ewa_forward(vc, px, py, pz, c6, fx, fy, limx, limy, e);
+      float dSv[9], dview[12], dproj[12];
+      geom_backward(vc, e, fx, fy, W, H, px, py, pz, pa.x, pa.y, pa.z, pa.w, pb.x, pc.y, false, gndx, gndy, dSv, dp, dview,
+                    dproj);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dS[k] += dSv[k];
+      if (out.stat_denom) {
+        out.stat_xyz_gradient_accum[i] += sqrtf(gndx * gndx + gndy * gndy);
+        out.stat_denom[i] += 1.0f;
+        out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)vb.radii[vv][i]);
+      }
+    }
+    if (ok) {
+      float* m2 = vb.dL_dmeans2D[vv];
+      m2[3 * i] = gndx; m2[3 * i + 1] = gndy; m2[3 * i + 2] = 0.f;
+    }
+  }
+
+  float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+  if (any) sigma_backward(dS, R, s3, mod, q, dscale, drot);
+
+  // gradient rows -> LDS (zeros for Gaussians no view saw) -> coalesced write-back
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane < n_valid) {
+#pragma unroll
+    for (int k = 0; k < F; ++k) sh[k] = dsh[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (out.dL_dshs && !(out.accumulate && amask == 0ull))
+    stage_sh_out<KT>(out.dL_dshs, wave_first, n_valid, KT, lw, out.accumulate != 0);
+
+  if (ok && !(out.accumulate && !any)) {
+    if (out.accumulate) {
+      dp[0] += out.dL_dmeans3D[3 * i]; dp[1] += out.dL_dmeans3D[3 * i + 1]; dp[2] += out.dL_dmeans3D[3 * i + 2];
+      gop += out.dL_dopacities[i];
+      dscale[0] += out.dL_dscales[3 * i]; dscale[1] += out.dL_dscales[3 * i + 1]; dscale[2] += out.dL_dscales[3 * i + 2];
+      const float4 o = *reinterpret_cast<const float4*>(out.dL_drotations + 4 * i);
+      drot[0] += o.x; drot[1] += o.y; drot[2] += o.z; drot[3] += o.w;
+    }
+    out.dL_dmeans3D[3 * i] = dp[0]; out.dL_dmeans3D[3 * i + 1] = dp[1]; out.dL_dmeans3D[3 * i + 2] = dp[2];
+    out.dL_dopacities[i] = gop;
+    out.dL_dscales[3 * i] = dscale[0]; out.dL_dscales[3 * i + 1] = dscale[1]; out.dL_dscales[3 * i + 2] = dscale[2];
+    *reinterpret_cast<float4*>(out.dL_drotations + 4 * i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
+  }
+}
+
 }  // namespace
 
 uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P);   // binning.hip: first key buffer of the depth sort
@@ -1114,6 +1297,41 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const Gsr
     default: GSR_LAUNCH_K8(0); break;
   }
 #undef GSR_LAUNCH_K8
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
+
+// K8 for n_views views of the same Gaussians in one pass. Supported: shs with K in {1, 4, 9, 16}, (scales, rotations),
+// no camera gradients, no scene table (the caller falls back to one gsr_launch_preprocess_bwd per view otherwise).
+bool gsr_preprocess_bwd_views_supported(const GsrView& v, const GsrGaussians& g, const GsrGrads& out) {
+  const int K = v.sh_stride;
+  return g.shs && !g.scene && g.scales && g.rotations && !g.cov3D_precomp && !g.colors_precomp &&
+         (K == 1 || K == 4 || K == 9 || K == 16) && !out.dL_dview && !out.dL_dproj && !out.dL_dcampos &&
+         out.dL_dshs && out.dL_dscales && out.dL_drotations && out.dL_dmeans3D && out.dL_dopacities;
+}
+
+int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians& g, const GsrGeom* geoms,
+                                    const GsrGrads* outs, hipStream_t stream) {
+  K8Views vb = K8Views{};
+  vb.nv = n_views;
+  for (int k = 0; k < n_views; ++k) {
+    vb.viewmatrix[k] = views[k].viewmatrix; vb.projmatrix[k] = views[k].projmatrix; vb.campos[k] = views[k].campos;
+    vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy;
+    vb.radii[k] = geoms[k].radii; vb.partials[k] = outs[k].partials; vb.dL_dmeans2D[k] = outs[k].dL_dmeans2D;
+  }
+  const GsrView& v = views[0];
+  const uint32_t nb = gsr_num_blocks(v.P);
+  const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
+#define GSR_LAUNCH_K8V(KT) \
+  hipLaunchKernelGGL(k_preprocess_bwd_views<KT>, dim3(nb), dim3(256), lds, stream, v, g, vb, outs[0])
+  switch (v.sh_stride) {
+    case 16: GSR_LAUNCH_K8V(16); break;
+    case 9: GSR_LAUNCH_K8V(9); break;
+    case 4: GSR_LAUNCH_K8V(4); break;
+    case 1: GSR_LAUNCH_K8V(1); break;
+    default: return GSR_EINVAL;
+  }
+#undef GSR_LAUNCH_K8V
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }

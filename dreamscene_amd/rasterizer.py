@@ -483,6 +483,58 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
     return o
 
 
+def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=None, accumulate: bool = False) -> dict:
+    """Backward of several views of the same Gaussians through gsr_backward_views: K7 per view, one K8 pass over all
+    views. Returns the SUMMED parameter gradients (written to / added to the arena's views when given) and the per-view
+    means2D gradients [V,P,3]."""
+    lib = L.load()
+    V = len(states)
+    st0 = states[0]
+    dev, P, K = st0.dev, st0.P, st0.K
+    g = st0.gauss
+    f32 = torch.float32
+    av = {}
+    if arena is not None:
+        if arena.P != P or (g.shs and arena.K != K) or arena.flat.device != dev:
+            raise ValueError("GradArena does not match this view's (P, K, device)")
+        av = arena.views
+
+    def new(*shape, name=None):
+        t = av.get(name)
+        return t if t is not None else torch.empty(shape, dtype=f32, device=dev)
+    o = dict(dL_dmeans3D=new(P, 3, name="means3D"), dL_dopacities=new(P, 1, name="opacities"),
+             dL_dshs=new(P, K, 3, name="shs") if g.shs else None, dL_dcolors=new(P, 3) if g.colors_precomp else None,
+             dL_dscales=new(P, 3, name="scales") if g.scales else None,
+             dL_drotations=new(P, 4, name="rotations") if g.rotations else None,
+             dL_dcov3D=new(P, 6) if g.cov3D_precomp else None)
+    m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
+    partials = torch.empty((V, max(P, 1), 12), dtype=f32, device=dev)
+    views = (L.GsrView * V)(*[st.view for st in states])
+    geoms = (L.GsrGeom * V)(*[st.geom for st in states])
+    bins = (L.GsrBinning * V)(*[st.binning for st in states])
+    imgs = (L.GsrImages * V)(*[st.images for st in states])
+    igs = (L.GsrImageGrads * V)()
+    grs = (L.GsrGrads * V)()
+    keep = []
+    for k in range(V):
+        gc, gda = _prep(dL_dcolors[k], "dL_dcolor", dev), _prep(dL_ddepth_alphas[k], "dL_ddepth_alpha", dev)
+        keep += [gc, gda]
+        igs[k].dL_dcolor, igs[k].dL_ddepth_alpha = gc.data_ptr(), gda.data_ptr()
+        for name, t in o.items():
+            setattr(grs[k], name, _ptr(t))
+        grs[k].dL_dmeans2D = m2d[k].data_ptr()
+        grs[k].partials = partials[k].data_ptr()
+        grs[k].accumulate = int(bool(accumulate and arena is not None))
+        _bind_stats(grs[k], P, dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    prof = PROFILE.handle if PROFILE is not None else None
+    with torch.cuda.device(dev):
+        L.check(lib.gsr_backward_views(V, views, C.byref(g), geoms, bins, imgs, igs, grs, stream, prof),
+                "gsr_backward_views")
+    o["dL_dmeans2D"] = m2d[:, :P]
+    return o
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):

@@ -14,7 +14,6 @@ parameter gradients on the device (K8 accumulate mode).
 from __future__ import annotations
 
 import ctypes as C
-import types
 from typing import List, Sequence
 
 import torch
@@ -90,40 +89,14 @@ class _RasterizeViews(torch.autograd.Function):
         sts = ctx.states
         V = len(sts)
         st0 = sts[0]
-        H, W, dev, P, K = st0.view.image_height, st0.view.image_width, st0.dev, st0.P, st0.K
-        arena, acc0 = R.GRAD_ARENA, R.ACCUMULATE
-        m2d = []
-        first = None
-        for k, st in enumerate(sts):
+        H, W, dev = st0.view.image_height, st0.view.image_width, st0.dev
+        gcs, gdas = [], []
+        for k in range(V):
             g_color, g_da = grads[3 * k], grads[3 * k + 2]
-            if g_color is None:
-                g_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-            if g_da is None:
-                g_da = torch.zeros((2, H, W), dtype=torch.float32, device=dev)
-            if arena is not None:
-                o = R.rasterize_backward_raw(st, g_color, g_da, arena=arena, accumulate=(acc0 or k > 0))
-            elif k == 0:
-                o = R.rasterize_backward_raw(st, g_color, g_da)
-                # later views are ADDED to view 0's gradient tensors on the device
-                names = dict(means3D="dL_dmeans3D", opacities="dL_dopacities", shs="dL_dshs", scales="dL_dscales",
-                             rotations="dL_drotations")
-                local = types.SimpleNamespace(P=P, K=K, flat=o["dL_dmeans3D"],
-                                              views={n: o[k_] for n, k_ in names.items() if o.get(k_) is not None})
-                first = o
-            else:
-                if first.get("dL_dcolors") is not None or first.get("dL_dcov3D") is not None:
-                    o = R.rasterize_backward_raw(st, g_color, g_da)     # precomputed colours / covariances: plain sum
-                    for key in ("dL_dmeans3D", "dL_dopacities", "dL_dcolors", "dL_dcov3D", "dL_dshs", "dL_dscales",
-                                "dL_drotations"):
-                        if first.get(key) is not None:
-                            first[key] += o[key]
-                else:
-                    o = R.rasterize_backward_raw(st, g_color, g_da, arena=local, accumulate=True)
-            if first is None:
-                first = o
-            m2d.append(o["dL_dmeans2D"])
-        o = first
-        return (o["dL_dmeans3D"], torch.stack(m2d), o["dL_dshs"], o["dL_dcolors"],
+            gcs.append(g_color if g_color is not None else torch.zeros((3, H, W), dtype=torch.float32, device=dev))
+            gdas.append(g_da if g_da is not None else torch.zeros((2, H, W), dtype=torch.float32, device=dev))
+        o = R.rasterize_backward_views_raw(sts, gcs, gdas, arena=R.GRAD_ARENA, accumulate=R.ACCUMULATE)
+        return (o["dL_dmeans3D"], o["dL_dmeans2D"], o["dL_dshs"], o["dL_dcolors"],
                 o["dL_dopacities"].reshape(ctx.opac_shape), o["dL_dscales"], o["dL_drotations"], o["dL_dcov3D"], None)
 
 

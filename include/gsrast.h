@@ -255,6 +255,17 @@ int gsr_forward_render(const GsrView*, const GsrGeom*, uint64_t n_pairs, GsrBinn
 int gsr_backward(const GsrView*, const GsrGaussians*, const GsrGeom*, const GsrBinning*, const GsrImages*,
                  const GsrImageGrads*, GsrGrads*, void* stream, GsrProfile* prof);
 
+/* Backward of n_views views of the SAME Gaussians (forwarded together or not): K7 per view, then ONE K8 pass that reads
+ * every parameter row once, loops over the views and writes the summed parameter gradients once (supported for shs with
+ * K in {1,4,9,16} + scales/rotations without camera gradients; other combinations run K8 view by view with the same
+ * result). All arrays have n_views entries. Per view: outs[k].partials and outs[k].dL_dmeans2D (and dL_dview / dL_dproj /
+ * dL_dcampos); the parameter gradient pointers, `accumulate` and the stat_* pointers are taken from outs[0] (give every
+ * entry the same ones): the SUM over the views is written (accumulate = 0) or added (accumulate = 1) there, and the
+ * statistics are updated once per view that saw the Gaussian. */
+int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians*, const GsrGeom* geoms,
+                       const GsrBinning* binnings, const GsrImages* images, const GsrImageGrads* image_grads,
+                       GsrGrads* outs, void* stream, GsrProfile* prof);
+
 /* ---- replacement of `simple_knn._C.distCUDA2` (gs_renderer.py:9, 590-593) --------
  * out[i] = mean of the squared distances from points[i] to its 3 nearest other points (exact; FLT_MAX stands in
  * for neighbours that do not exist when n < 4). points [n,3] fp32, out [n] fp32, both on the device; scratch:
