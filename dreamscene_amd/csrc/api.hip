@@ -6,6 +6,8 @@ thread_local int gsr_tls_hip_error = 0;
 // stage launchers (preprocess.hip, binning.hip, render.hip)
 int gsr_launch_preprocess(const GsrView&, const GsrGaussians&, GsrGeom&, hipStream_t);
 int gsr_launch_preprocess_bwd(const GsrView&, const GsrGaussians&, const GsrGeom&, const GsrGrads&, hipStream_t);
+bool gsr_preprocess_views_supported(const GsrView&, const GsrGaussians&);
+int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaussians&, GsrGeom* geoms, hipStream_t);
 bool gsr_preprocess_bwd_views_supported(const GsrView&, const GsrGaussians&, const GsrGrads&);
 int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians&, const GsrGeom* geoms,
                                     const GsrGrads* outs, hipStream_t);
@@ -177,9 +179,17 @@ int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGa
   hipStream_t stream = (hipStream_t)stream_;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS);
-    for (int k = 0; k < n_views; ++k) {
-      const int rc = gsr_launch_preprocess(views[k], *g, geoms[k], stream);
+    bool same_view_consts = true;
+    for (int k = 1; k < n_views; ++k)
+      same_view_consts = same_view_consts && views[k].sh_degree == v0.sh_degree && views[k].scale_modifier == v0.scale_modifier;
+    if (n_views > 1 && same_view_consts && gsr_preprocess_views_supported(v0, *g)) {
+      const int rc = gsr_launch_preprocess_views(n_views, views, *g, geoms, stream);
       if (rc) return rc;
+    } else {
+      for (int k = 0; k < n_views; ++k) {
+        const int rc = gsr_launch_preprocess(views[k], *g, geoms[k], stream);
+        if (rc) return rc;
+      }
     }
   }
   uint64_t* n_all = n_pairs_device(&geoms[0], v0.P) + 2;   // spare words of view 0's count block

@@ -365,6 +365,61 @@ __device__ __forceinline__ void stage_sh_out(float* __restrict__ dst_base, int64
   }
 }
 
+// ---- the per-view projection of one Gaussian (K1), shared by the single-view and the multi-view kernel
+struct Proj {
+  bool vis;
+  int32_t radius;
+  uint32_t ntiles, rect;   // rect: x0 | y0 << 8 | (w-1) << 16 | (h-1) << 24 (grids up to 256 x 256 tiles)
+  float q0x, q0y, ca, cb, cc, depth;
+};
+// near-plane cull (view depth > 0.2) and the NDC position with the reference's 1/(w + 1e-7) (graphics_utils.py:29-36)
+__device__ __forceinline__ bool proj_in_front(const ViewConst& vc, float px, float py, float pz, float& ndcx, float& ndcy) {
+  const float tzq = ((vc.V[2] * px + vc.V[6] * py) + vc.V[10] * pz) + vc.V[14];
+  if (!(tzq > GSR_NEAR_Z)) return false;
+  const float* PV = vc.PV;
+  const float hx = ((PV[0] * px + PV[4] * py) + PV[8] * pz) + PV[12];
+  const float hy = ((PV[1] * px + PV[5] * py) + PV[9] * pz) + PV[13];
+  const float hw = ((PV[3] * px + PV[7] * py) + PV[11] * pz) + PV[15];
+  const float pw = 1.0f / (hw + 0.0000001f);
+  ndcx = hx * pw; ndcy = hy * pw;
+  return true;
+}
+__device__ __forceinline__ void proj_footprint(const ViewConst& vc, float px, float py, float pz, const float c6[6],
+                                               float fx, float fy, float limx, float limy, int W, int H, int gx, int gy,
+                                               float ndcx, float ndcy, Proj& o) {
+  o.vis = false; o.radius = 0; o.ntiles = 0; o.rect = 0;
+  Ewa e;
+  ewa_forward(vc, px, py, pz, c6, fx, fy, limx, limy, e);
+  if ((fabsf(e.det) > 0.0f) && (fabsf(e.det) < INFINITY)) {
+    const float inv = 1.0f / e.det;
+    const float mid = 0.5f * (e.ca + e.cc);
+    const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - e.det));
+    const int32_t radius = gsr_f2i_sat(ceilf(3.0f * sqrtf(lam)));
+    const float pxl = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
+    const float pyl = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+    const float rf = (float)radius;
+    const int32_t x0 = min(gx, max(0, gsr_f2i_sat((pxl - rf) * 0.0625f)));
+    const int32_t y0 = min(gy, max(0, gsr_f2i_sat((pyl - rf) * 0.0625f)));
+    const int32_t x1 = min(gx, max(0, gsr_f2i_sat(((pxl + rf) + 15.0f) * 0.0625f)));
+    const int32_t y1 = min(gy, max(0, gsr_f2i_sat(((pyl + rf) + 15.0f) * 0.0625f)));
+    o.ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
+    o.rect = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)(x1 - x0 - 1) << 16) | ((uint32_t)(y1 - y0 - 1) << 24);
+    if (o.ntiles != 0) {
+      o.vis = true;
+      o.radius = radius;
+      o.q0x = pxl; o.q0y = pyl;
+      o.ca = e.cc * inv; o.cb = -e.cb * inv; o.cc = e.ca * inv;
+      o.depth = e.tz;
+    }
+  }
+}
+// Level of the conic form below which a splat can pass the alpha >= 1/255 gate: sigma exp(-q/2) >= 1/255 <=>
+// q = d^T Conic d <= 2 ln(255 sigma) =: tau (slightly inflated). Used only to skip (pixel block, splat) pairs that
+// cannot contribute (render.hip); negative = the splat contributes nowhere. Not part of any parity artefact.
+__device__ __forceinline__ float splat_tau(float opac) {
+  return (opac * 255.0f > 1.0f) ? 2.0f * logf(opac * 255.0f) * 1.0001f + 0.001f : -1.f;
+}
+
 // --------------------------------------------------------------------------------------------------------- K1
 template <int KT, bool SCENE = false, typename TAB = NoScene>
 __global__ void __launch_bounds__(256)
@@ -412,14 +467,8 @@ k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restr
       }
       if (sc.opacities_out) sc.opacities_out[i] = act_sigmoid(p_opac[row]);
     }
-    const float tzq = ((vc.V[2] * px + vc.V[6] * py) + vc.V[10] * pz) + vc.V[14];
-    if (tzq > GSR_NEAR_Z) {
-      const float* PV = vc.PV;
-      const float hx = ((PV[0] * px + PV[4] * py) + PV[8] * pz) + PV[12];
-      const float hy = ((PV[1] * px + PV[5] * py) + PV[9] * pz) + PV[13];
-      const float hw = ((PV[3] * px + PV[7] * py) + PV[11] * pz) + PV[15];
-      const float pw = 1.0f / (hw + 0.0000001f);
-      const float ndcx = hx * pw, ndcy = hy * pw;
+    float ndcx, ndcy;
+    if (proj_in_front(vc, px, py, pz, ndcx, ndcy)) {
       float c6[6];
       if (g.cov3D_precomp) {
 #pragma unroll
@@ -442,38 +491,14 @@ k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restr
         quat_to_R(q, R);
         cov3d_from(s0, s1, s2, R, c6);
       }
-      Ewa e;
-      ewa_forward(vc, px, py, pz, c6, fx, fy, limx, limy, e);
-      if ((fabsf(e.det) > 0.0f) && (fabsf(e.det) < INFINITY)) {
-        const float inv = 1.0f / e.det;
-        const float mid = 0.5f * (e.ca + e.cc);
-        const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - e.det));
-        radius = gsr_f2i_sat(ceilf(3.0f * sqrtf(lam)));
-        const float pxl = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
-        const float pyl = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
-        const float rf = (float)radius;
-        const int32_t x0 = min(gx, max(0, gsr_f2i_sat((pxl - rf) * 0.0625f)));
-        const int32_t y0 = min(gy, max(0, gsr_f2i_sat((pyl - rf) * 0.0625f)));
-        const int32_t x1 = min(gx, max(0, gsr_f2i_sat(((pxl + rf) + 15.0f) * 0.0625f)));
-        const int32_t y1 = min(gy, max(0, gsr_f2i_sat(((pyl + rf) + 15.0f) * 0.0625f)));
-        ntiles = (uint32_t)((x1 - x0) * (y1 - y0));
-        rect = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)(x1 - x0 - 1) << 16) | ((uint32_t)(y1 - y0 - 1) << 24);
-        if (ntiles != 0) {
-          vis = true;
-          q0x = pxl; q0y = pyl;
-          ca_ = e.cc * inv; cb_ = -e.cb * inv; cc_ = e.ca * inv;
-          depth = e.tz;
-          opac = SCENE ? act_sigmoid(p_opac[row]) : p_opac[row];
-          // Level of the conic form below which this splat can pass the alpha >= 1/255 gate:
-          // sigma exp(-q/2) >= 1/255  <=>  q = d^T Conic d <= 2 ln(255 sigma) =: tau (slightly inflated).
-          // Used only to skip (pixel block, splat) pairs that cannot contribute (render.hip); negative = the
-          // splat contributes nowhere. Not part of any parity artefact.
-          if (opac * 255.0f > 1.0f) tau_ = 2.0f * logf(opac * 255.0f) * 1.0001f + 0.001f;
-        } else {
-          radius = 0;
-        }
-      } else {
-        radius = 0;
+      Proj pr;
+      proj_footprint(vc, px, py, pz, c6, fx, fy, limx, limy, W, H, gx, gy, ndcx, ndcy, pr);
+      radius = pr.radius; ntiles = pr.ntiles; rect = pr.rect;
+      if (pr.vis) {
+        vis = true;
+        q0x = pr.q0x; q0y = pr.q0y; ca_ = pr.ca; cb_ = pr.cb; cc_ = pr.cc; depth = pr.depth;
+        opac = SCENE ? act_sigmoid(p_opac[row]) : p_opac[row];
+        tau_ = splat_tau(opac);
       }
     }
   }
@@ -577,6 +602,90 @@ k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restr
     }
   }
 
+}
+
+
+// ------------------------------------------------------------------------------------------- K1 over several views
+// The parameter rows (44 + 12K bytes per Gaussian) are read once for all views of a step; per view only the 48-byte
+// splat record, radius, tile count, depth key and tile rectangle are written. cov3D is view independent.
+struct K1Views {
+  int32_t nv;
+  const float* viewmatrix[GSR_MAX_BATCH_VIEWS];
+  const float* projmatrix[GSR_MAX_BATCH_VIEWS];
+  const float* campos[GSR_MAX_BATCH_VIEWS];
+  float tanfovx[GSR_MAX_BATCH_VIEWS];
+  float tanfovy[GSR_MAX_BATCH_VIEWS];
+  float* splat[GSR_MAX_BATCH_VIEWS];
+  int32_t* radii[GSR_MAX_BATCH_VIEWS];
+  uint32_t* tiles_touched[GSR_MAX_BATCH_VIEWS];
+  uint32_t* depth_keys[GSR_MAX_BATCH_VIEWS];
+  uint32_t* rects[GSR_MAX_BATCH_VIEWS];
+};
+
+template <int KT>
+__global__ void __launch_bounds__(256)
+k_preprocess_views(const GsrView v, const GsrGaussians g, const K1Views vb) {
+  constexpr int F = 3 * KT;
+  const int P = v.P, W = v.image_width, H = v.image_height;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+  const float px = g.means3D[3 * i], py = g.means3D[3 * i + 1], pz = g.means3D[3 * i + 2];
+  bool have_cov = false, have_sh = false;
+  float c6[6], shr[F];
+  float opac = 0.f, tau = -1.f;
+  for (int vv = 0; vv < vb.nv; ++vv) {
+    ViewConst vc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
+    const float tfx = vb.tanfovx[vv], tfy = vb.tanfovy[vv];
+    const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
+    Proj pr;
+    pr.vis = false; pr.radius = 0; pr.ntiles = 0; pr.rect = 0;
+    float ndcx, ndcy;
+    if (proj_in_front(vc, px, py, pz, ndcx, ndcy)) {
+      if (!have_cov) {     // first view that has the Gaussian in front of it: scales / rotation -> cov3D, once
+        have_cov = true;
+        const float mod = v.scale_modifier;
+        const float s0 = mod * g.scales[3 * i], s1 = mod * g.scales[3 * i + 1], s2 = mod * g.scales[3 * i + 2];
+        const float4 q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
+        float R[9];
+        quat_to_R(q, R);
+        cov3d_from(s0, s1, s2, R, c6);
+      }
+      proj_footprint(vc, px, py, pz, c6, fx, fy, 1.3f * tfx, 1.3f * tfy, W, H, gx, gy, ndcx, ndcy, pr);
+    }
+    float rgb[3] = {0.f, 0.f, 0.f};
+    if (pr.vis) {
+      if (!have_sh) {      // first view that sees it: the SH row and the opacity, once
+        have_sh = true;
+        load_row<F>(g.shs + (size_t)i * F, shr);
+        opac = g.opacities[i];
+        tau = splat_tau(opac);
+      }
+      float dx = px - vc.cam[0], dy = py - vc.cam[1], dz = pz - vc.cam[2];
+      const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+      dx = dx / len; dy = dy / len; dz = dz / len;
+      float b[16];
+      sh_basis(v.sh_degree, dx, dy, dz, b);
+      float acc[3];
+      sh_colour_n<KT>(v.sh_degree, shr, b, acc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
+    }
+    vb.radii[vv][i] = pr.radius;
+    vb.tiles_touched[vv][i] = pr.ntiles;
+    vb.depth_keys[vv][i] = pr.vis ? __float_as_uint(pr.depth) : 0xFFFFFFFFu;
+    vb.rects[vv][i] = pr.rect;
+    if (pr.vis) {
+      float4* o = reinterpret_cast<float4*>(vb.splat[vv] + 12 * i);
+      o[0] = make_float4(pr.q0x, pr.q0y, pr.ca, pr.cb);
+      o[1] = make_float4(pr.cc, opac, pr.depth, rgb[0]);
+      o[2] = make_float4(rgb[1], rgb[2], tau, 0.f);
+    }
+  }
 }
 
 // d colour / d (unit view direction), contracted with s_k = <sh_k, dL/dcolour>: the derivative of the SH basis
@@ -1332,6 +1441,38 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
     default: return GSR_EINVAL;
   }
 #undef GSR_LAUNCH_K8V
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
+
+// K1 for n_views views of the same Gaussians in one pass (shs with K in {1,4,9,16}, scales + rotations, no scene table).
+bool gsr_preprocess_views_supported(const GsrView& v, const GsrGaussians& g) {
+  const int K = v.sh_stride;
+  return g.shs && !g.scene && g.scales && g.rotations && !g.cov3D_precomp && !g.colors_precomp &&
+         (K == 1 || K == 4 || K == 9 || K == 16);
+}
+
+int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaussians& g, GsrGeom* geoms,
+                                hipStream_t stream) {
+  K1Views vb = K1Views{};
+  vb.nv = n_views;
+  for (int k = 0; k < n_views; ++k) {
+    vb.viewmatrix[k] = views[k].viewmatrix; vb.projmatrix[k] = views[k].projmatrix; vb.campos[k] = views[k].campos;
+    vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy;
+    vb.splat[k] = geoms[k].splat; vb.radii[k] = geoms[k].radii; vb.tiles_touched[k] = geoms[k].tiles_touched;
+    vb.depth_keys[k] = gsr_depth_keys(geoms[k], views[k].P); vb.rects[k] = gsr_tile_rects(geoms[k], views[k].P);
+  }
+  const GsrView& v = views[0];
+  const uint32_t nb = gsr_num_blocks(v.P);
+#define GSR_LAUNCH_K1V(KT) hipLaunchKernelGGL(k_preprocess_views<KT>, dim3(nb), dim3(256), 0, stream, v, g, vb)
+  switch (v.sh_stride) {
+    case 16: GSR_LAUNCH_K1V(16); break;
+    case 9: GSR_LAUNCH_K1V(9); break;
+    case 4: GSR_LAUNCH_K1V(4); break;
+    case 1: GSR_LAUNCH_K1V(1); break;
+    default: return GSR_EINVAL;
+  }
+#undef GSR_LAUNCH_K1V
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }
