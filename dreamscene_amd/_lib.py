@@ -98,6 +98,7 @@ SYMBOLS = [
     ("gsr_profile_create", C.c_void_p, []),
     ("gsr_profile_destroy", None, [C.c_void_p]),
     ("gsr_profile_set_stage_mask", None, [C.c_void_p, C.c_uint32]),
+    ("gsr_profile_set_sampling", None, [C.c_void_p, C.c_uint32]),
     ("gsr_profile_collect", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("gsr_forward_project", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom),
                                       C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
@@ -168,6 +169,10 @@ class Profile:
         """Record only the named stages (None = all)."""
         mask = 0xFFFFFFFF if names is None else sum(1 << STAGES.index(n) for n in names)
         self.lib.gsr_profile_set_stage_mask(self.handle, mask)
+
+    def set_sampling(self, every: int = 1):
+        """Record one of every `every` occurrences of each stage."""
+        self.lib.gsr_profile_set_sampling(self.handle, int(every))
 
     def collect(self) -> dict:
         check(self.lib.gsr_profile_collect(self.handle, self.ms, self.counts), "gsr_profile_collect")

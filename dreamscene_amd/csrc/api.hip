@@ -14,11 +14,12 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
 int gsr_launch_depth_order(GsrGeom&, const GsrView&, hipStream_t, GsrProfile*, int batch, size_t bstride,
                            uint64_t* n_pairs_all);
 uint64_t* gsr_pair_counts(const GsrGeom&, int32_t P);
+bool gsr_uses_columns(const GsrView&);
 int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint64_t* n_dev, const uint64_t* n_dev_vis,
                        GsrBinning&, hipStream_t, GsrProfile*);
-int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, GsrImages&, hipStream_t);
+int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, GsrImages&, hipStream_t, GsrProfile*);
 int gsr_launch_render_bwd(const GsrView&, const GsrGeom&, const GsrBinning&, const GsrImages&, const GsrImageGrads&,
-                          GsrGrads&, hipStream_t);
+                          GsrGrads&, hipStream_t, GsrProfile*);
 
 namespace {
 
@@ -107,6 +108,12 @@ void gsr_profile_set_stage_mask(GsrProfile* p, uint32_t mask) {
   if (p) p->mask = mask;
 }
 
+void gsr_profile_set_sampling(GsrProfile* p, uint32_t every) {
+  if (!p) return;
+  p->every = every ? every : 1;
+  for (int i = 0; i < GSR_STAGE_COUNT; ++i) p->tick[i] = 0;
+}
+
 int gsr_profile_collect(GsrProfile* p, double* ms, int64_t* counts) {
   if (!p || !ms || !counts) return GSR_EINVAL;
   for (int i = 0; i < p->n; ++i) {
@@ -141,9 +148,11 @@ static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geo
     if (rc) return rc;
   }
   uint64_t* n_dev = n_pairs_device(geom, v->P);
-  rc = gsr_launch_depth_order(*geom, *v, stream, prof, 1, 0, nullptr);
+  // async + column path: n_pairs_host is page-locked and k_col_plan stores N there itself (no copy operation)
+  const bool direct = !sync && gsr_uses_columns(*v);
+  rc = gsr_launch_depth_order(*geom, *v, stream, prof, 1, 0, direct ? n_pairs_host : nullptr);
   if (rc) return rc;
-  GSR_HIP(hipMemcpyAsync(n_pairs_host, n_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  if (!direct) GSR_HIP(hipMemcpyAsync(n_pairs_host, n_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   if (sync) {
     GSR_HIP(hipStreamSynchronize(stream));
     if (*n_pairs_host >= (1ull << 32)) return GSR_ECAPACITY;
@@ -192,12 +201,11 @@ int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGa
       }
     }
   }
-  uint64_t* n_all = n_pairs_device(&geoms[0], v0.P) + 2;   // spare words of view 0's count block
-  int rc = gsr_launch_depth_order(geoms[0], v0, stream, prof, n_views, bstride, n_all);
+  // k_col_plan stores the views' counts straight into the caller's page-locked array (no copy operation)
+  int rc = gsr_launch_depth_order(geoms[0], v0, stream, prof, n_views, bstride, n_pairs_pinned);
   if (rc) return rc;
   for (int k = 1; k < n_views; ++k)
     geoms[k].sorted_idx = reinterpret_cast<uint32_t*>((char*)geoms[0].sorted_idx + (size_t)k * bstride);
-  GSR_HIP(hipMemcpyAsync(n_pairs_pinned, n_all, sizeof(uint64_t) * (size_t)n_views, hipMemcpyDeviceToHost, stream));
   return GSR_OK;
 }
 
@@ -228,11 +236,8 @@ int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, 
   const uint64_t* n_vis = v->P > 0 ? n_pairs_device(geom, v->P) + 1 : nullptr;
   rc = gsr_launch_binning(*v, *geom, n_pairs, n_dev, n_vis, *b, stream, prof);
   if (rc) return rc;
-  {
-    GsrStageTimer t(prof, stream, GSR_STAGE_RENDER_FWD);
-    rc = gsr_launch_render_fwd(*v, *geom, *b, *img, stream);
-    if (rc) return rc;
-  }
+  rc = gsr_launch_render_fwd(*v, *geom, *b, *img, stream, prof);
+  if (rc) return rc;
   return GSR_OK;
 }
 
@@ -271,8 +276,7 @@ static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom
 static int backward_render(const GsrView* v, const GsrGeom* geom, const GsrBinning* b, const GsrImages* img,
                            const GsrImageGrads* ig, GsrGrads* out, hipStream_t stream, GsrProfile* prof) {
   GSR_HIP(hipMemsetAsync(out->partials, 0, (size_t)v->P * 12 * sizeof(float), stream));
-  GsrStageTimer t(prof, stream, GSR_STAGE_RENDER_BWD);
-  return gsr_launch_render_bwd(*v, *geom, *b, *img, *ig, *out, stream);
+  return gsr_launch_render_bwd(*v, *geom, *b, *img, *ig, *out, stream, prof);
 }
 
 int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, const GsrBinning* b,

@@ -497,6 +497,7 @@ extern "C" uint32_t gsr_num_blocks(int32_t P) { return (uint32_t)((P + 255) / 25
 static bool use_columns(int32_t H, int32_t W, int32_t P) {
   return (W + GSR_TILE - 1) / GSR_TILE <= 256 && (H + GSR_TILE - 1) / GSR_TILE <= 256 && P < (1 << 24);
 }
+bool gsr_uses_columns(const GsrView& v) { return use_columns(v.image_height, v.image_width, v.P); }
 static uint32_t col_runs(int32_t P) { return (uint32_t)(((P > 0 ? P : 1) + kColRun - 1) / kColRun); }
 
 // Scratch of the projection stage: depth-sort keys x2 / values x2 (one of them becomes sorted_idx), histograms,
@@ -545,6 +546,7 @@ uint64_t* gsr_pair_counts(const GsrGeom& geom, int32_t P) { return carve_project
 // After K1 (which wrote the depth keys into scratch.k0): depth sort, depth-ordered counts, scan -> N.
 // batch > 1: `batch` views whose projection scratch buffers are `bstride` bytes apart (geom = the first view's) go
 // through every launch together (blockIdx.y = view); n_pairs_all (device, may be NULL) receives the N of all views.
+// n_pairs_all may be page-locked HOST memory (device-visible): the column path's k_col_plan stores the counts there itself.
 int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, GsrProfile* prof, int batch,
                            size_t bstride, uint64_t* n_pairs_all) {
   const int32_t P = v.P;

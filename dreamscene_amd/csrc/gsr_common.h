@@ -31,6 +31,8 @@ struct GsrProfile {
   int n = 0;
   int created = 0;
   uint32_t mask = 0xFFFFFFFFu;
+  uint32_t every = 1;                       // record one of every `every` occurrences of a stage ...
+  uint32_t tick[GSR_STAGE_COUNT] = {};      // ... counted per stage
 };
 
 // RAII-free stage bracket: records start/stop events on `stream` if profiling is on.
@@ -40,6 +42,7 @@ struct GsrStageTimer {
   int slot;
   GsrStageTimer(GsrProfile* prof, hipStream_t stream, int stage) : p(prof), s(stream), slot(-1) {
     if (!p || p->n >= GsrProfile::kMax || !((p->mask >> stage) & 1u)) return;
+    if (p->every > 1 && (p->tick[stage]++ % p->every) != 0) return;
     slot = p->n++;
     if (slot >= p->created) {
       (void)hipEventCreate(&p->ev[slot][0]);
@@ -49,9 +52,11 @@ struct GsrStageTimer {
     p->stage[slot] = stage;
     (void)hipEventRecord(p->ev[slot][0], s);
   }
-  ~GsrStageTimer() {
+  void stop() {
     if (slot >= 0) (void)hipEventRecord(p->ev[slot][1], s);
+    slot = -1;
   }
+  ~GsrStageTimer() { stop(); }
 };
 
 // float -> int32: truncating, saturating, NaN -> 0 (SEMANTICS.md; identical to the C oracle's f2i_sat).

@@ -150,8 +150,9 @@ typedef struct GsrBinning {
   int32_t fwd_mode;        /* forward compositing variant: 0 = four 8x8-quarter work items per tile, 4 lanes per pixel
                               (few / deep tiles); 1 = one work item per tile, one pixel per lane (thousands of
                               shallow tiles). Same semantics; a performance choice                 */
-  uint32_t* stats_host;    /* optional page-locked host word: receives (asynchronously) the number of non-empty
-                              tiles of this view, the statistic a caller can base the next call's fwd_mode on    */
+  uint32_t* stats_host;    /* optional page-locked (device-visible, e.g. hipHostMalloc / torch pinned) host word: a
+                              kernel stores the number of non-empty tiles of this view there, the statistic a caller
+                              can base the next call's fwd_mode on                                                */
 } GsrBinning;
 
 /* Per-pixel outputs (scene_gaussian.py:1012,1023) and the per-pixel state backward needs. */
@@ -213,6 +214,9 @@ GsrProfile* gsr_profile_create(void);
 void gsr_profile_destroy(GsrProfile*);
 /* Record only the stages whose bit (1u << GSR_STAGE_*) is set; default all. */
 void gsr_profile_set_stage_mask(GsrProfile*, uint32_t mask);
+/* Record only one of every `every` occurrences of each stage (bounds the cost of the two event records per occurrence
+ * inside a timed region); counts[] of gsr_profile_collect reports how many were recorded. */
+void gsr_profile_set_sampling(GsrProfile*, uint32_t every);
 /* Synchronises the recorded events and ADDS each stage's elapsed ms into ms[GSR_STAGE_COUNT] and the
  * number of recordings into counts[]; then clears the recordings. */
 int gsr_profile_collect(GsrProfile*, double* ms, int64_t* counts);
