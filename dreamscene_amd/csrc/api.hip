@@ -7,9 +7,9 @@ thread_local int gsr_tls_hip_error = 0;
 int gsr_launch_preprocess(const GsrView&, const GsrGaussians&, GsrGeom&, hipStream_t);
 int gsr_launch_preprocess_bwd(const GsrView&, const GsrGaussians&, const GsrGeom&, const GsrGrads&, hipStream_t);
 bool gsr_preprocess_views_supported(const GsrView&, const GsrGaussians&);
-int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaussians&, GsrGeom* geoms, hipStream_t);
+int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaussians* gs, GsrGeom* geoms, hipStream_t);
 bool gsr_preprocess_bwd_views_supported(const GsrView&, const GsrGaussians&, const GsrGrads&);
-int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians&, const GsrGeom* geoms,
+int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians* gs, const GsrGeom* geoms,
                                     const GsrGrads* outs, hipStream_t);
 int gsr_launch_depth_order(GsrGeom&, const GsrView&, hipStream_t, GsrProfile*, int batch, size_t bstride,
                            uint64_t* n_pairs_all);
@@ -72,6 +72,13 @@ int check_gaussians(const GsrView* v, const GsrGaussians* g) {
   }
   if (g->rotations && !aligned16(g->rotations)) return GSR_EINVAL;
   return GSR_OK;
+}
+
+// The views of a batch share their Gaussians; only `scales` may be a different tensor per view.
+bool same_except_scales(const GsrGaussians& a, const GsrGaussians& b) {
+  return a.means3D == b.means3D && a.opacities == b.opacities && a.shs == b.shs && a.colors_precomp == b.colors_precomp &&
+         a.rotations == b.rotations && a.cov3D_precomp == b.cov3D_precomp && a.scene == b.scene &&
+         (a.scales != nullptr) == (b.scales != nullptr);
 }
 
 }  // namespace
@@ -160,18 +167,19 @@ static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geo
   return GSR_OK;
 }
 
-int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGaussians* g, GsrGeom* geoms,
+int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGaussians* gs, GsrGeom* geoms,
                               uint64_t* n_pairs_pinned, void* stream_, GsrProfile* prof) {
-  if (n_views < 1 || n_views > GSR_MAX_BATCH_VIEWS || !views || !geoms || !n_pairs_pinned) return GSR_EINVAL;
+  if (n_views < 1 || n_views > GSR_MAX_BATCH_VIEWS || !views || !gs || !geoms || !n_pairs_pinned) return GSR_EINVAL;
+  const GsrGaussians* g = &gs[0];
   const GsrView& v0 = views[0];
   size_t bstride = 0;
   for (int k = 0; k < n_views; ++k) {
     int rc = check_view(&views[k]);
     if (rc) return rc;
-    rc = check_gaussians(&views[k], g);
+    rc = check_gaussians(&views[k], &gs[k]);
     if (rc) return rc;
     if (views[k].P != v0.P || views[k].image_height != v0.image_height || views[k].image_width != v0.image_width ||
-        views[k].sh_stride != v0.sh_stride)
+        views[k].sh_stride != v0.sh_stride || !same_except_scales(gs[k], gs[0]))
       return GSR_EINVAL;
     const GsrGeom& ge = geoms[k];
     n_pairs_pinned[k] = 0;
@@ -190,13 +198,13 @@ int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGa
     GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS);
     bool same_view_consts = true;
     for (int k = 1; k < n_views; ++k)
-      same_view_consts = same_view_consts && views[k].sh_degree == v0.sh_degree && views[k].scale_modifier == v0.scale_modifier;
+      same_view_consts = same_view_consts && views[k].scale_modifier == v0.scale_modifier;
     if (n_views > 1 && same_view_consts && gsr_preprocess_views_supported(v0, *g)) {
-      const int rc = gsr_launch_preprocess_views(n_views, views, *g, geoms, stream);
+      const int rc = gsr_launch_preprocess_views(n_views, views, gs, geoms, stream);
       if (rc) return rc;
     } else {
       for (int k = 0; k < n_views; ++k) {
-        const int rc = gsr_launch_preprocess(views[k], *g, geoms[k], stream);
+        const int rc = gsr_launch_preprocess(views[k], gs[k], geoms[k], stream);
         if (rc) return rc;
       }
     }
@@ -295,21 +303,31 @@ int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, c
   return GSR_OK;
 }
 
-int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians* g, const GsrGeom* geoms,
+int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians* gs, const GsrGeom* geoms,
                        const GsrBinning* bs, const GsrImages* imgs, const GsrImageGrads* igs, GsrGrads* outs,
                        void* stream_, GsrProfile* prof) {
-  if (n_views < 1 || n_views > GSR_MAX_BATCH_VIEWS || !views || !geoms || !bs || !imgs || !igs || !outs) return GSR_EINVAL;
+  if (n_views < 1 || n_views > GSR_MAX_BATCH_VIEWS || !views || !gs || !geoms || !bs || !imgs || !igs || !outs)
+    return GSR_EINVAL;
+  const GsrGaussians* g = &gs[0];
+  bool per_view_scales = false;
   for (int k = 0; k < n_views; ++k) {
-    const int rc = check_backward(&views[k], g, &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k]);
+    const int rc = check_backward(&views[k], &gs[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k]);
     if (rc) return rc;
+    if (!same_except_scales(gs[k], gs[0])) return GSR_EINVAL;
+    per_view_scales = per_view_scales || gs[k].scales != gs[0].scales;
     if (views[k].P != views[0].P || views[k].image_height != views[0].image_height ||
         views[k].image_width != views[0].image_width || views[k].sh_stride != views[0].sh_stride ||
-        views[k].sh_degree != views[0].sh_degree || views[k].scale_modifier != views[0].scale_modifier)
+        views[k].scale_modifier != views[0].scale_modifier)
       return GSR_EINVAL;
   }
   if (views[0].P == 0) return GSR_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  if (per_view_scales)       // every view then needs its own scale gradient buffer
+    for (int k = 0; k < n_views; ++k)
+      for (int j = 0; j < k; ++j)
+        if (!outs[k].dL_dscales || outs[k].dL_dscales == outs[j].dL_dscales) return GSR_EINVAL;
   const bool fused = n_views > 1 && gsr_preprocess_bwd_views_supported(views[0], *g, outs[0]);
+  if (per_view_scales && !fused) return GSR_EINVAL;   // per-view scales are only supported by the fused pass
   for (int k = 0; k < n_views; ++k) {
     const int rc = backward_render(&views[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k], stream, prof);
     if (rc) return rc;
@@ -317,7 +335,8 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
       GsrGrads o = outs[k];
       const GsrGrads& o0 = outs[0];
       o.dL_dmeans3D = o0.dL_dmeans3D; o.dL_dopacities = o0.dL_dopacities; o.dL_dshs = o0.dL_dshs;
-      o.dL_dcolors = o0.dL_dcolors; o.dL_dscales = o0.dL_dscales; o.dL_drotations = o0.dL_drotations;
+      o.dL_dcolors = o0.dL_dcolors; o.dL_drotations = o0.dL_drotations;
+      if (!per_view_scales) o.dL_dscales = o0.dL_dscales;
       o.dL_dcov3D = o0.dL_dcov3D; o.scene = o0.scene;
       o.accumulate = (k > 0) ? 1 : o0.accumulate;
       GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
@@ -327,7 +346,7 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   }
   if (fused) {
     GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
-    const int rc = gsr_launch_preprocess_bwd_views(n_views, views, *g, geoms, outs, stream);
+    const int rc = gsr_launch_preprocess_bwd_views(n_views, views, gs, geoms, outs, stream);
     if (rc) return rc;
   }
   return GSR_OK;

@@ -615,6 +615,9 @@ struct K1Views {
   const float* campos[GSR_MAX_BATCH_VIEWS];
   float tanfovx[GSR_MAX_BATCH_VIEWS];
   float tanfovy[GSR_MAX_BATCH_VIEWS];
+  int32_t sh_degree[GSR_MAX_BATCH_VIEWS];
+  int32_t per_view_scales;
+  const float* scales[GSR_MAX_BATCH_VIEWS];
   float* splat[GSR_MAX_BATCH_VIEWS];
   int32_t* radii[GSR_MAX_BATCH_VIEWS];
   uint32_t* tiles_touched[GSR_MAX_BATCH_VIEWS];
@@ -646,10 +649,11 @@ k_preprocess_views(const GsrView v, const GsrGaussians g, const K1Views vb) {
     pr.vis = false; pr.radius = 0; pr.ntiles = 0; pr.rect = 0;
     float ndcx, ndcy;
     if (proj_in_front(vc, px, py, pz, ndcx, ndcy)) {
-      if (!have_cov) {     // first view that has the Gaussian in front of it: scales / rotation -> cov3D, once
+      if (!have_cov || vb.per_view_scales) {   // scales / rotation -> cov3D: once, or per view if the scales differ
         have_cov = true;
         const float mod = v.scale_modifier;
-        const float s0 = mod * g.scales[3 * i], s1 = mod * g.scales[3 * i + 1], s2 = mod * g.scales[3 * i + 2];
+        const float* sc = vb.scales[vv];
+        const float s0 = mod * sc[3 * i], s1 = mod * sc[3 * i + 1], s2 = mod * sc[3 * i + 2];
         const float4 q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
         float R[9];
         quat_to_R(q, R);
@@ -669,9 +673,9 @@ k_preprocess_views(const GsrView v, const GsrGaussians g, const K1Views vb) {
       const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float b[16];
-      sh_basis(v.sh_degree, dx, dy, dz, b);
+      sh_basis(vb.sh_degree[vv], dx, dy, dz, b);
       float acc[3];
-      sh_colour_n<KT>(v.sh_degree, shr, b, acc);
+      sh_colour_n<KT>(vb.sh_degree[vv], shr, b, acc);
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
     }
@@ -1155,9 +1159,15 @@ struct K8Views {
   const float* campos[GSR_MAX_BATCH_VIEWS];
   float tanfovx[GSR_MAX_BATCH_VIEWS];
   float tanfovy[GSR_MAX_BATCH_VIEWS];
+  int32_t sh_degree[GSR_MAX_BATCH_VIEWS];   // the active degree may differ per view (scene_render's sh_deg_aug)
   const int32_t* radii[GSR_MAX_BATCH_VIEWS];
   const float* partials[GSR_MAX_BATCH_VIEWS];
   float* dL_dmeans2D[GSR_MAX_BATCH_VIEWS];
+  // per-view scales (the trainers add fresh noise to the activated scales of every view, scene_gaussian.py:1004-1008):
+  // then every view has its own scales tensor and its own scale gradient; the other parameters are shared
+  int32_t per_view_scales;
+  const float* scales[GSR_MAX_BATCH_VIEWS];
+  float* dL_dscales[GSR_MAX_BATCH_VIEWS];
 };
 
 template <int KT>
@@ -1165,7 +1175,7 @@ __global__ void __launch_bounds__(256)
 k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, const GsrGrads out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int F = 3 * KT;
-  const int P = v.P, W = v.image_width, H = v.image_height, D = v.sh_degree;
+  const int P = v.P, W = v.image_width, H = v.image_height;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t i = (int64_t)blockIdx.x * 256 + tid;
   const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
@@ -1185,12 +1195,15 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   float4 q = make_float4(1, 0, 0, 0);
   if (any) {
     px = g.means3D[3 * i]; py = g.means3D[3 * i + 1]; pz = g.means3D[3 * i + 2];
-    s3[0] = mod * g.scales[3 * i]; s3[1] = mod * g.scales[3 * i + 1]; s3[2] = mod * g.scales[3 * i + 2];
     q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
     quat_to_R(q, R);
-    cov3d_from(s3[0], s3[1], s3[2], R, c6);
+    if (!vb.per_view_scales) {
+      s3[0] = mod * g.scales[3 * i]; s3[1] = mod * g.scales[3 * i + 1]; s3[2] = mod * g.scales[3 * i + 2];
+      cov3d_from(s3[0], s3[1], s3[2], R, c6);
+    }
     load_row<F>(g.shs + (size_t)i * F, sh);      // the lane's own SH row, kept (read only) in its LDS row
   }
+  float drot[4] = {0.f, 0.f, 0.f, 0.f};
 
   float dsh[F];
 #pragma unroll
@@ -1209,6 +1222,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
 #pragma unroll
       for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
       const float tfx = vb.tanfovx[vv], tfy = vb.tanfovy[vv];
+      const int D = vb.sh_degree[vv];
       const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
       const float limx = 1.3f * tfx, limy = 1.3f * tfy;
       const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
@@ -1256,13 +1270,27 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
         dp[0] += (ddx - x * dot) / len; dp[1] += (ddy - y * dot) / len; dp[2] += (ddz - z * dot) / len;
       }
       // (2)-(5) geometry of this view
+      if (vb.per_view_scales) {
+        const float* sc = vb.scales[vv];
+        s3[0] = mod * sc[3 * i]; s3[1] = mod * sc[3 * i + 1]; s3[2] = mod * sc[3 * i + 2];
+        cov3d_from(s3[0], s3[1], s3[2], R, c6);
+      }
       Ewa e;
       ewa_forward(vc, px, py, pz, c6, fx, fy, limx, limy, e);
       float dSv[9], dview[12], dproj[12];
       geom_backward(vc, e, fx, fy, W, H, px, py, pz, pa.x, pa.y, pa.z, pa.w, pb.x, pc.y, false, gndx, gndy, dSv, dp, dview,
                     dproj);
+      if (vb.per_view_scales) {      // this view's own scales: its own scale gradient; the quaternion's is summed
+        float ds_v[3], dr_v[4];
+        sigma_backward(dSv, R, s3, mod, q, ds_v, dr_v);
+        float* o = vb.dL_dscales[vv];
+        o[3 * i] = ds_v[0]; o[3 * i + 1] = ds_v[1]; o[3 * i + 2] = ds_v[2];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) dS[k] += dSv[k];
+        for (int k = 0; k < 4; ++k) drot[k] += dr_v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dS[k] += dSv[k];
+      }
       if (out.stat_denom) {
         out.stat_xyz_gradient_accum[i] += sqrtf(gndx * gndx + gndy * gndy);
         out.stat_denom[i] += 1.0f;
@@ -1272,11 +1300,15 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     if (ok) {
       float* m2 = vb.dL_dmeans2D[vv];
       m2[3 * i] = gndx; m2[3 * i + 1] = gndy; m2[3 * i + 2] = 0.f;
+      if (vb.per_view_scales && !vis) {
+        float* o = vb.dL_dscales[vv];
+        o[3 * i] = 0.f; o[3 * i + 1] = 0.f; o[3 * i + 2] = 0.f;
+      }
     }
   }
 
-  float dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-  if (any) sigma_backward(dS, R, s3, mod, q, dscale, drot);
+  float dscale[3] = {0.f, 0.f, 0.f};
+  if (any && !vb.per_view_scales) sigma_backward(dS, R, s3, mod, q, dscale, drot);
 
   // gradient rows -> LDS (zeros for Gaussians no view saw) -> coalesced write-back
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1293,13 +1325,17 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     if (out.accumulate) {
       dp[0] += out.dL_dmeans3D[3 * i]; dp[1] += out.dL_dmeans3D[3 * i + 1]; dp[2] += out.dL_dmeans3D[3 * i + 2];
       gop += out.dL_dopacities[i];
-      dscale[0] += out.dL_dscales[3 * i]; dscale[1] += out.dL_dscales[3 * i + 1]; dscale[2] += out.dL_dscales[3 * i + 2];
+      if (!vb.per_view_scales) {
+        dscale[0] += out.dL_dscales[3 * i]; dscale[1] += out.dL_dscales[3 * i + 1]; dscale[2] += out.dL_dscales[3 * i + 2];
+      }
       const float4 o = *reinterpret_cast<const float4*>(out.dL_drotations + 4 * i);
       drot[0] += o.x; drot[1] += o.y; drot[2] += o.z; drot[3] += o.w;
     }
     out.dL_dmeans3D[3 * i] = dp[0]; out.dL_dmeans3D[3 * i + 1] = dp[1]; out.dL_dmeans3D[3 * i + 2] = dp[2];
     out.dL_dopacities[i] = gop;
-    out.dL_dscales[3 * i] = dscale[0]; out.dL_dscales[3 * i + 1] = dscale[1]; out.dL_dscales[3 * i + 2] = dscale[2];
+    if (!vb.per_view_scales) {
+      out.dL_dscales[3 * i] = dscale[0]; out.dL_dscales[3 * i + 1] = dscale[1]; out.dL_dscales[3 * i + 2] = dscale[2];
+    }
     *reinterpret_cast<float4*>(out.dL_drotations + 4 * i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
   }
 }
@@ -1419,13 +1455,16 @@ bool gsr_preprocess_bwd_views_supported(const GsrView& v, const GsrGaussians& g,
          out.dL_dshs && out.dL_dscales && out.dL_drotations && out.dL_dmeans3D && out.dL_dopacities;
 }
 
-int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians& g, const GsrGeom* geoms,
+int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians* gs, const GsrGeom* geoms,
                                     const GsrGrads* outs, hipStream_t stream) {
+  const GsrGaussians& g = gs[0];
   K8Views vb = K8Views{};
   vb.nv = n_views;
   for (int k = 0; k < n_views; ++k) {
+    vb.scales[k] = gs[k].scales; vb.dL_dscales[k] = outs[k].dL_dscales;
+    if (gs[k].scales != g.scales) vb.per_view_scales = 1;
     vb.viewmatrix[k] = views[k].viewmatrix; vb.projmatrix[k] = views[k].projmatrix; vb.campos[k] = views[k].campos;
-    vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy;
+    vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy; vb.sh_degree[k] = views[k].sh_degree;
     vb.radii[k] = geoms[k].radii; vb.partials[k] = outs[k].partials; vb.dL_dmeans2D[k] = outs[k].dL_dmeans2D;
   }
   const GsrView& v = views[0];
@@ -1452,13 +1491,16 @@ bool gsr_preprocess_views_supported(const GsrView& v, const GsrGaussians& g) {
          (K == 1 || K == 4 || K == 9 || K == 16);
 }
 
-int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaussians& g, GsrGeom* geoms,
+int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaussians* gs, GsrGeom* geoms,
                                 hipStream_t stream) {
+  const GsrGaussians& g = gs[0];
   K1Views vb = K1Views{};
   vb.nv = n_views;
   for (int k = 0; k < n_views; ++k) {
+    vb.scales[k] = gs[k].scales;
+    if (gs[k].scales != g.scales) vb.per_view_scales = 1;
     vb.viewmatrix[k] = views[k].viewmatrix; vb.projmatrix[k] = views[k].projmatrix; vb.campos[k] = views[k].campos;
-    vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy;
+    vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy; vb.sh_degree[k] = views[k].sh_degree;
     vb.splat[k] = geoms[k].splat; vb.radii[k] = geoms[k].radii; vb.tiles_touched[k] = geoms[k].tiles_touched;
     vb.depth_keys[k] = gsr_depth_keys(geoms[k], views[k].P); vb.rects[k] = gsr_tile_rects(geoms[k], views[k].P);
   }

@@ -507,9 +507,13 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
              dL_dscales=new(P, 3, name="scales") if g.scales else None,
              dL_drotations=new(P, 4, name="rotations") if g.rotations else None,
              dL_dcov3D=new(P, 6) if g.cov3D_precomp else None)
+    per_view_scales = any(st.gauss.scales != g.scales for st in states)
+    if per_view_scales:        # every view has its own scales tensor -> its own scale gradient
+        o["dL_dscales"] = torch.empty((V, P, 3), dtype=f32, device=dev)
     m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
     partials = torch.empty((V, max(P, 1), 12), dtype=f32, device=dev)
     views = (L.GsrView * V)(*[st.view for st in states])
+    gauss = (L.GsrGaussians * V)(*[st.gauss for st in states])
     geoms = (L.GsrGeom * V)(*[st.geom for st in states])
     bins = (L.GsrBinning * V)(*[st.binning for st in states])
     imgs = (L.GsrImages * V)(*[st.images for st in states])
@@ -522,6 +526,8 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         igs[k].dL_dcolor, igs[k].dL_ddepth_alpha = gc.data_ptr(), gda.data_ptr()
         for name, t in o.items():
             setattr(grs[k], name, _ptr(t))
+        if per_view_scales:
+            grs[k].dL_dscales = o["dL_dscales"][k].data_ptr()
         grs[k].dL_dmeans2D = m2d[k].data_ptr()
         grs[k].partials = partials[k].data_ptr()
         grs[k].accumulate = int(bool(accumulate and arena is not None))
@@ -529,7 +535,7 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
     stream = torch.cuda.current_stream(dev).cuda_stream
     prof = PROFILE.handle if PROFILE is not None else None
     with torch.cuda.device(dev):
-        L.check(lib.gsr_backward_views(V, views, C.byref(g), geoms, bins, imgs, igs, grs, stream, prof),
+        L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof),
                 "gsr_backward_views")
     o["dL_dmeans2D"] = m2d[:, :P]
     return o

@@ -9,6 +9,7 @@ parameter gradients on the device (K8 accumulate mode).
 
     rast = GaussianRasterizerViews([settings_0, ..., settings_3])
     outs = rast(means3D, means2D, opacities, shs=shs, scales=scales, rotations=rotations)   # means2D: [V,P,3] zeros
+    # scales: [P,3] shared, or [V,P,3] = every view its own (the trainers add fresh noise to the scales of every view)
     (image_k, radii_k, depth_alpha_k) = outs[k]
 """
 from __future__ import annotations
@@ -26,27 +27,35 @@ MAX_VIEWS = 16
 
 def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs, colors_precomp, scales, rotations,
                                 cov3D_precomp, want_aux: bool = False):
-    """Forward of V views. Returns [(outputs, state)] like rasterize_forward_raw per view."""
+    """Forward of V views. Returns [(outputs, state)] like rasterize_forward_raw per view.
+    scales: [P,3] shared by the views, or [V,P,3] (every view its own, e.g. with the trainers' per-view scale noise)."""
     lib = L.load()
     V = len(settings_list)
+    per_view = scales is not None and scales.dim() == 3
+    if per_view and scales.shape[0] != V:
+        raise ValueError(f"per-view scales must be [V,P,3] with V = {V}")
+    if per_view:
+        scales = scales.contiguous()
+    sc = (lambda k: scales[k]) if per_view else (lambda k: scales)
     s0 = settings_list[0]
     dev = means3D.device
     P, H, W = int(means3D.shape[0]), int(s0.image_height), int(s0.image_width)
-    same = all(int(s.image_height) == H and int(s.image_width) == W and s.sh_degree == s0.sh_degree for s in settings_list)
+    same = all(int(s.image_height) == H and int(s.image_width) == W and s.scale_modifier == s0.scale_modifier
+               for s in settings_list)
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = R._workspace(dev, stream)
     batched = (1 < V <= MAX_VIEWS and same and P > 0 and R.FORWARD_MODE == "auto" and ws.hint.get((P, H, W)) is not None
                and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24) and not any(s.score_flag for s in settings_list))
     if not batched:
-        return [R.rasterize_forward_raw(s, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
-                                        want_aux=want_aux) for s in settings_list]
+        return [R.rasterize_forward_raw(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp,
+                                        want_aux=want_aux) for k, s in enumerate(settings_list)]
     prof = R.PROFILE.handle if R.PROFILE is not None else None
     stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
     with torch.cuda.device(dev):
         big = ws.scratch("proj_scratch_batch", stride * V)
         if ws.batch_pinned is None:
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
-        gens = [R._forward_steps(s, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, False,
+        gens = [R._forward_steps(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp, False,
                                  want_aux, None, None,
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
                                       event=ws.event))
@@ -54,8 +63,9 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
         heads = [next(g) for g in gens]                       # allocated + bound; waiting for the projection
         views = (L.GsrView * V)(*[h[0] for h in heads])
         geoms = (L.GsrGeom * V)(*[h[1] for h in heads])
-        L.check(lib.gsr_forward_project_batch(V, views, C.byref(heads[0][2]), geoms, ws.batch_pinned.data_ptr(), stream,
-                                              prof), "gsr_forward_project_batch")
+        gauss = (L.GsrGaussians * V)(*[h[2] for h in heads])
+        L.check(lib.gsr_forward_project_batch(V, views, gauss, geoms, ws.batch_pinned.data_ptr(), stream, prof),
+                "gsr_forward_project_batch")
         for k, h in enumerate(heads):
             h[1].sorted_idx = geoms[k].sorted_idx
         ws.event.record(torch.cuda.current_stream(dev))

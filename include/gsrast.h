@@ -245,11 +245,13 @@ int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uin
  * object_trainer.py:302-382): the launch-latency-bound depth sorts and column counts of all views go through each
  * launch together. Requirements: equal P / image size / sh_stride, image at most 4096 x 4096, and the views'
  * GsrGeom.scratch buffers equally spaced (geoms[k].scratch == geoms[0].scratch + k * stride, stride a multiple of 256).
+ * gaussians[k] are the inputs of view k: identical pointers for every view except `scales`, which may be a different
+ * tensor per view (the trainers add fresh noise to the activated scales of every view, scene_gaussian.py:1004-1008).
  * No host synchronisation: n_pairs_pinned[n_views] (page-locked) is valid once the work enqueued so far has finished.
  * Each view then continues with its own gsr_forward_render. */
 #define GSR_MAX_BATCH_VIEWS 16
-int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGaussians*, GsrGeom* geoms,
-                              uint64_t* n_pairs_pinned, void* stream, GsrProfile* prof);
+int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGaussians* gaussians /* [n_views] */,
+                              GsrGeom* geoms, uint64_t* n_pairs_pinned, void* stream, GsrProfile* prof);
 
 /* K3 pair emission in depth order, K4 stable tile sort, K5 tile ranges, K6 front-to-back compositing. */
 int gsr_forward_render(const GsrView*, const GsrGeom*, uint64_t n_pairs, GsrBinning*, GsrImages*, void* stream,
@@ -265,8 +267,10 @@ int gsr_backward(const GsrView*, const GsrGaussians*, const GsrGeom*, const GsrB
  * result). All arrays have n_views entries. Per view: outs[k].partials and outs[k].dL_dmeans2D (and dL_dview / dL_dproj /
  * dL_dcampos); the parameter gradient pointers, `accumulate` and the stat_* pointers are taken from outs[0] (give every
  * entry the same ones): the SUM over the views is written (accumulate = 0) or added (accumulate = 1) there, and the
- * statistics are updated once per view that saw the Gaussian. */
-int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians*, const GsrGeom* geoms,
+ * statistics are updated once per view that saw the Gaussian. With per-view `scales` (see gsr_forward_project_batch)
+ * every outs[k].dL_dscales is its own [P,3] buffer and receives view k's scale gradient (never accumulated). */
+int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians* gaussians /* [n_views] */,
+                       const GsrGeom* geoms,
                        const GsrBinning* binnings, const GsrImages* images, const GsrImageGrads* image_grads,
                        GsrGrads* outs, void* stream, GsrProfile* prof);
 

@@ -8,8 +8,8 @@ from tests.util import settings_for, small_scene, tol_ok
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,D,use_arena", [(16, 3, False), (4, 1, True)])
-def test_batched_views_match_sequential(built_lib, K, D, use_arena):
+@pytest.mark.parametrize("K,D,use_arena,noisy_scales", [(16, 3, False, False), (4, 1, True, False), (16, 3, False, True)])
+def test_batched_views_match_sequential(built_lib, K, D, use_arena, noisy_scales):
     from dreamscene_amd import multiview, rasterizer as R, synth
     from dreamscene_amd.rasterizer import GaussianRasterizer
     from dreamscene_amd.views import GaussianRasterizerViews
@@ -17,9 +17,15 @@ def test_batched_views_match_sequential(built_lib, K, D, use_arena):
     P, H, W, V = 1500, 112, 144, 4
     g, _ = small_scene(P=P, H=H, W=W, K=K, seed=17)
     cams = synth.object_cameras(V + 1, H, W, radius=3.0)[1:]
-    sets = [settings_for(c, [0.2, 0.4, 0.6], D, dev) for c in cams]
+    # per-view background and active SH degree (scene_render's bg / sh_deg augmentation draws them per view)
+    sets = [settings_for(c, [0.2 * k, 0.4, 1.0 - 0.3 * k], D if k != 2 else 0, dev) for k, c in enumerate(cams)]
     t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items()}
     leaves = [t[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    # the trainers add fresh noise to the activated scales of every view (scene_gaussian.py:1004-1008): [V,P,3] scales
+    gen = torch.Generator().manual_seed(3)
+    noise = torch.randn((V, P, 3), generator=gen).to(dev)
+    view_scales = (lambda: torch.clamp(t["scales"][None] + noise * ((0.2 ** 0.5) * t["scales"][None] / 4), 0.0)) \
+        if noisy_scales else None
     gis = [torch.tensor(synth.upstream_grads(H, W, seed=k)[0], device=dev) for k in range(V)]
     gdas = [torch.tensor(synth.upstream_grads(H, W, seed=k)[1], device=dev) for k in range(V)]
 
@@ -27,9 +33,9 @@ def test_batched_views_match_sequential(built_lib, K, D, use_arena):
         outs, tot, m2ds = [], None, []
         for k, s in enumerate(sets):
             m2d = torch.zeros((P, 3), device=dev, requires_grad=True)
+            sck = view_scales()[k] if noisy_scales else t["scales"]
             img, radii, da = GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2d, shs=t["shs"],
-                                                    opacities=t["opacities"], scales=t["scales"],
-                                                    rotations=t["rotations"])
+                                                    opacities=t["opacities"], scales=sck, rotations=t["rotations"])
             gr = torch.autograd.grad([img, da], leaves + [m2d], [gis[k], gdas[k]])
             outs.append((img, radii, da))
             m2ds.append(gr[-1])
@@ -43,8 +49,8 @@ def test_batched_views_match_sequential(built_lib, K, D, use_arena):
     try:
         for rep in range(2):
             m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
-            outs = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
-                        rotations=t["rotations"])
+            outs = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
+                        scales=view_scales() if noisy_scales else t["scales"], rotations=t["rotations"])
             grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [m2d],
                                         [y for k in range(V) for y in (gis[k], gdas[k])])
     finally:
