@@ -176,6 +176,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    host_enqueue_s = time.perf_counter() - t0        # the host is done enqueueing; the GPU may still be working
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -228,6 +229,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

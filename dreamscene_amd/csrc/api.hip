@@ -282,8 +282,9 @@ static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom
 }
 
 static int backward_render(const GsrView* v, const GsrGeom* geom, const GsrBinning* b, const GsrImages* img,
-                           const GsrImageGrads* ig, GsrGrads* out, hipStream_t stream, GsrProfile* prof) {
-  GSR_HIP(hipMemsetAsync(out->partials, 0, (size_t)v->P * 12 * sizeof(float), stream));
+                           const GsrImageGrads* ig, GsrGrads* out, hipStream_t stream, GsrProfile* prof,
+                           bool clear_partials = true) {
+  if (clear_partials) GSR_HIP(hipMemsetAsync(out->partials, 0, (size_t)v->P * 12 * sizeof(float), stream));
   return gsr_launch_render_bwd(*v, *geom, *b, *img, *ig, *out, stream, prof);
 }
 
@@ -328,8 +329,14 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
         if (!outs[k].dL_dscales || outs[k].dL_dscales == outs[j].dL_dscales) return GSR_EINVAL;
   const bool fused = n_views > 1 && gsr_preprocess_bwd_views_supported(views[0], *g, outs[0]);
   if (per_view_scales && !fused) return GSR_EINVAL;   // per-view scales are only supported by the fused pass
+  // the views' partials usually are the rows of one [n_views, P, 12] tensor: one clear instead of n_views
+  const size_t pbytes = (size_t)views[0].P * 12 * sizeof(float);
+  bool contiguous = true;
+  for (int k = 1; k < n_views; ++k)
+    contiguous = contiguous && ((char*)outs[k].partials == (char*)outs[0].partials + (size_t)k * pbytes);
+  if (contiguous) GSR_HIP(hipMemsetAsync(outs[0].partials, 0, pbytes * (size_t)n_views, stream));
   for (int k = 0; k < n_views; ++k) {
-    const int rc = backward_render(&views[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k], stream, prof);
+    const int rc = backward_render(&views[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k], stream, prof, !contiguous);
     if (rc) return rc;
     if (!fused) {   // unsupported combination: K8 view by view, views 1.. added to what view 0 wrote
       GsrGrads o = outs[k];

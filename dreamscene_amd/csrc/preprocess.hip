@@ -1170,7 +1170,7 @@ struct K8Views {
   float* dL_dscales[GSR_MAX_BATCH_VIEWS];
 };
 
-template <int KT>
+template <int KT, bool PVS>   // PVS: per-view scales
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, const GsrGrads out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1197,7 +1197,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     px = g.means3D[3 * i]; py = g.means3D[3 * i + 1]; pz = g.means3D[3 * i + 2];
     q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
     quat_to_R(q, R);
-    if (!vb.per_view_scales) {
+    if constexpr (!PVS) {
       s3[0] = mod * g.scales[3 * i]; s3[1] = mod * g.scales[3 * i + 1]; s3[2] = mod * g.scales[3 * i + 2];
       cov3d_from(s3[0], s3[1], s3[2], R, c6);
     }
@@ -1270,7 +1270,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
         dp[0] += (ddx - x * dot) / len; dp[1] += (ddy - y * dot) / len; dp[2] += (ddz - z * dot) / len;
       }
       // (2)-(5) geometry of this view
-      if (vb.per_view_scales) {
+      if constexpr (PVS) {
         const float* sc = vb.scales[vv];
         s3[0] = mod * sc[3 * i]; s3[1] = mod * sc[3 * i + 1]; s3[2] = mod * sc[3 * i + 2];
         cov3d_from(s3[0], s3[1], s3[2], R, c6);
@@ -1280,7 +1280,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       float dSv[9], dview[12], dproj[12];
       geom_backward(vc, e, fx, fy, W, H, px, py, pz, pa.x, pa.y, pa.z, pa.w, pb.x, pc.y, false, gndx, gndy, dSv, dp, dview,
                     dproj);
-      if (vb.per_view_scales) {      // this view's own scales: its own scale gradient; the quaternion's is summed
+      if constexpr (PVS) {      // this view's own scales: its own scale gradient; the quaternion's is summed
         float ds_v[3], dr_v[4];
         sigma_backward(dSv, R, s3, mod, q, ds_v, dr_v);
         float* o = vb.dL_dscales[vv];
@@ -1300,7 +1300,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     if (ok) {
       float* m2 = vb.dL_dmeans2D[vv];
       m2[3 * i] = gndx; m2[3 * i + 1] = gndy; m2[3 * i + 2] = 0.f;
-      if (vb.per_view_scales && !vis) {
+      if (PVS && !vis) {
         float* o = vb.dL_dscales[vv];
         o[3 * i] = 0.f; o[3 * i + 1] = 0.f; o[3 * i + 2] = 0.f;
       }
@@ -1308,7 +1308,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   }
 
   float dscale[3] = {0.f, 0.f, 0.f};
-  if (any && !vb.per_view_scales) sigma_backward(dS, R, s3, mod, q, dscale, drot);
+  if (any && !PVS) sigma_backward(dS, R, s3, mod, q, dscale, drot);
 
   // gradient rows -> LDS (zeros for Gaussians no view saw) -> coalesced write-back
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1325,7 +1325,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     if (out.accumulate) {
       dp[0] += out.dL_dmeans3D[3 * i]; dp[1] += out.dL_dmeans3D[3 * i + 1]; dp[2] += out.dL_dmeans3D[3 * i + 2];
       gop += out.dL_dopacities[i];
-      if (!vb.per_view_scales) {
+      if constexpr (!PVS) {
         dscale[0] += out.dL_dscales[3 * i]; dscale[1] += out.dL_dscales[3 * i + 1]; dscale[2] += out.dL_dscales[3 * i + 2];
       }
       const float4 o = *reinterpret_cast<const float4*>(out.dL_drotations + 4 * i);
@@ -1333,7 +1333,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     }
     out.dL_dmeans3D[3 * i] = dp[0]; out.dL_dmeans3D[3 * i + 1] = dp[1]; out.dL_dmeans3D[3 * i + 2] = dp[2];
     out.dL_dopacities[i] = gop;
-    if (!vb.per_view_scales) {
+    if constexpr (!PVS) {
       out.dL_dscales[3 * i] = dscale[0]; out.dL_dscales[3 * i + 1] = dscale[1]; out.dL_dscales[3 * i + 2] = dscale[2];
     }
     *reinterpret_cast<float4*>(out.dL_drotations + 4 * i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
@@ -1470,8 +1470,11 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
   const GsrView& v = views[0];
   const uint32_t nb = gsr_num_blocks(v.P);
   const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
-#define GSR_LAUNCH_K8V(KT) \
-  hipLaunchKernelGGL(k_preprocess_bwd_views<KT>, dim3(nb), dim3(256), lds, stream, v, g, vb, outs[0])
+#define GSR_LAUNCH_K8V(KT)                                                                                       \
+  if (vb.per_view_scales)                                                                                        \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, outs[0]);  \
+  else                                                                                                           \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, false>), dim3(nb), dim3(256), lds, stream, v, g, vb, outs[0])
   switch (v.sh_stride) {
     case 16: GSR_LAUNCH_K8V(16); break;
     case 9: GSR_LAUNCH_K8V(9); break;

@@ -548,6 +548,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                         cov3D_precomp, want_aux=False)
         ctx.st = st
         ctx.opac_shape = opacities.shape
+        ctx.set_materialize_grads(False)       # no zero tensors for outputs nobody differentiates (radii is [P] int32)
         ctx.mark_non_differentiable(out["radii"])
         if settings.score_flag:
             ctx.mark_non_differentiable(out["score"])

@@ -46,6 +46,7 @@ class _RasterizeModels(torch.autograd.Function):
                                           scene=dict(models=models, scale_noise=scale_noise, sh_noise=sh_noise))
         ctx.st = st
         ctx.n_leaves = len(leaves)
+        ctx.set_materialize_grads(False)       # no zero tensors for outputs nobody differentiates (radii is [P] int32)
         ctx.mark_non_differentiable(out["radii"])
         if settings.score_flag:
             ctx.mark_non_differentiable(out["score"])

@@ -88,6 +88,7 @@ class _RasterizeViews(torch.autograd.Function):
                                           cov3D_precomp)
         ctx.states = [st for _, st in res]
         ctx.opac_shape = opacities.shape
+        ctx.set_materialize_grads(False)       # no zero tensors for outputs nobody differentiates (radii is [P] int32)
         outs = []
         for o, _ in res:
             ctx.mark_non_differentiable(o["radii"])
