@@ -111,6 +111,8 @@ SYMBOLS = [
     ("gsr_backward_views", C.c_int, [C.c_int32, C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom),
                                      C.POINTER(GsrBinning), C.POINTER(GsrImages), C.POINTER(GsrImageGrads),
                                      C.POINTER(GsrGrads), C.c_void_p, C.c_void_p]),
+    ("gsr_forward_render_batch", C.c_int, [C.c_int32, C.POINTER(GsrView), C.POINTER(GsrGeom), C.c_uint64,
+                                           C.POINTER(GsrBinning), C.POINTER(GsrImages), C.c_void_p, C.c_void_p]),
     ("gsr_knn_scratch_bytes", C.c_size_t, [C.c_int32]),
     ("gsr_knn_mean_dist2", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("gsr_backward", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom), C.POINTER(GsrBinning),

@@ -18,6 +18,8 @@ bool gsr_uses_columns(const GsrView&);
 int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint64_t* n_dev, const uint64_t* n_dev_vis,
                        GsrBinning&, hipStream_t, GsrProfile*);
 int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, GsrImages&, hipStream_t, GsrProfile*);
+int gsr_launch_work_order_fwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
+int gsr_launch_work_order_bwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
 int gsr_launch_render_bwd(const GsrView&, const GsrGeom&, const GsrBinning&, const GsrImages&, const GsrImageGrads&,
                           GsrGrads&, hipStream_t, GsrProfile*);
 
@@ -227,8 +229,8 @@ int gsr_forward_project_async(const GsrView* v, const GsrGaussians* g, GsrGeom* 
   return forward_project(v, g, geom, n_pairs_pinned, stream_, prof, false);
 }
 
-int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, GsrBinning* b, GsrImages* img,
-                       void* stream_, GsrProfile* prof) {
+static int check_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, const GsrBinning* b,
+                        const GsrImages* img) {
   int rc = check_view(v);
   if (rc) return rc;
   if (!geom || !b || !img) return GSR_EINVAL;
@@ -238,14 +240,48 @@ int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, 
   if (n_pairs && (!b->point_list || !geom->splat)) return GSR_EINVAL;
   if (v->P > 0 && (!geom->scratch || geom->scratch_bytes < gsr_project_scratch_bytes(v->P))) return GSR_ESCRATCH;
   if (n_pairs >= (1ull << 32)) return GSR_ECAPACITY;
-  hipStream_t stream = (hipStream_t)stream_;
+  return GSR_OK;
+}
+
+static int render_binning(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, GsrBinning* b, hipStream_t stream,
+                          GsrProfile* prof) {
   if (v->P == 0) n_pairs = 0;
   const uint64_t* n_dev = (b->count_on_device && v->P > 0) ? n_pairs_device(geom, v->P) : nullptr;
   const uint64_t* n_vis = v->P > 0 ? n_pairs_device(geom, v->P) + 1 : nullptr;
-  rc = gsr_launch_binning(*v, *geom, n_pairs, n_dev, n_vis, *b, stream, prof);
+  return gsr_launch_binning(*v, *geom, n_pairs, n_dev, n_vis, *b, stream, prof);
+}
+
+int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, GsrBinning* b, GsrImages* img,
+                       void* stream_, GsrProfile* prof) {
+  int rc = check_render(v, geom, n_pairs, b, img);
   if (rc) return rc;
-  rc = gsr_launch_render_fwd(*v, *geom, *b, *img, stream, prof);
+  hipStream_t stream = (hipStream_t)stream_;
+  rc = render_binning(v, geom, n_pairs, b, stream, prof);
   if (rc) return rc;
+  rc = gsr_launch_work_order_fwd(1, v, b, img, stream);
+  if (rc) return rc;
+  return gsr_launch_render_fwd(*v, *geom, *b, *img, stream, prof);
+}
+
+int gsr_forward_render_batch(int32_t n_views, const GsrView* views, const GsrGeom* geoms, uint64_t n_pairs,
+                             GsrBinning* bs, GsrImages* imgs, void* stream_, GsrProfile* prof) {
+  if (n_views < 1 || n_views > GSR_MAX_BATCH_VIEWS || !views || !geoms || !bs || !imgs) return GSR_EINVAL;
+  for (int k = 0; k < n_views; ++k) {
+    const int rc = check_render(&views[k], &geoms[k], n_pairs, &bs[k], &imgs[k]);
+    if (rc) return rc;
+    if (views[k].image_height != views[0].image_height || views[k].image_width != views[0].image_width) return GSR_EINVAL;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  for (int k = 0; k < n_views; ++k) {
+    const int rc = render_binning(&views[k], &geoms[k], n_pairs, &bs[k], stream, prof);
+    if (rc) return rc;
+  }
+  int rc = gsr_launch_work_order_fwd(n_views, views, bs, imgs, stream);   // the work lists of all views in one launch
+  if (rc) return rc;
+  for (int k = 0; k < n_views; ++k) {
+    rc = gsr_launch_render_fwd(views[k], geoms[k], bs[k], imgs[k], stream, prof);
+    if (rc) return rc;
+  }
   return GSR_OK;
 }
 
@@ -294,6 +330,8 @@ int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, c
   if (rc) return rc;
   if (v->P == 0) return GSR_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  rc = gsr_launch_work_order_bwd(1, v, b, img, stream);
+  if (rc) return rc;
   rc = backward_render(v, geom, b, img, ig, out, stream, prof);
   if (rc) return rc;
   {
@@ -335,6 +373,10 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   for (int k = 1; k < n_views; ++k)
     contiguous = contiguous && ((char*)outs[k].partials == (char*)outs[0].partials + (size_t)k * pbytes);
   if (contiguous) GSR_HIP(hipMemsetAsync(outs[0].partials, 0, pbytes * (size_t)n_views, stream));
+  {
+    const int rc = gsr_launch_work_order_bwd(n_views, views, bs, imgs, stream);   // all views' work lists in one launch
+    if (rc) return rc;
+  }
   for (int k = 0; k < n_views; ++k) {
     const int rc = backward_render(&views[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k], stream, prof, !contiguous);
     if (rc) return rc;

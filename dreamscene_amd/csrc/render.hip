@@ -141,9 +141,25 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t x, uint32_t* w
 
 // Forward work list: tile ids ordered heaviest-first (33 buckets of floor(log2(len+1)), descending; the order
 // inside a bucket is arbitrary); zeroes tile_depth. Single workgroup.
+// Several views at once: workgroup blockIdx.x builds the list of view blockIdx.x (pointer tables in the kernel arguments).
+struct WorkFwdViews {
+  const uint32_t* ranges[GSR_MAX_BATCH_VIEWS];
+  uint32_t* tile_depth[GSR_MAX_BATCH_VIEWS];
+  uint32_t* work[GSR_MAX_BATCH_VIEWS];
+  uint32_t* stats_host[GSR_MAX_BATCH_VIEWS];
+};
+struct WorkBwdViews {
+  const uint32_t* tile_depth[GSR_MAX_BATCH_VIEWS];
+  uint32_t* items[GSR_MAX_BATCH_VIEWS];
+  uint32_t items_cap[GSR_MAX_BATCH_VIEWS];
+};
+
 __global__ void __launch_bounds__(1024)
-k_work_order_fwd(const uint32_t n_tiles, const uint32_t* __restrict__ ranges, uint32_t* __restrict__ tile_depth,
-                 uint32_t* __restrict__ work, uint32_t* __restrict__ stats_host) {
+k_work_order_fwd(const uint32_t n_tiles, const WorkFwdViews wv) {
+  const uint32_t* __restrict__ ranges = wv.ranges[blockIdx.x];
+  uint32_t* __restrict__ tile_depth = wv.tile_depth[blockIdx.x];
+  uint32_t* __restrict__ work = wv.work[blockIdx.x];
+  uint32_t* __restrict__ stats_host = wv.stats_host[blockIdx.x];
   __shared__ uint32_t cnt[34], cur[34];
   const int tid = threadIdx.x;
   if (tid < 34) cnt[tid] = 0;
@@ -172,8 +188,10 @@ k_work_order_fwd(const uint32_t n_tiles, const uint32_t* __restrict__ ranges, ui
 // first) so that the in-order hardware dispatch does longest-first scheduling.
 // items[0] = number of items, items[2 + 2 i] = tile, items[3 + 2 i] = segment. Single workgroup.
 __global__ void __launch_bounds__(1024)
-k_work_order_bwd(const uint32_t n_tiles, const uint32_t* __restrict__ tile_depth, uint32_t* __restrict__ items,
-                 const uint32_t items_cap) {
+k_work_order_bwd(const uint32_t n_tiles, const WorkBwdViews wv) {
+  const uint32_t* __restrict__ tile_depth = wv.tile_depth[blockIdx.x];
+  uint32_t* __restrict__ items = wv.items[blockIdx.x];
+  const uint32_t items_cap = wv.items_cap[blockIdx.x];
   __shared__ uint32_t cnt[16], cur[16];
   const int tid = threadIdx.x;
   if (tid < 16) cnt[tid] = 0;
@@ -689,13 +707,35 @@ static int persistent_groups(int per_cu) {
 
 // The stage timers (GSR_STAGE_RENDER_FWD / _BWD) bracket the compositing kernel alone (not the work-list kernel), so
 // that bench.py's roofline entry and the rocprofv3 average of that kernel measure the same thing.
+// Work lists of n views (same image size) in one launch.
+int gsr_launch_work_order_fwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t stream) {
+  const uint32_t tiles = gsr_num_tiles(views[0].image_height, views[0].image_width);
+  WorkFwdViews wv = WorkFwdViews{};
+  for (int k = 0; k < n; ++k) {
+    wv.ranges[k] = bs[k].ranges; wv.tile_depth[k] = imgs[k].tile_depth; wv.work[k] = bs[k].tile_work;
+    wv.stats_host[k] = bs[k].stats_host;
+  }
+  hipLaunchKernelGGL(k_work_order_fwd, dim3((uint32_t)n), dim3(1024), 0, stream, tiles, wv);
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
+int gsr_launch_work_order_bwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t stream) {
+  const uint32_t tiles = gsr_num_tiles(views[0].image_height, views[0].image_width);
+  WorkBwdViews wv = WorkBwdViews{};
+  for (int k = 0; k < n; ++k) {
+    wv.tile_depth[k] = imgs[k].tile_depth; wv.items[k] = bs[k].tile_work + tiles; wv.items_cap[k] = bs[k].bwd_items_cap;
+  }
+  hipLaunchKernelGGL(k_work_order_bwd, dim3((uint32_t)n), dim3(1024), 0, stream, tiles, wv);
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
+
+// K6 of one view (its work list must have been built).
 int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, GsrImages& img,
                           hipStream_t stream, GsrProfile* prof) {
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
   const float4* splat = reinterpret_cast<const float4*>(geom.splat);
   uint32_t* work = b.tile_work;
-  hipLaunchKernelGGL(k_work_order_fwd, dim3(1), dim3(1024), 0, stream, tiles, b.ranges, img.tile_depth, work,
-                     b.stats_host);
   GsrStageTimer timer(prof, stream, GSR_STAGE_RENDER_FWD);
   if (b.fwd_mode == 1) {
     if (img.important_score)
@@ -727,10 +767,10 @@ int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinnin
 
 int gsr_launch_render_bwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, const GsrImages& img,
                           const GsrImageGrads& ig, GsrGrads& out, hipStream_t stream, GsrProfile* prof) {
+  // K7 of one view (its work list must have been built)
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
   uint32_t* items = b.tile_work + tiles;
   const uint32_t items_cap = b.bwd_items_cap;
-  hipLaunchKernelGGL(k_work_order_bwd, dim3(1), dim3(1024), 0, stream, tiles, img.tile_depth, items, items_cap);
   GsrStageTimer timer(prof, stream, GSR_STAGE_RENDER_BWD);
   hipLaunchKernelGGL(k_render_bwd, dim3(items_cap), dim3(256), 0, stream, v.image_width, v.image_height, items,
                      img.tile_depth, img.ckpt, b.ranges, b.point_list,

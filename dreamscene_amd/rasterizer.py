@@ -148,7 +148,7 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                    rotations, cov3D_precomp, want_keys, want_aux, mode, scene, batch):
     """Generator behind rasterize_forward_raw. With batch = dict(scratch=<this view's slice of the batch's projection
     scratch>, pinned=<pinned int64 [V]>, index=k, event=<Event>) it allocates and binds, YIELDS (view struct, geom struct)
-    for the caller to run gsr_forward_project_batch over all views, and continues with the render when resumed.
+    for the caller to run gsr_forward_project_batch / gsr_forward_render_batch over all views, and continues when resumed.
     Returns (outputs, state) through StopIteration.value."""
     """Forward through the C ABI. Returns (outputs dict, _State). Used by the autograd Function and by tests.
     scene (SURVEY.md 8f rank 2): {"models": [(xyz, scaling, rotation, opacity, features_dc, features_rest), ...] raw
@@ -315,17 +315,17 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
             buf, ptrs, offs = alloc_state(cap)
             bind(ptrs, cap, True)
             if batch is not None:
-                yield st.view, geom, g       # the caller projects all views of the batch in one go
+                # the caller projects (gsr_forward_project_batch) and renders (gsr_forward_render_batch) all views of
+                # the batch in one go, then resumes this generator for the bookkeeping
+                yield st.view, geom, g, b, im, cap
                 pinned, pidx, event = batch["pinned"], batch["index"], batch["event"]
             else:
                 pinned, pidx, event = ws.n_pinned, 0, ws.event
                 L.check(lib.gsr_forward_project_async(C.byref(st.view), C.byref(g), C.byref(geom), pinned.data_ptr(),
                                                       stream, prof), "gsr_forward_project_async")
                 event.record(torch.cuda.current_stream(dev))
-            L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), cap, C.byref(b), C.byref(im), stream, prof),
-                    "gsr_forward_render")
-            if batch is not None:
-                yield None                   # every view's render is enqueued before anybody waits for the counts
+                L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), cap, C.byref(b), C.byref(im), stream,
+                                               prof), "gsr_forward_render")
             event.synchronize()              # projection finished long before the render was even enqueued
             N = int(pinned[pidx].item()) if P > 0 else 0
             keep_bufs = (buf,)

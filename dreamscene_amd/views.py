@@ -60,7 +60,7 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
                                       event=ws.event))
                 for k, s in enumerate(settings_list)]
-        heads = [next(g) for g in gens]                       # allocated + bound; waiting for the projection
+        heads = [next(g) for g in gens]                       # allocated + bound: (view, geom, gaussians, binning, images, cap)
         views = (L.GsrView * V)(*[h[0] for h in heads])
         geoms = (L.GsrGeom * V)(*[h[1] for h in heads])
         gauss = (L.GsrGaussians * V)(*[h[2] for h in heads])
@@ -69,10 +69,14 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
         for k, h in enumerate(heads):
             h[1].sorted_idx = geoms[k].sorted_idx
         ws.event.record(torch.cuda.current_stream(dev))
-        for g in gens:
-            next(g)                                           # renders of all views enqueued
+        caps = {h[5] for h in heads}
+        assert len(caps) == 1, caps                           # same (P, H, W) -> same speculated capacity
+        bins = (L.GsrBinning * V)(*[h[3] for h in heads])
+        imgs = (L.GsrImages * V)(*[h[4] for h in heads])
+        L.check(lib.gsr_forward_render_batch(V, views, geoms, caps.pop(), bins, imgs, stream, prof),
+                "gsr_forward_render_batch")
         results = []
-        for g in gens:
+        for g in gens:                                        # counts are read only now: everything is enqueued
             try:
                 next(g)
                 raise RuntimeError("forward generator did not finish")

@@ -257,6 +257,11 @@ int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGa
 int gsr_forward_render(const GsrView*, const GsrGeom*, uint64_t n_pairs, GsrBinning*, GsrImages*, void* stream,
                        GsrProfile* prof);
 
+/* The same for n_views views projected together (gsr_forward_project_batch), all with buffers for n_pairs pairs:
+ * binning per view, the heaviest-first work lists of all views in one launch, then K6 per view. */
+int gsr_forward_render_batch(int32_t n_views, const GsrView* views, const GsrGeom* geoms, uint64_t n_pairs,
+                             GsrBinning* binnings, GsrImages* images, void* stream, GsrProfile* prof);
+
 /* K7 reverse traversal of every pixel's blend list + K8 chain rule to the inputs. */
 int gsr_backward(const GsrView*, const GsrGaussians*, const GsrGeom*, const GsrBinning*, const GsrImages*,
                  const GsrImageGrads*, GsrGrads*, void* stream, GsrProfile* prof);
