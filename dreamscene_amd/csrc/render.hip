@@ -655,12 +655,12 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const
       const float alpha = fminf(GSR_ALPHA_MAX, b.y * G);
       const bool hit = live && (power <= 0.0f) && (alpha >= GSR_ALPHA_MIN);
       if (__ballot(hit) == 0ull) continue;
-      float v[10];
-#pragma unroll
-      for (int q = 0; q < 10; ++q) v[q] = 0.f;
+      // per-lane factors of the 10 sums; lanes without a hit contribute zeros (only these three are cleared)
+      float qv = 0.f, wv = 0.f, gdl = 0.f;
       if (hit) {
         const float4 c = s2[j];
-        const float inv = __frcp_rn(1.0f - alpha);
+        // v_rcp_f32 (1 ulp): T is only reconstructed for the gradient weights here, no gate depends on it
+        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
         T = T * inv;
         const float w = alpha * T;
         float dL_dalpha;
@@ -676,13 +676,18 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const
         last_alpha = alpha;
         dL_dalpha -= (Tf * inv) * bg_dot;
         // raw moments of q = dL/dG * G over the pixels; K8 turns them into dL/dmean2D and dL/dconic
-        const float q = (b.y * dL_dalpha) * G;
-        const float m1 = q * dx, m2 = q * dy;
+        qv = (b.y * dL_dalpha) * G;
+        gdl = G * dL_dalpha;
+        wv = w;
+      }
+      float v[10];
+      {
+        const float m1 = qv * dx, m2 = qv * dy;
         v[0] = m1; v[1] = m2;
         v[2] = m1 * dx; v[3] = m1 * dy; v[4] = m2 * dy;
-        v[5] = G * dL_dalpha;
-        v[6] = w * gC0; v[7] = w * gC1; v[8] = w * gC2;
-        v[9] = w * gD;
+        v[5] = gdl;
+        v[6] = wv * gC0; v[7] = wv * gC1; v[8] = wv * gC2;
+        v[9] = wv * gD;
       }
       const float sred = reduce10(v, lane);
       if (commit) unsafeAtomicAdd(partials + 12 * (size_t)sid[j] + comp, sred);
