@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fwd-mode", type=int, default=None, help="force the forward compositing variant (0 / 1)")
     ap.add_argument("--unbatched", action="store_true",
                     help="render the views of a step one call at a time (GaussianRasterizer) instead of through "
                          "GaussianRasterizerViews (same kernels; the depth sorts of all views share their launches)")
@@ -76,6 +77,7 @@ def main():
     from dreamscene_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
     _lib.load()   # fail loudly if the HIP library is missing: there is no fallback
+    R.FWD_MODE = args.fwd_mode
     H = W = args.res
     if args.scene == "object":
         K, D = 16, args.sh_degree

@@ -79,3 +79,28 @@ def test_batched_views_fall_back_without_hint_or_on_big_grids(built_lib):
     res2 = rasterize_views_forward_raw(sets, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None)
     for (o1, _), (o2, _) in zip(res1, res2):
         assert torch.equal(o1["color"], o2["color"]) and torch.equal(o1["radii"], o2["radii"]) and o1["N"] == o2["N"]
+
+
+@pytest.mark.gpu
+def test_batched_views_recover_from_capacity_overflow(built_lib):
+    """The speculated pair capacity of the batch is too small for the next call (the splats grew): every view is redone
+    exactly; results equal the exact two-phase forward."""
+    from dreamscene_amd import rasterizer as R, synth
+    from dreamscene_amd.views import rasterize_views_forward_raw
+    dev = torch.device("cuda:0")
+    P, K, D, H, W, V = 2000, 4, 1, 96, 128, 3
+    g, _ = small_scene(P=P, H=H, W=W, K=K, seed=41, scale_mul=1.0)
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    cams = synth.object_cameras(V + 1, H, W, radius=3.0)[1:]
+    sets = [settings_for(c, [0, 0, 0], D, dev) for c in cams]
+    args = lambda sc: (t["means3D"], t["opacities"], t["shs"], None, sc, t["rotations"], None)
+    for _ in range(2):                                    # unbatched, then batched: the hint is the small N
+        small = rasterize_views_forward_raw(sets, *args(t["scales"]))
+    big_scales = t["scales"] * 6.0
+    res = rasterize_views_forward_raw(sets, *args(big_scales))
+    assert all(o["N"] > 2.5 * s_["N"] for (o, _), (s_, _) in zip(res, small)), "the test must overflow the speculation"
+    for s, (o, _) in zip(sets, res):
+        ref, _ = R.rasterize_forward_raw(s, *args(big_scales), mode="sync")
+        assert o["N"] == ref["N"]
+        assert torch.equal(o["radii"], ref["radii"])
+        assert torch.equal(o["color"], ref["color"]) and torch.equal(o["depth_alpha"], ref["depth_alpha"])
