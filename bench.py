@@ -49,8 +49,8 @@ def algorithmic_bytes(stage: str, P: int, N: int, HW: int, K: int, D: int) -> fl
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=500_000)
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--scene", choices=["object", "indoor"], default="object")
@@ -219,7 +219,7 @@ def main():
         capture[0] = True                 # one more (untimed) step keeping view 0's own gradients for the check
         out = step()
         torch.cuda.synchronize(dev)
-        cpu_baseline, grad_err = cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, out)
+        cpu_baseline, grad_err = cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, out, extra_cams=cams[1:])
 
     if rank == 0:
         views = world * args.steps * V
@@ -251,10 +251,10 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, hip_n_contrib=None):
+def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, hip_n_contrib=None, extra_cams=()):
     """Times the scalar C oracle (a CPU port of the same algorithm; the reference has no CPU path)
-    on ONE fwd+bwd view of the same workload, single thread, and reuses that run to report the HIP path's max
-    gradient error at the full benchmark size."""
+    on a bounded sample of the same workload (fwd+bwd views of the orbit, single thread, ~10 s), and reuses the first
+    view to report the HIP path's max gradient error at the full benchmark size."""
     from oracle import c_oracle as CO
     CO.build()
     P = g["means3D"].shape[0]
@@ -264,6 +264,17 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, hip_n_contrib=N
     f = CO.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
     b = CO.backward(v, f, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
     dt = time.perf_counter() - t0
+    n_timed, dt_total = 1, dt
+    for c2 in extra_cams:                 # more views of the same orbit: a steadier figure (bounded: ~1 s each)
+        v2 = CO.make_view(P, K, D, H, W, c2.tanfovx, c2.tanfovy, [1.0, 1.0, 1.0], c2.world_view_transform,
+                          c2.full_proj_transform, c2.camera_center)
+        t1 = time.perf_counter()
+        f2 = CO.forward(v2, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        CO.backward(v2, f2, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        dt_total += time.perf_counter() - t1
+        n_timed += 1
+        if dt_total > 12.0:
+            break
     img, da, radii, grads = hip_out
     names = ["dL_dmeans3D", "dL_dshs", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]
     worst, worst_frac, per = 0.0, 0.0, {}
@@ -276,9 +287,9 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, hip_n_contrib=N
         worst_frac = max(worst_frac, per[n]["frac_over_1e-5"])
     d_img = np.abs(img.detach().cpu().numpy() - f["image"]).max(axis=0)
     nc_diff = int((hip_n_contrib != f["n_contrib"]).sum()) if hip_n_contrib is not None else None
-    base = {"value": round(1.0 / dt, 5), "unit": "views/s", "cores": 1, "kind": "port",
-            "sample": f"1 fwd+bwd view of the same workload ({P} Gaussians @{W}x{H}) through oracle/gsr_oracle.c, "
-                      f"single thread, {dt:.1f} s; host has {os.cpu_count()} cores"}
+    base = {"value": round(n_timed / dt_total, 5), "unit": "views/s", "cores": 1, "kind": "port",
+            "sample": f"{n_timed} fwd+bwd views of the same workload ({P} Gaussians @{W}x{H}, orbit cameras) through "
+                      f"oracle/gsr_oracle.c, single thread, {dt_total:.1f} s; host has {os.cpu_count()} cores"}
     # hard gates (alpha < 1/255, T < 1e-4) put a few (pixel, splat) pairs on the other side of a rounding
     # difference at this size (SEMANTICS.md section 6): report how many pixels / entries, not only the max
     return base, {"bit_exact_radii": bool(np.array_equal(radii.cpu().numpy(), f["radii"])),
