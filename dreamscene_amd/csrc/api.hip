@@ -78,8 +78,18 @@ int check_gaussians(const GsrView* v, const GsrGaussians* g) {
 
 // The views of a batch share their Gaussians; only `scales` may be a different tensor per view.
 bool same_except_scales(const GsrGaussians& a, const GsrGaussians& b) {
+  if (a.scene || b.scene) {   // scene input: the same models for every view; noise samples / returned scales may differ
+    if (!a.scene || !b.scene || a.scene->n_models != b.scene->n_models) return false;
+    for (int m = 0; m < a.scene->n_models; ++m) {
+      const GsrModel &x = a.scene->models[m], &y = b.scene->models[m];
+      if (x.count != y.count || x.xyz != y.xyz || x.scaling != y.scaling || x.rotation != y.rotation ||
+          x.opacity != y.opacity || x.features_dc != y.features_dc || x.features_rest != y.features_rest)
+        return false;
+    }
+    return true;
+  }
   return a.means3D == b.means3D && a.opacities == b.opacities && a.shs == b.shs && a.colors_precomp == b.colors_precomp &&
-         a.rotations == b.rotations && a.cov3D_precomp == b.cov3D_precomp && a.scene == b.scene &&
+         a.rotations == b.rotations && a.cov3D_precomp == b.cov3D_precomp &&
          (a.scales != nullptr) == (b.scales != nullptr);
 }
 
@@ -386,7 +396,7 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
       o.dL_dmeans3D = o0.dL_dmeans3D; o.dL_dopacities = o0.dL_dopacities; o.dL_dshs = o0.dL_dshs;
       o.dL_dcolors = o0.dL_dcolors; o.dL_drotations = o0.dL_drotations;
       if (!per_view_scales) o.dL_dscales = o0.dL_dscales;
-      o.dL_dcov3D = o0.dL_dcov3D; o.scene = o0.scene;
+      o.dL_dcov3D = o0.dL_dcov3D;      // (o.scene stays view k's own table: same model tensors, its own dL_dscales_out)
       o.accumulate = (k > 0) ? 1 : o0.accumulate;
       GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
       const int rc2 = gsr_launch_preprocess_bwd(views[k], *g, geoms[k], o, stream);

@@ -618,6 +618,10 @@ struct K1Views {
   int32_t sh_degree[GSR_MAX_BATCH_VIEWS];
   int32_t per_view_scales;
   const float* scales[GSR_MAX_BATCH_VIEWS];
+  // scene input (raw leaves): per-view noise samples and the per-view activated scales handed back to the caller
+  const float* scale_noise[GSR_MAX_BATCH_VIEWS];
+  const float* sh_noise[GSR_MAX_BATCH_VIEWS];
+  float* scales_out[GSR_MAX_BATCH_VIEWS];
   float* splat[GSR_MAX_BATCH_VIEWS];
   int32_t* radii[GSR_MAX_BATCH_VIEWS];
   uint32_t* tiles_touched[GSR_MAX_BATCH_VIEWS];
@@ -676,6 +680,102 @@ k_preprocess_views(const GsrView v, const GsrGaussians g, const K1Views vb) {
       sh_basis(vb.sh_degree[vv], dx, dy, dz, b);
       float acc[3];
       sh_colour_n<KT>(vb.sh_degree[vv], shr, b, acc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
+    }
+    vb.radii[vv][i] = pr.radius;
+    vb.tiles_touched[vv][i] = pr.ntiles;
+    vb.depth_keys[vv][i] = pr.vis ? __float_as_uint(pr.depth) : 0xFFFFFFFFu;
+    vb.rects[vv][i] = pr.rect;
+    if (pr.vis) {
+      float4* o = reinterpret_cast<float4*>(vb.splat[vv] + 12 * i);
+      o[0] = make_float4(pr.q0x, pr.q0y, pr.ca, pr.cb);
+      o[1] = make_float4(pr.cc, opac, pr.depth, rgb[0]);
+      o[2] = make_float4(rgb[1], rgb[2], tau, 0.f);
+    }
+  }
+}
+
+
+// K1 over several views of a SCENE (raw leaves of several models, activations fused; see k_preprocess<K, true>): the
+// raw rows are read once, exp / normalize / sigmoid are applied once, the per-view scale noise (and SH noise) per view.
+template <int KT>
+__global__ void __launch_bounds__(256)
+k_preprocess_views_scene(const GsrView v, const SceneTab sc, const K1Views vb) {
+  constexpr int F = 3 * KT;
+  const int W = v.image_width, H = v.image_height;
+  const Rows rw = resolve_rows<true>(sc, v.P);
+  if (!rw.ok) return;
+  const int64_t i = rw.i, row = rw.row;
+  const int m = rw.m;
+  const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+  const float* xyz = sc.xyz[m];
+  const float px = xyz[3 * row], py = xyz[3 * row + 1], pz = xyz[3 * row + 2];
+  float aact[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) aact[k] = expf(sc.scaling[m][3 * row + k]);
+  bool have_R = false, have_cov = false, have_sh = false;
+  float R[9], c6[6], shr[F];
+  float opac = 0.f, tau = -1.f;
+  for (int vv = 0; vv < vb.nv; ++vv) {
+    const float* sn = vb.scale_noise[vv];
+    float sa[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      sa[k] = sn ? fmaxf(aact[k] + sn[3 * i + k] * ((kSqrtPoint2 * aact[k]) / 4.0f), 0.0f) : aact[k];
+    if (vb.scales_out[vv]) {
+      float* so = vb.scales_out[vv];
+      so[3 * i] = sa[0]; so[3 * i + 1] = sa[1]; so[3 * i + 2] = sa[2];
+    }
+    ViewConst vc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
+    const float tfx = vb.tanfovx[vv], tfy = vb.tanfovy[vv];
+    const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
+    Proj pr;
+    pr.vis = false; pr.radius = 0; pr.ntiles = 0; pr.rect = 0;
+    float ndcx, ndcy;
+    if (proj_in_front(vc, px, py, pz, ndcx, ndcy)) {
+      if (!have_R) {
+        have_R = true;
+        float4 q = *reinterpret_cast<const float4*>(sc.rotation[m] + 4 * row);
+        const float nrm = act_quat_norm(q);
+        q = make_float4(q.x / nrm, q.y / nrm, q.z / nrm, q.w / nrm);
+        quat_to_R(q, R);
+      }
+      if (!have_cov || sn) {
+        have_cov = true;
+        const float mod = v.scale_modifier;
+        cov3d_from(mod * sa[0], mod * sa[1], mod * sa[2], R, c6);
+      }
+      proj_footprint(vc, px, py, pz, c6, fx, fy, 1.3f * tfx, 1.3f * tfy, W, H, gx, gy, ndcx, ndcy, pr);
+    }
+    float rgb[3] = {0.f, 0.f, 0.f};
+    if (pr.vis) {
+      if (!have_sh) {
+        have_sh = true;
+        load_row<3>(sc.dc[m] + row * 3, shr);
+        if constexpr (KT > 1) load_row<F - 3>(sc.rest[m] + row * (F - 3), shr + 3);
+        opac = act_sigmoid(sc.opacity[m][row]);
+        tau = splat_tau(opac);
+      }
+      float dx = px - vc.cam[0], dy = py - vc.cam[1], dz = pz - vc.cam[2];
+      const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+      dx = dx / len; dy = dy / len; dz = dz / len;
+      float b[16];
+      sh_basis(vb.sh_degree[vv], dx, dy, dz, b);
+      float acc[3];
+      if (vb.sh_noise[vv]) {
+        float shv[F];
+        const float* nz = vb.sh_noise[vv] + (size_t)i * F;
+#pragma unroll
+        for (int k = 0; k < F; ++k) shv[k] = shr[k] + nz[k] * (kSqrtPoint2 * shr[k]);
+        sh_colour_n<KT>(vb.sh_degree[vv], shv, b, acc);
+      } else {
+        sh_colour_n<KT>(vb.sh_degree[vv], shr, b, acc);
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
     }
@@ -1168,6 +1268,10 @@ struct K8Views {
   int32_t per_view_scales;
   const float* scales[GSR_MAX_BATCH_VIEWS];
   float* dL_dscales[GSR_MAX_BATCH_VIEWS];
+  // scene input (raw leaves): per-view noise samples, per-view gradient arriving through the returned scales
+  const float* scale_noise[GSR_MAX_BATCH_VIEWS];
+  const float* sh_noise[GSR_MAX_BATCH_VIEWS];
+  const float* dL_dscales_out[GSR_MAX_BATCH_VIEWS];
 };
 
 template <int KT, bool PVS>   // PVS: per-view scales
@@ -1340,6 +1444,206 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   }
 }
 
+
+// K8 over several views of a SCENE: the raw rows are read once, every view has its own (possibly noisy) scales, the
+// gradients of the raw leaves are summed over the views in registers and written once per model tensor.
+template <int KT>
+__global__ void __launch_bounds__(256)
+k_preprocess_bwd_views_scene(const GsrView v, const SceneTab sc, const SceneGradTab sg, const K8Views vb,
+                             const GsrGrads out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int F = 3 * KT;
+  const int W = v.image_width, H = v.image_height;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const Rows rw = resolve_rows<true>(sc, v.P);
+  const int64_t i = rw.i, row = rw.row, wave_first = rw.wave_row;
+  const int m = rw.m, n_valid = rw.n_valid;
+  const bool ok = rw.ok;
+  const float mod = v.scale_modifier;
+  constexpr int stride = F | 1;
+  float* lw = lds + wave * (64 * stride);
+  float* sh = lw + lane * stride;
+
+  bool any = false, has_gs = false;
+  for (int vv = 0; vv < vb.nv; ++vv) {
+    any = any || (ok && vb.radii[vv][i] > 0);
+    has_gs = has_gs || (vb.dL_dscales_out[vv] != nullptr);
+  }
+  const unsigned long long amask = __ballot(any);
+
+  float px = 0, py = 0, pz = 0, R[9], aact[3] = {0.f, 0.f, 0.f}, qnorm = 1.0f;
+  float4 q = make_float4(1, 0, 0, 0);
+  if (ok && (any || has_gs)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) aact[k] = expf(sc.scaling[m][3 * row + k]);
+  }
+  if (any) {
+    const float* xyz = sc.xyz[m];
+    px = xyz[3 * row]; py = xyz[3 * row + 1]; pz = xyz[3 * row + 2];
+    q = *reinterpret_cast<const float4*>(sc.rotation[m] + 4 * row);
+    qnorm = act_quat_norm(q);
+    q = make_float4(q.x / qnorm, q.y / qnorm, q.z / qnorm, q.w / qnorm);
+    quat_to_R(q, R);
+    load_row<3>(sc.dc[m] + row * 3, sh);                     // raw SH row, kept (read only) in the lane's LDS row
+    if constexpr (KT > 1) load_row<F - 3>(sc.rest[m] + row * (F - 3), sh + 3);
+  }
+
+  float dsh[F];
+#pragma unroll
+  for (int k = 0; k < F; ++k) dsh[k] = 0.f;
+  float dp[3] = {0.f, 0.f, 0.f}, gop = 0.f, drot[4] = {0.f, 0.f, 0.f, 0.f}, dsraw[3] = {0.f, 0.f, 0.f};
+
+  for (int vv = 0; vv < vb.nv; ++vv) {
+    const bool vis = ok && (vb.radii[vv][i] > 0);
+    float gndx = 0.f, gndy = 0.f;
+    // this view's scales and their derivative w.r.t. the raw (log) scaling
+    float sa[3] = {0.f, 0.f, 0.f}, dsc[3] = {0.f, 0.f, 0.f};
+    if (ok && (vis || vb.dL_dscales_out[vv])) {
+      const float* sn = vb.scale_noise[vv];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float n = sn ? sn[3 * i + k] : 0.f;
+        const float pre = sn ? aact[k] + n * ((kSqrtPoint2 * aact[k]) / 4.0f) : aact[k];
+        sa[k] = sn ? fmaxf(pre, 0.0f) : aact[k];
+        dsc[k] = sn ? (pre >= 0.0f ? aact[k] * (1.0f + n * (kSqrtPoint2 / 4.0f)) : 0.0f) : aact[k];
+      }
+      if (vb.dL_dscales_out[vv]) {   // loss on the returned scales: reaches every Gaussian
+        const float* gs = vb.dL_dscales_out[vv];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dsraw[k] += gs[3 * i + k] * dsc[k];
+      }
+    }
+    if (vis) {
+      ViewConst vc;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
+      const float tfx = vb.tanfovx[vv], tfy = vb.tanfovy[vv];
+      const int D = vb.sh_degree[vv];
+      const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
+      const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
+      const float4 pa = pp[0], pb = pp[1], pc = pp[2];
+      gop += pb.y;
+      const float grgb[3] = {pb.z, pb.w, pc.x};
+      // (1) colour -> SH coefficients (through this view's noise), view direction
+      {
+        const float vx = px - vc.cam[0], vy = py - vc.cam[1], vz = pz - vc.cam[2];
+        const float len = sqrtf((vx * vx + vy * vy) + vz * vz);
+        const float x = vx / len, y = vy / len, z = vz / len;
+        float b[16];
+        sh_basis(D, x, y, z, b);
+        const float* nz = vb.sh_noise[vv] ? vb.sh_noise[vv] + (size_t)i * F : nullptr;
+        float shv[F];
+#pragma unroll
+        for (int k = 0; k < F; ++k) shv[k] = nz ? sh[k] + nz[k] * (kSqrtPoint2 * sh[k]) : sh[k];
+        float acc[3];
+        sh_colour_n<KT>(D, shv, b, acc);
+        float gch[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gch[c] = (acc[c] + 0.5f < 0.0f) ? 0.0f : grgb[c];
+        float s[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] = 0.f;
+        const int nb = (D + 1) * (D + 1);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          if (k < nb) {
+            s[k] = (shv[3 * k] * gch[0] + shv[3 * k + 1] * gch[1]) + shv[3 * k + 2] * gch[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float gk = b[k] * gch[c];
+              dsh[3 * k + c] += nz ? gk * (1.0f + kSqrtPoint2 * nz[3 * k + c]) : gk;
+            }
+          }
+        }
+        float ddx, ddy, ddz;
+        sh_ddir(D, x, y, z, s, ddx, ddy, ddz);
+        const float dot = (x * ddx + y * ddy) + z * ddz;
+        dp[0] += (ddx - x * dot) / len; dp[1] += (ddy - y * dot) / len; dp[2] += (ddz - z * dot) / len;
+      }
+      // (2)-(6) geometry of this view with this view's scales
+      const float s3[3] = {mod * sa[0], mod * sa[1], mod * sa[2]};
+      float c6[6];
+      cov3d_from(s3[0], s3[1], s3[2], R, c6);
+      Ewa e;
+      ewa_forward(vc, px, py, pz, c6, fx, fy, 1.3f * tfx, 1.3f * tfy, e);
+      float dSv[9], dview[12], dproj[12];
+      geom_backward(vc, e, fx, fy, W, H, px, py, pz, pa.x, pa.y, pa.z, pa.w, pb.x, pc.y, false, gndx, gndy, dSv, dp, dview,
+                    dproj);
+      float ds_v[3], dr_v[4];
+      sigma_backward(dSv, R, s3, mod, q, ds_v, dr_v);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dsraw[k] += ds_v[k] * dsc[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) drot[k] += dr_v[k];
+      if (out.stat_denom) {
+        out.stat_xyz_gradient_accum[i] += sqrtf(gndx * gndx + gndy * gndy);
+        out.stat_denom[i] += 1.0f;
+        out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)vb.radii[vv][i]);
+      }
+    }
+    if (ok) {
+      float* m2 = vb.dL_dmeans2D[vv];
+      m2[3 * i] = gndx; m2[3 * i + 1] = gndy; m2[3 * i + 2] = 0.f;
+    }
+  }
+
+  // gradient rows -> LDS (zeros for Gaussians no view saw) -> coalesced write-back into features_dc / features_rest
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane < n_valid) {
+#pragma unroll
+    for (int k = 0; k < F; ++k) sh[k] = dsh[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const bool acc = out.accumulate != 0;
+  if (!(acc && amask == 0ull)) {
+    if (sg.dc[m]) stage_rows_out<3>(sg.dc[m] + wave_first * 3, 3, 0, stride, n_valid, lw, acc, amask);
+    if constexpr (KT > 1) {
+      if (sg.rest[m]) stage_rows_out<F - 3>(sg.rest[m] + wave_first * (F - 3), F - 3, 3, stride, n_valid, lw, acc, amask);
+    }
+  }
+
+  if (ok) {
+    if (acc && !any) {
+      float* o = sg.scaling[m];
+      if (has_gs && o) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[3 * row + k] += dsraw[k];
+      }
+    } else {
+      // through q = raw / |raw| and sigmoid
+      const float qd = ((q.x * drot[0] + q.y * drot[1]) + q.z * drot[2]) + q.w * drot[3];
+      const float dr[4] = {(drot[0] - q.x * qd) / qnorm, (drot[1] - q.y * qd) / qnorm, (drot[2] - q.z * qd) / qnorm,
+                           (drot[3] - q.w * qd) / qnorm};
+      float gop_raw = 0.f;
+      if (any) {
+        const float sgm = act_sigmoid(sc.opacity[m][row]);
+        gop_raw = gop * (sgm * (1.0f - sgm));
+      }
+      float* o;
+      if ((o = sg.xyz[m])) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[3 * row + k] = acc ? o[3 * row + k] + dp[k] : dp[k];
+      }
+      if ((o = sg.scaling[m])) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[3 * row + k] = acc ? o[3 * row + k] + dsraw[k] : dsraw[k];
+      }
+      if ((o = sg.rotation[m])) {
+        float4 t = make_float4(dr[0], dr[1], dr[2], dr[3]);
+        if (acc) {
+          const float4 old = *reinterpret_cast<const float4*>(o + 4 * row);
+          t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w;
+        }
+        *reinterpret_cast<float4*>(o + 4 * row) = t;
+      }
+      if ((o = sg.opacity[m])) o[row] = acc ? o[row] + gop_raw : gop_raw;
+    }
+  }
+}
+
 }  // namespace
 
 uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P);   // binning.hip: first key buffer of the depth sort
@@ -1450,6 +1754,8 @@ int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const Gsr
 // no camera gradients, no scene table (the caller falls back to one gsr_launch_preprocess_bwd per view otherwise).
 bool gsr_preprocess_bwd_views_supported(const GsrView& v, const GsrGaussians& g, const GsrGrads& out) {
   const int K = v.sh_stride;
+  if (g.scene)
+    return out.scene && (K == 1 || K == 4 || K == 9 || K == 16) && !out.dL_dview && !out.dL_dproj && !out.dL_dcampos;
   return g.shs && !g.scene && g.scales && g.rotations && !g.cov3D_precomp && !g.colors_precomp &&
          (K == 1 || K == 4 || K == 9 || K == 16) && !out.dL_dview && !out.dL_dproj && !out.dL_dcampos &&
          out.dL_dshs && out.dL_dscales && out.dL_drotations && out.dL_dmeans3D && out.dL_dopacities;
@@ -1461,6 +1767,10 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
   K8Views vb = K8Views{};
   vb.nv = n_views;
   for (int k = 0; k < n_views; ++k) {
+    if (g.scene) {
+      vb.scale_noise[k] = gs[k].scene->scale_noise; vb.sh_noise[k] = gs[k].scene->sh_noise;
+      vb.dL_dscales_out[k] = outs[k].scene ? outs[k].scene->dL_dscales_out : nullptr;
+    }
     vb.scales[k] = gs[k].scales; vb.dL_dscales[k] = outs[k].dL_dscales;
     if (gs[k].scales != g.scales) vb.per_view_scales = 1;
     vb.viewmatrix[k] = views[k].viewmatrix; vb.projmatrix[k] = views[k].projmatrix; vb.campos[k] = views[k].campos;
@@ -1468,8 +1778,24 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
     vb.radii[k] = geoms[k].radii; vb.partials[k] = outs[k].partials; vb.dL_dmeans2D[k] = outs[k].dL_dmeans2D;
   }
   const GsrView& v = views[0];
-  const uint32_t nb = gsr_num_blocks(v.P);
   const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
+  if (g.scene) {
+    SceneTab t; SceneGradTab gt;
+    const uint32_t nbs = scene_tables(*g.scene, outs[0].scene, t, gt);
+#define GSR_LAUNCH_K8VS(KT) \
+  hipLaunchKernelGGL(k_preprocess_bwd_views_scene<KT>, dim3(nbs), dim3(256), lds, stream, v, t, gt, vb, outs[0])
+    switch (v.sh_stride) {
+      case 16: GSR_LAUNCH_K8VS(16); break;
+      case 9: GSR_LAUNCH_K8VS(9); break;
+      case 4: GSR_LAUNCH_K8VS(4); break;
+      case 1: GSR_LAUNCH_K8VS(1); break;
+      default: return GSR_EINVAL;
+    }
+#undef GSR_LAUNCH_K8VS
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+  }
+  const uint32_t nb = gsr_num_blocks(v.P);
 #define GSR_LAUNCH_K8V(KT)                                                                                       \
   if (vb.per_view_scales)                                                                                        \
     hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, outs[0]);  \
@@ -1490,6 +1816,7 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
 // K1 for n_views views of the same Gaussians in one pass (shs with K in {1,4,9,16}, scales + rotations, no scene table).
 bool gsr_preprocess_views_supported(const GsrView& v, const GsrGaussians& g) {
   const int K = v.sh_stride;
+  if (g.scene) return K == 1 || K == 4 || K == 9 || K == 16;
   return g.shs && !g.scene && g.scales && g.rotations && !g.cov3D_precomp && !g.colors_precomp &&
          (K == 1 || K == 4 || K == 9 || K == 16);
 }
@@ -1500,6 +1827,10 @@ int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaus
   K1Views vb = K1Views{};
   vb.nv = n_views;
   for (int k = 0; k < n_views; ++k) {
+    if (g.scene) {
+      vb.scale_noise[k] = gs[k].scene->scale_noise; vb.sh_noise[k] = gs[k].scene->sh_noise;
+      vb.scales_out[k] = gs[k].scene->scales_out;
+    }
     vb.scales[k] = gs[k].scales;
     if (gs[k].scales != g.scales) vb.per_view_scales = 1;
     vb.viewmatrix[k] = views[k].viewmatrix; vb.projmatrix[k] = views[k].projmatrix; vb.campos[k] = views[k].campos;
@@ -1508,6 +1839,21 @@ int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaus
     vb.depth_keys[k] = gsr_depth_keys(geoms[k], views[k].P); vb.rects[k] = gsr_tile_rects(geoms[k], views[k].P);
   }
   const GsrView& v = views[0];
+  if (g.scene) {
+    SceneTab t; SceneGradTab gt;
+    const uint32_t nbs = scene_tables(*g.scene, nullptr, t, gt);
+#define GSR_LAUNCH_K1VS(KT) hipLaunchKernelGGL(k_preprocess_views_scene<KT>, dim3(nbs), dim3(256), 0, stream, v, t, vb)
+    switch (v.sh_stride) {
+      case 16: GSR_LAUNCH_K1VS(16); break;
+      case 9: GSR_LAUNCH_K1VS(9); break;
+      case 4: GSR_LAUNCH_K1VS(4); break;
+      case 1: GSR_LAUNCH_K1VS(1); break;
+      default: return GSR_EINVAL;
+    }
+#undef GSR_LAUNCH_K1VS
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+  }
   const uint32_t nb = gsr_num_blocks(v.P);
 #define GSR_LAUNCH_K1V(KT) hipLaunchKernelGGL(k_preprocess_views<KT>, dim3(nb), dim3(256), 0, stream, v, g, vb)
   switch (v.sh_stride) {

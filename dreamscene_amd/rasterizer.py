@@ -483,6 +483,68 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
     return o
 
 
+def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, model_grads=None, accumulate: bool = False,
+                                       dL_dscales_outs=None) -> dict:
+    """Backward of several views of the same SCENE (raw leaves, rasterize_forward_raw(scene=...) per view or batched):
+    K7 per view, one K8 pass over all views; the gradients of the raw leaves are the sums over the views, written to (or,
+    with accumulate, added to) one tensor per leaf. dL_dscales_outs: per view, the gradient arriving through the returned
+    scales (or None)."""
+    lib = L.load()
+    V = len(states)
+    st0 = states[0]
+    dev, P, K = st0.dev, st0.P, st0.K
+    f32 = torch.float32
+    sc0, keep0 = st0.scene
+    outs = []
+    for m in range(sc0.n_models):
+        leaves = keep0[m]
+        given = model_grads[m] if model_grads is not None else (None,) * 6
+        row = []
+        for t, gt in zip(leaves, given):
+            if t is None or (t.numel() == 0 and gt is None):
+                row.append(None if t is None else torch.zeros_like(t))
+                continue
+            if gt is None:
+                if accumulate:
+                    raise ValueError("accumulate=True needs the gradient tensors to add to")
+                gt = torch.empty_like(t)
+            elif gt.shape != t.shape or gt.dtype != f32 or not gt.is_contiguous() or gt.device != dev:
+                raise ValueError("model gradient tensors must match the raw leaves (shape, fp32, contiguous, device)")
+            row.append(gt)
+        outs.append(tuple(row))
+    m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
+    partials = torch.empty((V, max(P, 1), 12), dtype=f32, device=dev)
+    views = (L.GsrView * V)(*[st.view for st in states])
+    gauss = (L.GsrGaussians * V)(*[st.gauss for st in states])
+    geoms = (L.GsrGeom * V)(*[st.geom for st in states])
+    bins = (L.GsrBinning * V)(*[st.binning for st in states])
+    imgs = (L.GsrImages * V)(*[st.images for st in states])
+    igs = (L.GsrImageGrads * V)()
+    grs = (L.GsrGrads * V)()
+    sgs = [L.GsrSceneGrads() for _ in range(V)]
+    keep = []
+    for k in range(V):
+        gc, gda = _prep(dL_dcolors[k], "dL_dcolor", dev), _prep(dL_ddepth_alphas[k], "dL_ddepth_alpha", dev)
+        gso = _prep(dL_dscales_outs[k], "dL_dscales_out", dev) if dL_dscales_outs is not None else None
+        keep += [gc, gda, gso]
+        igs[k].dL_dcolor, igs[k].dL_ddepth_alpha = gc.data_ptr(), gda.data_ptr()
+        for m, row in enumerate(outs):
+            mg = sgs[k].models[m]
+            mg.xyz, mg.scaling, mg.rotation, mg.opacity = _ptr(row[0]), _ptr(row[1]), _ptr(row[2]), _ptr(row[3])
+            mg.features_dc, mg.features_rest = _ptr(row[4]), (_ptr(row[5]) if K > 1 else None)
+        sgs[k].dL_dscales_out = _ptr(gso)
+        grs[k].scene = C.pointer(sgs[k])
+        grs[k].dL_dmeans2D = m2d[k].data_ptr()
+        grs[k].partials = partials[k].data_ptr()
+        grs[k].accumulate = int(bool(accumulate))
+        _bind_stats(grs[k], P, dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    prof = PROFILE.handle if PROFILE is not None else None
+    with torch.cuda.device(dev):
+        L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof), "gsr_backward_views")
+    return dict(dL_dmeans2D=m2d[:, :P], model_grads=outs)
+
+
 def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=None, accumulate: bool = False) -> dict:
     """Backward of several views of the same Gaussians through gsr_backward_views: K7 per view, one K8 pass over all
     views. Returns the SUMMED parameter gradients (written to / added to the arena's views when given) and the per-view

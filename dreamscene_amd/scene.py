@@ -81,6 +81,54 @@ def rasterize_models(settings, models: Sequence, means2D: torch.Tensor, scale_no
     return _RasterizeModels.apply(settings, scale_noise, sh_noise, means2D, *flat)
 
 
+class _RasterizeModelsViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, settings_list, scale_noise, sh_noise, means2D, *leaves):
+        from .views import rasterize_views_forward_raw
+        V = len(settings_list)
+        models = [tuple(leaves[6 * m:6 * m + 6]) for m in range(len(leaves) // 6)]
+        scenes = [dict(models=models, scale_noise=None if scale_noise is None else scale_noise[k],
+                       sh_noise=None if sh_noise is None else sh_noise[k]) for k in range(V)]
+        res = rasterize_views_forward_raw(settings_list, None, None, None, None, None, None, None, scenes=scenes)
+        ctx.states = [st for _, st in res]
+        ctx.set_materialize_grads(False)
+        outs = []
+        for o, _ in res:
+            ctx.mark_non_differentiable(o["radii"])
+            outs += [o["color"], o["radii"], o["depth_alpha"], o["act_scales"]]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        sts = ctx.states
+        V = len(sts)
+        H, W, dev = sts[0].view.image_height, sts[0].view.image_width, sts[0].dev
+        z = lambda c: torch.zeros((c, H, W), dtype=torch.float32, device=dev)
+        gcs = [grads[4 * k] if grads[4 * k] is not None else z(3) for k in range(V)]
+        gdas = [grads[4 * k + 2] if grads[4 * k + 2] is not None else z(2) for k in range(V)]
+        gss = [grads[4 * k + 3] for k in range(V)]
+        bufs = MODEL_GRAD_BUFFERS
+        o = R.rasterize_backward_views_scene_raw(sts, gcs, gdas, model_grads=bufs, accumulate=bufs is not None,
+                                                 dL_dscales_outs=gss if any(g is not None for g in gss) else None)
+        flat = []
+        for row in o["model_grads"]:
+            flat.extend([None] * 6 if bufs is not None else row)
+        return (None, None, None, o["dL_dmeans2D"], *flat)
+
+
+def rasterize_models_views(settings_list, models: Sequence, means2D: torch.Tensor,
+                           scale_noise: Optional[torch.Tensor] = None, sh_noise: Optional[torch.Tensor] = None):
+    """The views of one optimizer step of several GaussianModels in one call (raw leaves, activations and per-view noise
+    fused: scale_noise [V,P,3], sh_noise [V,P,K,3] N(0,1) samples or None). means2D: [V,P,3] zeros. Returns a list of
+    (image, radii, depth_alpha, scales) per view; the parameter gradients are the sums over the views."""
+    flat = []
+    for m in models:
+        flat.extend(_leaves(m))
+    V = len(settings_list)
+    out = _RasterizeModelsViews.apply(tuple(settings_list), scale_noise, sh_noise, means2D, *flat)
+    return [tuple(out[4 * k:4 * k + 4]) for k in range(V)]
+
+
 def scene_render(models: Sequence, camera, bg_color: torch.Tensor, active_sh_degree: int,
                  scaling_modifier: float = 1.0, black_video: bool = False, sh_deg_aug_ratio: float = 0.1,
                  bg_aug_ratio: float = 0.3, shs_aug_ratio: float = 1.0, scale_aug_ratio: float = 1.0,

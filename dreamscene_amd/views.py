@@ -26,11 +26,15 @@ MAX_VIEWS = 16
 
 
 def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs, colors_precomp, scales, rotations,
-                                cov3D_precomp, want_aux: bool = False):
+                                cov3D_precomp, want_aux: bool = False, scenes=None):
     """Forward of V views. Returns [(outputs, state)] like rasterize_forward_raw per view.
-    scales: [P,3] shared by the views, or [V,P,3] (every view its own, e.g. with the trainers' per-view scale noise)."""
+    scales: [P,3] shared by the views, or [V,P,3] (every view its own, e.g. with the trainers' per-view scale noise).
+    scenes: instead of the tensors, one `scene` dict per view (rasterize_forward_raw): the same models' raw leaves,
+    per-view noise samples."""
     lib = L.load()
     V = len(settings_list)
+    if scenes is not None:
+        return _views_forward_scene(lib, settings_list, scenes, want_aux)
     per_view = scales is not None and scales.dim() == 3
     if per_view and scales.shape[0] != V:
         raise ValueError(f"per-view scales must be [V,P,3] with V = {V}")
@@ -60,29 +64,66 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
                                       event=ws.event))
                 for k, s in enumerate(settings_list)]
-        heads = [next(g) for g in gens]                       # allocated + bound: (view, geom, gaussians, binning, images, cap)
-        views = (L.GsrView * V)(*[h[0] for h in heads])
-        geoms = (L.GsrGeom * V)(*[h[1] for h in heads])
-        gauss = (L.GsrGaussians * V)(*[h[2] for h in heads])
-        L.check(lib.gsr_forward_project_batch(V, views, gauss, geoms, ws.batch_pinned.data_ptr(), stream, prof),
-                "gsr_forward_project_batch")
-        for k, h in enumerate(heads):
-            h[1].sorted_idx = geoms[k].sorted_idx
-        ws.event.record(torch.cuda.current_stream(dev))
-        caps = {h[5] for h in heads}
-        assert len(caps) == 1, caps                           # same (P, H, W) -> same speculated capacity
-        bins = (L.GsrBinning * V)(*[h[3] for h in heads])
-        imgs = (L.GsrImages * V)(*[h[4] for h in heads])
-        L.check(lib.gsr_forward_render_batch(V, views, geoms, caps.pop(), bins, imgs, stream, prof),
-                "gsr_forward_render_batch")
-        results = []
-        for g in gens:                                        # counts are read only now: everything is enqueued
-            try:
-                next(g)
-                raise RuntimeError("forward generator did not finish")
-            except StopIteration as e:
-                results.append(e.value)
+        results = _drive_batch(lib, ws, gens, V, dev, stream, prof)
     return results
+
+
+def _drive_batch(lib, ws, gens, V, dev, stream, prof):
+    """Common tail of the batched forwards: project all views, render all views, then let every generator finish."""
+    heads = [next(g) for g in gens]                       # (view, geom, gaussians, binning, images, cap)
+    views = (L.GsrView * V)(*[h[0] for h in heads])
+    geoms = (L.GsrGeom * V)(*[h[1] for h in heads])
+    gauss = (L.GsrGaussians * V)(*[h[2] for h in heads])
+    L.check(lib.gsr_forward_project_batch(V, views, gauss, geoms, ws.batch_pinned.data_ptr(), stream, prof),
+            "gsr_forward_project_batch")
+    for k, h in enumerate(heads):
+        h[1].sorted_idx = geoms[k].sorted_idx
+    ws.event.record(torch.cuda.current_stream(dev))
+    caps = {h[5] for h in heads}
+    assert len(caps) == 1, caps
+    bins = (L.GsrBinning * V)(*[h[3] for h in heads])
+    imgs = (L.GsrImages * V)(*[h[4] for h in heads])
+    L.check(lib.gsr_forward_render_batch(V, views, geoms, caps.pop(), bins, imgs, stream, prof),
+            "gsr_forward_render_batch")
+    results = []
+    for g in gens:
+        try:
+            next(g)
+            raise RuntimeError("forward generator did not finish")
+        except StopIteration as e:
+            results.append(e.value)
+    return results
+
+
+def _views_forward_scene(lib, settings_list, scenes, want_aux):
+    V = len(settings_list)
+    s0 = settings_list[0]
+    models = scenes[0]["models"]
+    dev = models[0][0].device
+    P = sum(int(m[0].shape[0]) for m in models)
+    H, W = int(s0.image_height), int(s0.image_width)
+    same = all(int(s.image_height) == H and int(s.image_width) == W and s.scale_modifier == s0.scale_modifier
+               for s in settings_list)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = R._workspace(dev, stream)
+    K = 1 + (int(models[0][5].shape[1]) if models[0][5] is not None and models[0][5].numel() > 0 else 0)
+    batched = (1 < V <= MAX_VIEWS and same and P > 0 and R.FORWARD_MODE == "auto" and ws.hint.get((P, H, W)) is not None
+               and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24) and K in (1, 4, 9, 16)
+               and not any(s.score_flag for s in settings_list))
+    if not batched:
+        return [R.rasterize_forward_raw(s, None, None, None, None, None, None, None, want_aux=want_aux, scene=sc)
+                for s, sc in zip(settings_list, scenes)]
+    prof = R.PROFILE.handle if R.PROFILE is not None else None
+    stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
+    with torch.cuda.device(dev):
+        big = ws.scratch("proj_scratch_batch", stride * V)
+        if ws.batch_pinned is None:
+            ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
+        gens = [R._forward_steps(s, None, None, None, None, None, None, None, False, want_aux, None, scenes[k],
+                                 dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
+                                      event=ws.event))
+                for k, s in enumerate(settings_list)]
+        return _drive_batch(lib, ws, gens, V, dev, stream, prof)
 
 
 class _RasterizeViews(torch.autograd.Function):

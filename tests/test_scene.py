@@ -200,3 +200,48 @@ def test_fused_scene_accumulates_into_model_buffers(built_lib):
     gu = torch.autograd.grad(loss, [t for m in models for t in m])
     for x, y in zip(g1, gu):
         assert tol_ok(x.cpu().numpy(), y.cpu().numpy(), atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,D,noise", [(16, 3, True), (4, 1, False)])
+def test_fused_scene_views_match_per_view_calls(built_lib, K, D, noise):
+    """rasterize_models_views (one K1 / K8 pass over the views of a step, raw leaves, per-view noise) == the per-view
+    rasterize_models calls: identical per-view outputs, parameter gradients = sum over the views."""
+    from dreamscene_amd import scene, synth
+    from tests.util import settings_for, tol_ok
+    dev = torch.device("cuda:0")
+    sizes, H, W, V = [300, 0, 700, 129], 96, 112, 3
+    P = sum(sizes)
+    models = _random_models(sizes, K, 51, dev)
+    leaves = [t for m in models for t in m]
+    cams = synth.object_cameras(V + 1, H, W, radius=3.0)[1:]
+    sets = [settings_for(c, [0.1 * k, 0.5, 0.9], D if k != 1 else 0, dev) for k, c in enumerate(cams)]
+    gen = torch.Generator().manual_seed(7)
+    sn = torch.randn((V, P, 3), generator=gen).to(dev) if noise else None
+    hn = torch.randn((V, P, K, 3), generator=gen).to(dev) if noise else None
+    gis = [torch.tensor(synth.upstream_grads(H, W, seed=k)[0], device=dev) for k in range(V)]
+    gdas = [torch.tensor(synth.upstream_grads(H, W, seed=k)[1], device=dev) for k in range(V)]
+
+    def loss_of(outs):
+        return sum((img * gis[k]).sum() + (da * gdas[k]).sum() + 0.01 * (k + 1) * sc.mean()
+                   for k, (img, _, da, sc) in enumerate(outs))
+
+    ref_outs, m2ds = [], []
+    for k in range(V):
+        m2d = torch.zeros((P, 3), device=dev, requires_grad=True)
+        ref_outs.append(scene.rasterize_models(sets[k], models, m2d, None if sn is None else sn[k],
+                                               None if hn is None else hn[k]))
+        m2ds.append(m2d)
+    ref_grads = torch.autograd.grad(loss_of(ref_outs), leaves + m2ds)
+    for rep in range(2):            # the first batched call of this (P, H, W) still runs view by view (no hint yet)
+        m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        outs = scene.rasterize_models_views(sets, models, m2d, sn, hn)
+        grads = torch.autograd.grad(loss_of(outs), leaves + [m2d])
+    for (img, radii, da, sc), (rimg, rradii, rda, rsc) in zip(outs, ref_outs):
+        assert torch.equal(radii, rradii) and torch.equal(sc, rsc)
+        assert torch.equal(img, rimg) and torch.equal(da, rda)
+    n = len(leaves)
+    for a, b, t in zip(grads[:n], ref_grads[:n], leaves):
+        if t.numel():
+            assert tol_ok(a.cpu().numpy(), b.cpu().numpy(), atol=3e-6)
+    assert tol_ok(grads[n].cpu().numpy(), torch.stack(ref_grads[n:]).cpu().numpy(), atol=3e-6)

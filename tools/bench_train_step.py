@@ -2,7 +2,9 @@
   A) drop-in only: per-view GaussianRasterizer calls inside the reference's loop, torch.optim.Adam, the trainer's
      boolean-mask statistics updates;
   B) this repo's step: GaussianRasterizerViews (one call for the C_batch_size views, per-view noisy scales), densification
-     statistics inside K8 (DensifyStats), FusedAdam.
+     statistics inside K8 (DensifyStats), FusedAdam;
+  C) as B, but the raw leaves go straight into the kernels (scene.rasterize_models_views: exp / sigmoid / normalize /
+     cat(f_dc, f_rest) and the per-view scale noise fused into K1 / K8).
 Same parameters, cameras, noise and losses; reports steps/s and the time of the pieces.
 usage: python tools/bench_train_step.py [--gaussians 500000] [--res 1024] [--views 4]"""
 import argparse, json, math, os, sys, time
@@ -94,7 +96,21 @@ def main():
             losses([o[0] for o in outs], [o[2] for o in outs], list(sc)).backward()
         opt_b.step(zero_grad=True)
 
-    for name, fn in (("A_drop_in_only", step_a), ("B_views_fused_epilogue", step_b)):
+    # ---------------- C: raw leaves straight into the views kernels (activations + noise fused)
+    from dreamscene_amd import scene
+    lv_c, groups_c = make()
+    opt_c = FusedAdam(groups_c, lr=0.0, eps=1e-15)
+    stats_c = densify.DensifyStats(P, dev)
+    model_c = tuple(lv_c[k] for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"))
+
+    def step_c():
+        vsp = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        outs = scene.rasterize_models_views(sets, [model_c], vsp, scale_noise=torch.randn((V, P, 3), device=dev))
+        with stats_c.collect():
+            losses([o[0] for o in outs], [o[2] for o in outs], [o[3] for o in outs]).backward()
+        opt_c.step(zero_grad=True)
+
+    for name, fn in (("A_drop_in_only", step_a), ("B_views_fused_epilogue", step_b), ("C_raw_leaves_views", step_c)):
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
@@ -105,6 +121,7 @@ def main():
         dt = (time.perf_counter() - t0) / a.steps
         res[name] = {"ms_per_step": round(dt * 1e3, 3), "steps_per_s": round(1 / dt, 2), "views_per_s": round(V / dt, 1)}
     res["speedup_B_over_A"] = round(res["A_drop_in_only"]["ms_per_step"] / res["B_views_fused_epilogue"]["ms_per_step"], 3)
+    res["speedup_C_over_A"] = round(res["A_drop_in_only"]["ms_per_step"] / res["C_raw_leaves_views"]["ms_per_step"], 3)
     res["workload"] = f"{P} Gaussians, K=16, {V} views @{W}x{H}, per-view scale noise, L2 + TV(depth) + scale loss, Adam, stats"
     print(json.dumps(res))
 
