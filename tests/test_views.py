@@ -104,3 +104,38 @@ def test_batched_views_recover_from_capacity_overflow(built_lib):
         assert o["N"] == ref["N"]
         assert torch.equal(o["radii"], ref["radii"])
         assert torch.equal(o["color"], ref["color"]) and torch.equal(o["depth_alpha"], ref["depth_alpha"])
+
+
+@pytest.mark.gpu
+def test_batched_views_with_precomputed_colours(built_lib):
+    """Inputs the fused K1 / K8 passes do not cover (colors_precomp): the batch still shares the sorts and runs K1 / K8
+    view by view, later views added to view 0's gradients."""
+    from dreamscene_amd import synth
+    from dreamscene_amd.rasterizer import GaussianRasterizer
+    from dreamscene_amd.views import GaussianRasterizerViews
+    dev = torch.device("cuda:0")
+    P, H, W, V = 900, 80, 96, 3
+    g, _ = small_scene(P=P, H=H, W=W, K=1, seed=61)
+    cams = synth.object_cameras(V + 1, H, W, radius=3.0)[1:]
+    sets = [settings_for(c, [0, 0, 0], 0, dev) for c in cams]
+    t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items() if k != "shs"}
+    cols = torch.rand((P, 3), device=dev, requires_grad=True)
+    leaves = [t["means3D"], cols, t["opacities"], t["scales"], t["rotations"]]
+    gis = [torch.tensor(synth.upstream_grads(H, W, seed=k)[0], device=dev) for k in range(V)]
+    gdas = [torch.tensor(synth.upstream_grads(H, W, seed=k)[1], device=dev) for k in range(V)]
+    tot = None
+    for k, s in enumerate(sets):
+        m2d = torch.zeros((P, 3), device=dev, requires_grad=True)
+        img, radii, da = GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2d, colors_precomp=cols,
+                                                opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+        gr = torch.autograd.grad([img, da], leaves, [gis[k], gdas[k]])
+        tot = list(gr) if tot is None else [a + b for a, b in zip(tot, gr)]
+    rast = GaussianRasterizerViews(sets)
+    for rep in range(2):
+        m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        outs = rast(means3D=t["means3D"], means2D=m2d, colors_precomp=cols, opacities=t["opacities"],
+                    scales=t["scales"], rotations=t["rotations"])
+        grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves,
+                                    [y for k in range(V) for y in (gis[k], gdas[k])])
+    for a, b in zip(grads, tot):
+        assert tol_ok(a.cpu().numpy(), b.cpu().numpy(), atol=3e-6)
