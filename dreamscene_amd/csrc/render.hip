@@ -578,10 +578,6 @@ k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const
   const uint32_t item = blockIdx.x;
   const int tile = (int)items[2 + 2 * item];
   const uint32_t seg = items[3 + 2 * item];
-#ifdef GSR_EXP_LDSPAD
-  __shared__ float pad[GSR_EXP_LDSPAD];
-  if (tile < 0) pad[threadIdx.x] = 1.f;
-#endif
   const uint32_t depth = tile_depth[tile];
   const uint32_t lo = seg * kBatch, hi = min(lo + (uint32_t)kBatch, depth);
   const int n = (int)(hi - lo);
