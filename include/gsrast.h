@@ -235,8 +235,9 @@ uint32_t gsr_num_blocks(int32_t P); /* entries of GsrGeom.block_offsets minus on
  * Synchronises `stream` once and stores the pair count N in *n_pairs_host (ordinary host memory). */
 int gsr_forward_project(const GsrView*, const GsrGaussians*, GsrGeom*, uint64_t* n_pairs_host, void* stream,
                         GsrProfile* prof);
-/* Same work, no host synchronisation: N is copied asynchronously into *n_pairs_pinned (must be page-locked host
- * memory) and is valid once the caller has waited for the work enqueued so far. Used with capacity mode
+/* Same work, no host synchronisation: N lands in *n_pairs_pinned (must be page-locked, device-visible host memory:
+ * hipHostMalloc / torch pinned; a kernel stores it there) and is valid once the caller has waited for the work enqueued
+ * so far. Used with capacity mode
  * (GsrBinning.count_on_device) so that a whole forward is enqueued without draining the GPU. */
 int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uint64_t* n_pairs_pinned, void* stream,
                               GsrProfile* prof);
@@ -246,9 +247,12 @@ int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uin
  * launch together. Requirements: equal P / image size / sh_stride, image at most 4096 x 4096, and the views'
  * GsrGeom.scratch buffers equally spaced (geoms[k].scratch == geoms[0].scratch + k * stride, stride a multiple of 256).
  * gaussians[k] are the inputs of view k: identical pointers for every view except `scales`, which may be a different
- * tensor per view (the trainers add fresh noise to the activated scales of every view, scene_gaussian.py:1004-1008).
- * No host synchronisation: n_pairs_pinned[n_views] (page-locked) is valid once the work enqueued so far has finished.
- * Each view then continues with its own gsr_forward_render. */
+ * tensor per view (the trainers add fresh noise to the activated scales of every view, scene_gaussian.py:1004-1008);
+ * with a `scene`, every view has its own GsrScene holding the SAME models and its own noise samples / scales_out.
+ * K1 runs once over all views (parameter rows read once) for shs or scene input with K in {1,4,9,16}.
+ * No host synchronisation: n_pairs_pinned[n_views] (page-locked, device-visible) receives the counts straight from a
+ * kernel and is valid once the work enqueued so far has finished.
+ * The views then continue with gsr_forward_render_batch (or each with its own gsr_forward_render). */
 #define GSR_MAX_BATCH_VIEWS 16
 int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGaussians* gaussians /* [n_views] */,
                               GsrGeom* geoms, uint64_t* n_pairs_pinned, void* stream, GsrProfile* prof);
@@ -273,7 +277,8 @@ int gsr_backward(const GsrView*, const GsrGaussians*, const GsrGeom*, const GsrB
  * dL_dcampos); the parameter gradient pointers, `accumulate` and the stat_* pointers are taken from outs[0] (give every
  * entry the same ones): the SUM over the views is written (accumulate = 0) or added (accumulate = 1) there, and the
  * statistics are updated once per view that saw the Gaussian. With per-view `scales` (see gsr_forward_project_batch)
- * every outs[k].dL_dscales is its own [P,3] buffer and receives view k's scale gradient (never accumulated). */
+ * every outs[k].dL_dscales is its own [P,3] buffer and receives view k's scale gradient (never accumulated). With a
+ * scene every outs[k].scene names the SAME model gradient tensors (summed over the views) and its own dL_dscales_out. */
 int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians* gaussians /* [n_views] */,
                        const GsrGeom* geoms,
                        const GsrBinning* binnings, const GsrImages* images, const GsrImageGrads* image_grads,
