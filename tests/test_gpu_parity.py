@@ -408,3 +408,20 @@ def test_whole_tile_forward_variant(built_lib, c_oracle):
         assert err(o["score"].cpu().numpy(), ref) <= 1e-4 * max(1.0, float(ref.max()))
     finally:
         R.FWD_MODE = old
+
+
+def test_thousands_of_equal_depths_keep_index_order(built_lib, c_oracle):
+    """5000 Gaussians at exactly the same depth: ties are resolved by Gaussian index, like the stable sort of the
+    reference formulation (exact, speculated-capacity and repeated calls)."""
+    from dreamscene_amd import synth
+    P, K, D, H, W = 6000, 4, 1, 96, 96
+    g = synth.g_object(P, seed=77, K=K)
+    g["means3D"][:5000] = g["means3D"][0]                  # identical centres: identical depth keys
+    g["scales"] = (g["scales"] * 3).astype(np.float32)
+    cam = synth.object_cameras(2, H, W, radius=3.0)[1]
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    v = oracle_view(c_oracle, cam, P, K, D, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    for rep in range(3):
+        out, _ = _run_hip(g, cam, bg, D)
+        _check_forward(out, f, P)
