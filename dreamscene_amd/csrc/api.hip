@@ -17,6 +17,8 @@ uint64_t* gsr_pair_counts(const GsrGeom&, int32_t P);
 bool gsr_uses_columns(const GsrView&);
 int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint64_t* n_dev, const uint64_t* n_dev_vis,
                        GsrBinning&, hipStream_t, GsrProfile*);
+int gsr_launch_binning_batch(int n, const GsrView* views, const GsrGeom* geoms, uint64_t cap, GsrBinning* bs, hipStream_t,
+                             GsrProfile*);
 int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, GsrImages&, hipStream_t, GsrProfile*);
 int gsr_launch_work_order_fwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
 int gsr_launch_work_order_bwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
@@ -282,9 +284,14 @@ int gsr_forward_render_batch(int32_t n_views, const GsrView* views, const GsrGeo
     if (views[k].image_height != views[0].image_height || views[k].image_width != views[0].image_width) return GSR_EINVAL;
   }
   hipStream_t stream = (hipStream_t)stream_;
-  for (int k = 0; k < n_views; ++k) {
-    const int rc = render_binning(&views[k], &geoms[k], n_pairs, &bs[k], stream, prof);
-    if (rc) return rc;
+  // capacity mode + equally spaced scratch buffers: emission and the ty pass of all views share their launches
+  bool all_dev = true;
+  for (int k = 0; k < n_views; ++k) all_dev = all_dev && bs[k].count_on_device && views[k].P == views[0].P;
+  if (!(all_dev && gsr_launch_binning_batch(n_views, views, geoms, n_pairs, bs, stream, prof) == GSR_OK)) {
+    for (int k = 0; k < n_views; ++k) {
+      const int rc = render_binning(&views[k], &geoms[k], n_pairs, &bs[k], stream, prof);
+      if (rc) return rc;
+    }
   }
   int rc = gsr_launch_work_order_fwd(n_views, views, bs, imgs, stream);   // the work lists of all views in one launch
   if (rc) return rc;

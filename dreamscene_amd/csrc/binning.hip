@@ -270,7 +270,10 @@ k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restr
 __global__ void __launch_bounds__(64)
 k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x, const uint32_t* __restrict__ rect_sorted,
             const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ hist1, const uint32_t nrun,
-            const uint32_t* __restrict__ colstart, const uint32_t cap, uint32_t* __restrict__ vals) {
+            const uint32_t* __restrict__ colstart, const uint32_t cap, uint32_t* __restrict__ vals, size_t ps, size_t ss) {
+  // several views per launch (blockIdx.y): projection scratch buffers ps bytes apart, sort scratch buffers ss bytes apart
+  n_vis = batch_ptr(n_vis, ps); rect_sorted = batch_ptr(rect_sorted, ps); sorted_idx = batch_ptr(sorted_idx, ps);
+  hist1 = batch_ptr(hist1, ps); colstart = batch_ptr(colstart, ps); vals = batch_ptr(vals, ss);
   __shared__ uint32_t col_run[256];
   __shared__ uint32_t pbase[65];
   __shared__ uint32_t rs[64], ids[64], mg[64];
@@ -369,7 +372,8 @@ __device__ __forceinline__ ColBlocks col_blocks(const uint32_t* __restrict__ col
 
 __global__ void __launch_bounds__(kSortThreads)
 k_row_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ colstart, const int gx, const uint32_t cap,
-           const int nbits, const uint32_t nblk, uint32_t* __restrict__ hist) {
+           const int nbits, const uint32_t nblk, uint32_t* __restrict__ hist, size_t ps, size_t ss) {
+  keys = batch_ptr(keys, ss); colstart = batch_ptr(colstart, ps); hist = batch_ptr(hist, ss);
   __shared__ uint32_t h[kRadix];
   __shared__ uint32_t sh_fb[257];
   __shared__ uint32_t sh_tmp[8];
@@ -395,11 +399,21 @@ k_row_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ colst
   hist[(uint64_t)tid * nblk + blockIdx.x] = h[tid];
 }
 
+// per-view outputs of the ty pass (they live in separately allocated per-view state buffers)
+struct RowOut {
+  uint32_t* point_list[GSR_MAX_BATCH_VIEWS];
+  uint32_t* ranges[GSR_MAX_BATCH_VIEWS];
+};
+
 // Stable scatter by ty. The first workgroup of every column also writes the ranges of the column's tiles.
 __global__ void __launch_bounds__(kSortThreads)
-k_row_scatter(const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ colstart, const int gx, const int gy,
-              const uint32_t cap, const int nbits, const uint32_t nblk, const uint32_t* __restrict__ hist,
-              const uint32_t* __restrict__ totals, uint32_t* __restrict__ ranges) {
+k_row_scatter(const uint32_t* __restrict__ vals_in, const RowOut ro, const uint32_t* __restrict__ colstart, const int gx,
+              const int gy, const uint32_t cap, const int nbits, const uint32_t nblk, const uint32_t* __restrict__ hist,
+              const uint32_t* __restrict__ totals, size_t ps, size_t ss) {
+  vals_in = batch_ptr(vals_in, ss); colstart = batch_ptr(colstart, ps); hist = batch_ptr(hist, ss);
+  totals = batch_ptr(totals, ss);
+  uint32_t* __restrict__ vals_out = ro.point_list[blockIdx.y];
+  uint32_t* __restrict__ ranges = ro.ranges[blockIdx.y];
   __shared__ uint32_t wh[4][kRadix];
   __shared__ uint32_t dbase[kRadix];
   __shared__ uint32_t wtot[4];
@@ -588,46 +602,73 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
   return GSR_OK;
 }
 
-// Column path of gsr_launch_binning.
-static int launch_binning_columns(const GsrView& v, const GsrGeom& geom, uint64_t cap64, const uint64_t* n_dev_vis,
-                                  GsrBinning& b, hipStream_t stream, GsrProfile* prof) {
+// Column path of gsr_launch_binning for n views whose projection scratch buffers (ps) and sort scratch buffers (ss) are
+// equally spaced (n == 1: any buffers). geoms / bs point at the first view's structs.
+static int launch_binning_columns(int n, const GsrView& v, const GsrGeom* geoms, uint64_t cap64, GsrBinning* bs, size_t ps,
+                                  size_t ss, hipStream_t stream, GsrProfile* prof) {
+  const GsrGeom& geom = geoms[0];
   const int gx = (v.image_width + GSR_TILE - 1) / GSR_TILE, gy = (v.image_height + GSR_TILE - 1) / GSR_TILE;
   const uint32_t cap = cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cap64;
   ProjectScratch s = carve_project(geom.scratch, v.P);
   const uint32_t* rect_sorted = (geom.sorted_idx == s.v0) ? s.k1 : s.k0;
+  const uint64_t* n_dev_vis = s.counts + 1;
   const uint32_t nrun = col_runs(v.P);
   const uint32_t nblk = (uint32_t)((cap64 + kPass2Block - 1) / kPass2Block) + (uint32_t)gx + 2;
-  char* base = (char*)b.scratch;
+  char* base = (char*)bs[0].scratch;
   uint32_t* vals1 = (uint32_t*)base; base += align256(cap64 * 4);
   uint32_t* hist = (uint32_t*)base; base += align256((size_t)kRadix * nblk * 4);
   uint32_t* totals = (uint32_t*)base;
+  RowOut ro = RowOut{};
+  for (int k = 0; k < n; ++k) { ro.point_list[k] = bs[k].point_list; ro.ranges[k] = bs[k].ranges; }
+  const uint32_t ny = (uint32_t)n;
   int nbits = 1;
   while ((1 << nbits) < gy) ++nbits;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_DUPLICATE);
     int nbits_x = 1;
     while ((1 << nbits_x) < gx) ++nbits_x;
-    hipLaunchKernelGGL(k_emit_cols, dim3(nrun), dim3(64), 0, stream, n_dev_vis, gx, nbits_x, rect_sorted,
-                       geom.sorted_idx, s.hist1, nrun, s.colstart, cap, vals1);
+    hipLaunchKernelGGL(k_emit_cols, dim3(nrun, ny), dim3(64), 0, stream, n_dev_vis, gx, nbits_x, rect_sorted,
+                       geom.sorted_idx, s.hist1, nrun, s.colstart, cap, vals1, ps, ss);
     GSR_HIP(hipGetLastError());
   }
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    hipLaunchKernelGGL(k_row_hist, dim3(nblk), dim3(kSortThreads), 0, stream, vals1, s.colstart, gx, cap, nbits, nblk,
-                       hist);
-    hipLaunchKernelGGL(k_radix_scan, dim3(kRadix), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr, 1u,
-                       (size_t)0);
-    hipLaunchKernelGGL(k_row_scatter, dim3(nblk), dim3(kSortThreads), 0, stream, vals1, b.point_list, s.colstart,
-                       gx, gy, cap, nbits, nblk, hist, totals, b.ranges);
+    hipLaunchKernelGGL(k_row_hist, dim3(nblk, ny), dim3(kSortThreads), 0, stream, vals1, s.colstart, gx, cap, nbits, nblk,
+                       hist, ps, ss);
+    hipLaunchKernelGGL(k_radix_scan, dim3(kRadix, ny), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr,
+                       1u, ss);
+    hipLaunchKernelGGL(k_row_scatter, dim3(nblk, ny), dim3(kSortThreads), 0, stream, vals1, ro, s.colstart, gx, gy, cap,
+                       nbits, nblk, hist, totals, ps, ss);
     GSR_HIP(hipGetLastError());
   }
-  if (b.keys_sorted) {
+  for (int k = 0; k < n; ++k) {
+    if (!bs[k].keys_sorted) continue;
     GsrStageTimer t(prof, stream, GSR_STAGE_RANGES);
-    hipLaunchKernelGGL(k_rebuild_keys_ranges, dim3(gx * gy), dim3(256), 0, stream, b.ranges, b.point_list, geom.splat,
-                       b.keys_sorted);
+    hipLaunchKernelGGL(k_rebuild_keys_ranges, dim3(gx * gy), dim3(256), 0, stream, bs[k].ranges, bs[k].point_list,
+                       geoms[k].splat, bs[k].keys_sorted);
     GSR_HIP(hipGetLastError());
   }
   return GSR_OK;
+}
+
+// Binning of n views in shared launches; returns GSR_EINVAL (nothing enqueued) if the views' buffers do not allow it
+// (column path only, equally spaced projection / sort scratch buffers, enough sort scratch): the caller then loops.
+int gsr_launch_binning_batch(int n, const GsrView* views, const GsrGeom* geoms, uint64_t cap, GsrBinning* bs,
+                             hipStream_t stream, GsrProfile* prof) {
+  const GsrView& v = views[0];
+  const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
+  if (n < 2 || cap == 0 || v.P == 0 || !use_columns(v.image_height, v.image_width, v.P)) return GSR_EINVAL;
+  const size_t ps = (size_t)((char*)geoms[1].scratch - (char*)geoms[0].scratch);
+  const size_t ss = (size_t)((char*)bs[1].scratch - (char*)bs[0].scratch);
+  const size_t need = gsr_sort_scratch_bytes(cap, tiles);
+  for (int k = 0; k < n; ++k) {
+    if (!geoms[k].sorted_idx || !bs[k].scratch || bs[k].scratch_bytes < need) return GSR_EINVAL;
+    if ((char*)geoms[k].scratch != (char*)geoms[0].scratch + (size_t)k * ps) return GSR_EINVAL;
+    if ((char*)bs[k].scratch != (char*)bs[0].scratch + (size_t)k * ss) return GSR_EINVAL;
+    if ((char*)geoms[k].sorted_idx != (char*)geoms[0].sorted_idx + (size_t)k * ps) return GSR_EINVAL;
+  }
+  if (ss < need || (ss & 255u) || (ps & 255u)) return GSR_EINVAL;
+  return launch_binning_columns(n, v, geoms, cap, bs, ps, ss, stream, prof);
 }
 
 // Emits, tile-sorts and ranges. `cap` = pairs the buffers hold; n_dev (may be NULL = exactly cap pairs) is the
@@ -641,7 +682,10 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
   }
   if (b.scratch_bytes < gsr_sort_scratch_bytes(cap, tiles) || !b.scratch) return GSR_ESCRATCH;
   if (!geom.sorted_idx) return GSR_EINVAL;
-  if (use_columns(v.image_height, v.image_width, v.P)) return launch_binning_columns(v, geom, cap, n_dev_vis, b, stream, prof);
+  if (use_columns(v.image_height, v.image_width, v.P)) {
+    (void)n_dev_vis;
+    return launch_binning_columns(1, v, &geom, cap, &b, 0, 0, stream, prof);
+  }
   char* base = (char*)b.scratch;
   uint32_t* keys_a = (uint32_t*)base; base += align256(cap * 4);
   uint32_t* keys_b = (uint32_t*)base; base += align256(cap * 4);

@@ -100,6 +100,7 @@ class _Workspace:
         self.batch_pinned = None     # pinned int64 [GSR_MAX_BATCH_VIEWS]: pair counts of a batched projection
         self.proj_scratch = None
         self.proj_scratch_batch = None
+        self.sort_scratch_batch = None
         self.sort_scratch = None
         self.hint = {}           # (P, H, W) -> decaying max of recent pair counts
         self.last_stats = {}     # (P, H, W) -> (non-empty tiles or None = read the pinned word, pair count)
@@ -270,7 +271,9 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
             geom.block_offsets = ptrs["block_offsets"]
             geom.scratch, geom.scratch_bytes = proj_scratch.data_ptr(), proj_scratch.numel()
             sort_bytes = int(lib.gsr_sort_scratch_bytes(cap, tiles))
-            sort_scratch = ws.scratch("sort_scratch", sort_bytes)
+            # batched: every view its own, equally spaced slice (emission and the ty pass of all views share launches)
+            sort_scratch = batch["sort"](sort_bytes) if (batch is not None and on_device) else \
+                ws.scratch("sort_scratch", sort_bytes)
             b.point_list, b.ranges, b.tile_work = ptrs["point_list"], ptrs["ranges"], ptrs["tile_work"]
             b.bwd_items_cap = cap // 256 + tiles
             b.keys_sorted = ptrs["keys_sorted"] if want_keys else None

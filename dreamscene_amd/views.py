@@ -57,15 +57,27 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
     stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
     with torch.cuda.device(dev):
         big = ws.scratch("proj_scratch_batch", stride * V)
+        sort_of = _sort_slices(ws, V)
         if ws.batch_pinned is None:
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
         gens = [R._forward_steps(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp, False,
                                  want_aux, None, None,
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
-                                      event=ws.event))
+                                      event=ws.event, sort=sort_of(k)))
                 for k, s in enumerate(settings_list)]
         results = _drive_batch(lib, ws, gens, V, dev, stream, prof)
     return results
+
+
+def _sort_slices(ws, V):
+    """k -> (nbytes -> slice k of one tensor holding V equally spaced sort scratch buffers)."""
+    def provider(k):
+        def get(nbytes):
+            stride = R._align(int(nbytes), 256)
+            big = ws.scratch("sort_scratch_batch", stride * V)
+            return big[k * stride:(k + 1) * stride]
+        return get
+    return provider
 
 
 def _drive_batch(lib, ws, gens, V, dev, stream, prof):
@@ -117,11 +129,12 @@ def _views_forward_scene(lib, settings_list, scenes, want_aux):
     stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
     with torch.cuda.device(dev):
         big = ws.scratch("proj_scratch_batch", stride * V)
+        sort_of = _sort_slices(ws, V)
         if ws.batch_pinned is None:
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
         gens = [R._forward_steps(s, None, None, None, None, None, None, None, False, want_aux, None, scenes[k],
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
-                                      event=ws.event))
+                                      event=ws.event, sort=sort_of(k)))
                 for k, s in enumerate(settings_list)]
         return _drive_batch(lib, ws, gens, V, dev, stream, prof)
 
