@@ -164,8 +164,8 @@ def main():
             step()
             sync()
         res = prof.collect()
-        n_fwd = max(1, res["render_fwd"][1])          # stages recorded several times per view are summed per view
-        stage_ms = {s: ms / n_fwd for s, (ms, c) in res.items()}
+        n_views_prof = max(1, args.warmup) * V        # per view (a stage may be one launch per view or per batch)
+        stage_ms = {s: ms / n_views_prof for s, (ms, c) in res.items()}
         # the roofline entry is for the dominant single KERNEL: "sort" and "scan" are groups of small launches
         # (18 and 2 per view) and are reported in stage_us_warmup only
         single = {k: v for k, v in stage_ms.items() if k not in ("sort", "scan")}
@@ -199,18 +199,21 @@ def main():
         N_pairs = int(o["N"])
         if cnt:
             avg_s = ms / cnt * 1e-3                   # the stage timer brackets exactly one launch of the kernel
-            ab = algorithmic_bytes(dominant, P, N_pairs, H * W, K, D)
+            per_launch = V if (V > 1 and not args.unbatched) else 1     # batched: one launch covers the step's V views
+            ab = algorithmic_bytes(dominant, P, N_pairs, H * W, K, D) * per_launch
             achieved = ab / avg_s / 1e9
             traffic = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tf):
                 try:
                     traffic = json.load(open(tf)).get(f"{args.scene}_{P}_{W}", {}).get(dominant)
+                    traffic = traffic * per_launch if traffic is not None else None   # (stored per view)
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes": int(ab),
+                        "avg_launch_us": round(avg_s * 1e6, 2), "views_per_launch": per_launch,
+                        "algorithmic_bytes": int(ab),
                         "stage_us_warmup": {s: round(v * 1e3, 2) for s, v in stage_ms.items()}}
 
     cpu_baseline = None

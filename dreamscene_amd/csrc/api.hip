@@ -20,6 +20,10 @@ int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint6
 int gsr_launch_binning_batch(int n, const GsrView* views, const GsrGeom* geoms, uint64_t cap, GsrBinning* bs, hipStream_t,
                              GsrProfile*);
 int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, GsrImages&, hipStream_t, GsrProfile*);
+int gsr_launch_render_fwd_views(int n, const GsrView* views, const GsrGeom* geoms, const GsrBinning* bs, GsrImages* imgs,
+                                hipStream_t, GsrProfile*);
+int gsr_launch_render_bwd_views(int n, const GsrView* views, const GsrGeom* geoms, const GsrBinning* bs,
+                                const GsrImages* imgs, const GsrImageGrads* igs, GsrGrads* outs, hipStream_t, GsrProfile*);
 int gsr_launch_work_order_fwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
 int gsr_launch_work_order_bwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
 int gsr_launch_render_bwd(const GsrView&, const GsrGeom&, const GsrBinning&, const GsrImages&, const GsrImageGrads&,
@@ -295,6 +299,13 @@ int gsr_forward_render_batch(int32_t n_views, const GsrView* views, const GsrGeo
   }
   int rc = gsr_launch_work_order_fwd(n_views, views, bs, imgs, stream);   // the work lists of all views in one launch
   if (rc) return rc;
+  // K6 of all views in one launch when they use the same variant / outputs
+  bool uniform = true;
+  for (int k = 1; k < n_views; ++k)
+    uniform = uniform && bs[k].fwd_mode == bs[0].fwd_mode &&
+              (imgs[k].important_score != nullptr) == (imgs[0].important_score != nullptr) &&
+              views[k].score_mode == views[0].score_mode;
+  if (uniform) return gsr_launch_render_fwd_views(n_views, views, geoms, bs, imgs, stream, prof);
   for (int k = 0; k < n_views; ++k) {
     rc = gsr_launch_render_fwd(views[k], geoms[k], bs[k], imgs[k], stream, prof);
     if (rc) return rc;
@@ -394,10 +405,17 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
     const int rc = gsr_launch_work_order_bwd(n_views, views, bs, imgs, stream);   // all views' work lists in one launch
     if (rc) return rc;
   }
-  for (int k = 0; k < n_views; ++k) {
-    const int rc = backward_render(&views[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k], stream, prof, !contiguous);
+  if (fused) {
+    // K7 of all views in one launch
+    if (!contiguous)
+      for (int k = 0; k < n_views; ++k) GSR_HIP(hipMemsetAsync(outs[k].partials, 0, pbytes, stream));
+    const int rc = gsr_launch_render_bwd_views(n_views, views, geoms, bs, imgs, igs, outs, stream, prof);
     if (rc) return rc;
-    if (!fused) {   // unsupported combination: K8 view by view, views 1.. added to what view 0 wrote
+  } else {
+    for (int k = 0; k < n_views; ++k) {
+      const int rc = backward_render(&views[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k], stream, prof, !contiguous);
+      if (rc) return rc;
+      // unsupported combination: K8 view by view, views 1.. added to what view 0 wrote
       GsrGrads o = outs[k];
       const GsrGrads& o0 = outs[0];
       o.dL_dmeans3D = o0.dL_dmeans3D; o.dL_dopacities = o0.dL_dopacities; o.dL_dshs = o0.dL_dshs;
@@ -406,7 +424,7 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
       o.dL_dcov3D = o0.dL_dcov3D;      // (o.scene stays view k's own table: same model tensors, its own dL_dscales_out)
       o.accumulate = (k > 0) ? 1 : o0.accumulate;
       GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
-      const int rc2 = gsr_launch_preprocess_bwd(views[k], *g, geoms[k], o, stream);
+      const int rc2 = gsr_launch_preprocess_bwd(views[k], gs[k], geoms[k], o, stream);
       if (rc2) return rc2;
     }
   }

@@ -246,8 +246,8 @@ struct Stage {
 // 4x more (and 4x finer) work items, 4x shorter dependency chains, tighter 4x4 culling; same gates in the same
 // list order (the only numerical change is the association of the running product inside a quad, ulp-level).
 template <bool SCORE>
-__global__ void __launch_bounds__(256)
-k_render_fwd(const int W, const int H, const uint32_t* __restrict__ work, float* __restrict__ ckpt,
+__device__ __forceinline__ void
+render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, float* __restrict__ ckpt,
              const uint32_t* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const float4* __restrict__ splat, const float* __restrict__ bg,
              float* __restrict__ out_color, float* __restrict__ out_da, float* __restrict__ final_T,
@@ -421,8 +421,8 @@ k_render_fwd(const int W, const int H, const uint32_t* __restrict__ work, float*
 // 377 us vs 124 us). The host picks the variant per call from the previous view's statistics
 // (GsrBinning.fwd_mode); both produce the same images up to the association of the transmittance product.
 template <bool SCORE>
-__global__ void __launch_bounds__(256)
-k_render_fwd_tile(const int W, const int H, const uint32_t* __restrict__ work, float* __restrict__ ckpt,
+__device__ __forceinline__ void
+render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work, float* __restrict__ ckpt,
                   const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                   const float4* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ out_color,
                   float* __restrict__ out_da, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -561,8 +561,8 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 // checkpoint at the segment end (prefix transmittance T_c and prefix sums C_c, D_c, W_c): the colour / depth /
 // alpha composited BEHIND that point, normalised to start there, is (X_final - X_c) / T_c, which is exactly the
 // `rec` state the sequential traversal would carry at that position. Other pixels start from their final state.
-__global__ void __launch_bounds__(256)
-k_render_bwd(const int W, const int H, const uint32_t* __restrict__ items, const uint32_t* __restrict__ tile_depth,
+__device__ __forceinline__ void
+render_bwd_body(const int W, const int H, const uint32_t* __restrict__ items, const uint32_t* __restrict__ tile_depth,
              const float* __restrict__ ckpt,
              const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
              const float4* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ color,
@@ -706,6 +706,60 @@ static int persistent_groups(int per_cu) {
   return cus[dev] * per_cu;
 }
 
+// ---- kernels: blockIdx.y selects the view (pointer tables in the kernel arguments); one view = tables of one
+struct FwdViews {
+  const uint32_t* work[GSR_MAX_BATCH_VIEWS];
+  float* ckpt[GSR_MAX_BATCH_VIEWS];
+  const uint32_t* ranges[GSR_MAX_BATCH_VIEWS];
+  const uint32_t* point_list[GSR_MAX_BATCH_VIEWS];
+  const float4* splat[GSR_MAX_BATCH_VIEWS];
+  const float* bg[GSR_MAX_BATCH_VIEWS];
+  float* out_color[GSR_MAX_BATCH_VIEWS];
+  float* out_da[GSR_MAX_BATCH_VIEWS];
+  float* final_T[GSR_MAX_BATCH_VIEWS];
+  uint32_t* n_contrib[GSR_MAX_BATCH_VIEWS];
+  uint32_t* tile_depth[GSR_MAX_BATCH_VIEWS];
+  float* score[GSR_MAX_BATCH_VIEWS];
+};
+struct BwdViews {
+  const uint32_t* items[GSR_MAX_BATCH_VIEWS];
+  const uint32_t* tile_depth[GSR_MAX_BATCH_VIEWS];
+  const float* ckpt[GSR_MAX_BATCH_VIEWS];
+  const uint32_t* ranges[GSR_MAX_BATCH_VIEWS];
+  const uint32_t* point_list[GSR_MAX_BATCH_VIEWS];
+  const float4* splat[GSR_MAX_BATCH_VIEWS];
+  const float* bg[GSR_MAX_BATCH_VIEWS];
+  const float* color[GSR_MAX_BATCH_VIEWS];
+  const float* depth_alpha[GSR_MAX_BATCH_VIEWS];
+  const float* final_T[GSR_MAX_BATCH_VIEWS];
+  const uint32_t* n_contrib[GSR_MAX_BATCH_VIEWS];
+  const float* dL_dcolor[GSR_MAX_BATCH_VIEWS];
+  const float* dL_dda[GSR_MAX_BATCH_VIEWS];
+  float* partials[GSR_MAX_BATCH_VIEWS];
+};
+
+template <bool SCORE>
+__global__ void __launch_bounds__(256) k_render_fwd(const int W, const int H, const FwdViews fv, const int score_mode) {
+  const int y = blockIdx.y;
+  render_fwd_body<SCORE>(W, H, fv.work[y], fv.ckpt[y], fv.ranges[y], fv.point_list[y], fv.splat[y], fv.bg[y],
+                         fv.out_color[y], fv.out_da[y], fv.final_T[y], fv.n_contrib[y], fv.tile_depth[y], fv.score[y],
+                         score_mode);
+}
+template <bool SCORE>
+__global__ void __launch_bounds__(256)
+k_render_fwd_tile(const int W, const int H, const FwdViews fv, const int score_mode) {
+  const int y = blockIdx.y;
+  render_fwd_tile_body<SCORE>(W, H, fv.work[y], fv.ckpt[y], fv.ranges[y], fv.point_list[y], fv.splat[y], fv.bg[y],
+                              fv.out_color[y], fv.out_da[y], fv.final_T[y], fv.n_contrib[y], fv.tile_depth[y],
+                              fv.score[y], score_mode);
+}
+__global__ void __launch_bounds__(256) k_render_bwd(const int W, const int H, const BwdViews bv) {
+  const int y = blockIdx.y;
+  render_bwd_body(W, H, bv.items[y], bv.tile_depth[y], bv.ckpt[y], bv.ranges[y], bv.point_list[y], bv.splat[y], bv.bg[y],
+                  bv.color[y], bv.depth_alpha[y], bv.final_T[y], bv.n_contrib[y], bv.dL_dcolor[y], bv.dL_dda[y],
+                  bv.partials[y]);
+}
+
 // The stage timers (GSR_STAGE_RENDER_FWD / _BWD) bracket the compositing kernel alone (not the work-list kernel), so
 // that bench.py's roofline entry and the rocprofv3 average of that kernel measure the same thing.
 // Work lists of n views (same image size) in one launch.
@@ -731,52 +785,61 @@ int gsr_launch_work_order_bwd(int n, const GsrView* views, const GsrBinning* bs,
   return GSR_OK;
 }
 
-// K6 of one view (its work list must have been built).
-int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, GsrImages& img,
-                          hipStream_t stream, GsrProfile* prof) {
+// K6 of n views in one launch (their work lists must have been built; same image size, forward variant and score
+// output for all of them -- the caller checks).
+int gsr_launch_render_fwd_views(int n, const GsrView* views, const GsrGeom* geoms, const GsrBinning* bs, GsrImages* imgs,
+                                hipStream_t stream, GsrProfile* prof) {
+  const GsrView& v = views[0];
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
-  const float4* splat = reinterpret_cast<const float4*>(geom.splat);
-  uint32_t* work = b.tile_work;
-  GsrStageTimer timer(prof, stream, GSR_STAGE_RENDER_FWD);
-  if (b.fwd_mode == 1) {
-    if (img.important_score)
-      hipLaunchKernelGGL(k_render_fwd_tile<true>, dim3(tiles), dim3(256), 0, stream, v.image_width, v.image_height, work,
-                         img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T,
-                         img.n_contrib, img.tile_depth, img.important_score, v.score_mode);
-    else
-      hipLaunchKernelGGL(k_render_fwd_tile<false>, dim3(tiles), dim3(256), 0, stream, v.image_width, v.image_height,
-                         work, img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha, img.final_T,
-                         img.n_contrib, img.tile_depth, (float*)nullptr, 0);
-    GSR_HIP(hipGetLastError());
-    timer.stop();
-    return GSR_OK;
+  FwdViews fv = FwdViews{};
+  for (int k = 0; k < n; ++k) {
+    fv.work[k] = bs[k].tile_work; fv.ckpt[k] = imgs[k].ckpt; fv.ranges[k] = bs[k].ranges;
+    fv.point_list[k] = bs[k].point_list; fv.splat[k] = reinterpret_cast<const float4*>(geoms[k].splat);
+    fv.bg[k] = views[k].bg; fv.out_color[k] = imgs[k].color; fv.out_da[k] = imgs[k].depth_alpha;
+    fv.final_T[k] = imgs[k].final_T; fv.n_contrib[k] = imgs[k].n_contrib; fv.tile_depth[k] = imgs[k].tile_depth;
+    fv.score[k] = imgs[k].important_score;
   }
-  const uint32_t grid = tiles * 4;
-  if (img.important_score) {
-    hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, work,
-                       img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha,
-                       img.final_T, img.n_contrib, img.tile_depth, img.important_score, v.score_mode);
+  const bool score = imgs[0].important_score != nullptr;
+  const uint32_t ny = (uint32_t)n;
+  GsrStageTimer timer(prof, stream, GSR_STAGE_RENDER_FWD);
+  if (bs[0].fwd_mode == 1) {
+    if (score) hipLaunchKernelGGL(k_render_fwd_tile<true>, dim3(tiles, ny), dim3(256), 0, stream, v.image_width, v.image_height, fv, v.score_mode);
+    else hipLaunchKernelGGL(k_render_fwd_tile<false>, dim3(tiles, ny), dim3(256), 0, stream, v.image_width, v.image_height, fv, 0);
   } else {
-    hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(256), 0, stream, v.image_width, v.image_height, work,
-                       img.ckpt, b.ranges, b.point_list, splat, v.bg, img.color, img.depth_alpha,
-                       img.final_T, img.n_contrib, img.tile_depth, (float*)nullptr, 0);
+    if (score) hipLaunchKernelGGL(k_render_fwd<true>, dim3(tiles * 4, ny), dim3(256), 0, stream, v.image_width, v.image_height, fv, v.score_mode);
+    else hipLaunchKernelGGL(k_render_fwd<false>, dim3(tiles * 4, ny), dim3(256), 0, stream, v.image_width, v.image_height, fv, 0);
   }
   GSR_HIP(hipGetLastError());
   timer.stop();
   return GSR_OK;
 }
+int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, GsrImages& img,
+                          hipStream_t stream, GsrProfile* prof) {
+  return gsr_launch_render_fwd_views(1, &v, &geom, &b, &img, stream, prof);
+}
 
-int gsr_launch_render_bwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, const GsrImages& img,
-                          const GsrImageGrads& ig, GsrGrads& out, hipStream_t stream, GsrProfile* prof) {
-  // K7 of one view (its work list must have been built)
+// K7 of n views in one launch (work lists built; same image size).
+int gsr_launch_render_bwd_views(int n, const GsrView* views, const GsrGeom* geoms, const GsrBinning* bs,
+                                const GsrImages* imgs, const GsrImageGrads* igs, GsrGrads* outs, hipStream_t stream,
+                                GsrProfile* prof) {
+  const GsrView& v = views[0];
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
-  uint32_t* items = b.tile_work + tiles;
-  const uint32_t items_cap = b.bwd_items_cap;
+  BwdViews bv = BwdViews{};
+  uint32_t items_cap = 0;
+  for (int k = 0; k < n; ++k) {
+    bv.items[k] = bs[k].tile_work + tiles; bv.tile_depth[k] = imgs[k].tile_depth; bv.ckpt[k] = imgs[k].ckpt;
+    bv.ranges[k] = bs[k].ranges; bv.point_list[k] = bs[k].point_list;
+    bv.splat[k] = reinterpret_cast<const float4*>(geoms[k].splat); bv.bg[k] = views[k].bg; bv.color[k] = imgs[k].color;
+    bv.depth_alpha[k] = imgs[k].depth_alpha; bv.final_T[k] = imgs[k].final_T; bv.n_contrib[k] = imgs[k].n_contrib;
+    bv.dL_dcolor[k] = igs[k].dL_dcolor; bv.dL_dda[k] = igs[k].dL_ddepth_alpha; bv.partials[k] = outs[k].partials;
+    items_cap = bs[k].bwd_items_cap > items_cap ? bs[k].bwd_items_cap : items_cap;
+  }
   GsrStageTimer timer(prof, stream, GSR_STAGE_RENDER_BWD);
-  hipLaunchKernelGGL(k_render_bwd, dim3(items_cap), dim3(256), 0, stream, v.image_width, v.image_height, items,
-                     img.tile_depth, img.ckpt, b.ranges, b.point_list,
-                     reinterpret_cast<const float4*>(geom.splat), v.bg, img.color, img.depth_alpha, img.final_T,
-                     img.n_contrib, ig.dL_dcolor, ig.dL_ddepth_alpha, out.partials);
+  hipLaunchKernelGGL(k_render_bwd, dim3(items_cap, (uint32_t)n), dim3(256), 0, stream, v.image_width, v.image_height, bv);
   GSR_HIP(hipGetLastError());
   return GSR_OK;
+}
+int gsr_launch_render_bwd(const GsrView& v, const GsrGeom& geom, const GsrBinning& b, const GsrImages& img,
+                          const GsrImageGrads& ig, GsrGrads& out, hipStream_t stream, GsrProfile* prof) {
+  return gsr_launch_render_bwd_views(1, &v, &geom, &b, &img, &ig, &out, stream, prof);
 }
