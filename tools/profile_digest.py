@@ -53,7 +53,9 @@ def main(tag, scene_key=None):
              f"# bench: {json.dumps(bench)[:1500]}",
              f"{'kernel':86s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'total_ms':>9s} {'%':>6s}"]
     per_stage = defaultdict(float)
-    n_fwd = max(1, len([1 for n in agg if "k_render_fwd" in n for _ in agg[n]]))
+    # per VIEW: the bench line says how many views the run rendered (a batched launch covers several views)
+    vps = (bench.get("config", {}) or {}).get("views_per_step_per_gpu", 1) if bench else 1
+    n_fwd = max(1, n_views * vps) if bench else max(1, len([1 for n in agg if "k_render_fwd" in n for _ in agg[n]]))
     for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         lines.append(f"{n[:86]:86s} {len(v):6d} {sum(v)/len(v)/1e3:9.2f} {min(v)/1e3:9.2f} {max(v)/1e3:9.2f} "
                      f"{sum(v)/1e6:9.3f} {100*sum(v)/tot:6.2f}")
@@ -83,7 +85,7 @@ def main(tag, scene_key=None):
             if not stage(kn):
                 continue
             plines.append(kn[:120])
-            n_f = max(1, max(len(v) for n2, dd in byk.items() if "k_render_fwd" in n2 for v in dd.values()))
+            n_f = n_fwd
             for cn, v in sorted(d.items()):
                 plines.append(f"    {cn:24s} dispatches={len(v):5d} avg={sum(v)/len(v):16.1f}")
                 if cn in ("FETCH_SIZE", "WRITE_SIZE"):
