@@ -31,9 +31,12 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
-    def step(self, closure=None, grads: Optional[Sequence[Optional[torch.Tensor]]] = None, zero_grad: bool = False):
+    def step(self, closure=None, grads: Optional[Sequence[Optional[torch.Tensor]]] = None, zero_grad: bool = False,
+             set_to_none: bool = False):
         """grads: optional gradient tensors, one per parameter in param_groups order (e.g. views of a GradArena),
-        instead of `p.grad`. zero_grad: clear the gradients inside the same pass over memory."""
+        instead of `p.grad`. zero_grad: clear the gradients inside the same pass over memory (persistent buffers such as
+        an arena). set_to_none: drop the `.grad` tensors after the step (like optimizer.zero_grad(set_to_none=True)): the
+        next backward's gradients then become `.grad` without an accumulation pass."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -80,4 +83,7 @@ class FusedAdam(torch.optim.Optimizer):
                     arr = (L.GsrAdamGroup * len(chunk))(*chunk)
                     L.check(lib.gsr_adam_step(arr, len(chunk), step, betas[0], betas[1], eps, int(zero_grad), stream),
                             "gsr_adam_step")
+        if set_to_none and grads is None:
+            for _, p in flat:
+                p.grad = None          # (the launch above holds its own references through `keep` until enqueued)
         return loss

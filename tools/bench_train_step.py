@@ -94,7 +94,7 @@ def main():
         outs = rast(means3D=lv_b["_xyz"], means2D=vsp, shs=shs, opacities=opac, scales=sc, rotations=rots)
         with stats.collect():          # (all views' statistics; the reference keeps the last view's only)
             losses([o[0] for o in outs], [o[2] for o in outs], list(sc)).backward()
-        opt_b.step(zero_grad=True)
+        opt_b.step(set_to_none=True)
 
     # ---------------- C: raw leaves straight into the views kernels (activations + noise fused)
     from dreamscene_amd import scene
@@ -108,7 +108,7 @@ def main():
         outs = scene.rasterize_models_views(sets, [model_c], vsp, scale_noise=torch.randn((V, P, 3), device=dev))
         with stats_c.collect():
             losses([o[0] for o in outs], [o[2] for o in outs], [o[3] for o in outs]).backward()
-        opt_c.step(zero_grad=True)
+        opt_c.step(set_to_none=True)
 
     for name, fn in (("A_drop_in_only", step_a), ("B_views_fused_epilogue", step_b), ("C_raw_leaves_views", step_c)):
         for _ in range(5):
