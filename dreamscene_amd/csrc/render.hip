@@ -227,12 +227,15 @@ k_work_order_bwd(const uint32_t n_tiles, const WorkBwdViews wv) {
   }
 }
 
+// Double-buffered staging of 256 list entries. The reach mask of an entry rides in the unused fourth component of its
+// third splat row (s2[..].w): 24 KB instead of 29 KB per workgroup = one more workgroup per CU; the Gaussian ids are only
+// staged by the score variant.
+template <bool SCORE>
 struct Stage {
   float4 s0[2][kBatch], s1[2][kBatch], s2[2][kBatch];
-  uint32_t sid[2][kBatch];
-  uint32_t smask[2][kBatch];
-  uint32_t item;
+  uint32_t sid[SCORE ? 2 : 1][SCORE ? kBatch : 1];
 };
+__device__ __forceinline__ uint32_t stage_mask(const float4& s2row) { return __float_as_uint(s2row.w); }
 
 // --------------------------------------------------------------------------------------------------------- K6
 // Forward compositing, "list-parallel lanes": FOUR lanes share a pixel and take four consecutive candidates of
@@ -253,7 +256,7 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
              float* __restrict__ out_color, float* __restrict__ out_da, float* __restrict__ final_T,
              uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_depth, float* __restrict__ score,
              const int score_mode) {
-  __shared__ Stage st;
+  __shared__ Stage<SCORE> st;
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = lane & 3, pl = lane >> 2;
@@ -285,9 +288,10 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
     int buf = 0;
     for (uint32_t base = r0; base < r1; base += kBatch, buf ^= 1) {
       const int n = (int)min((uint32_t)kBatch, r1 - base);
-      st.s0[buf][tid] = n0; st.s1[buf][tid] = n1; st.s2[buf][tid] = n2;
-      st.smask[buf][tid] = (tid < n) ? block_mask_t<4>(n0, n1, n2, q_x0, q_y0) : 0u;
-      if (SCORE) st.sid[buf][tid] = nid;
+      st.s0[buf][tid] = n0; st.s1[buf][tid] = n1;
+      st.s2[buf][tid] = make_float4(n2.x, n2.y, n2.z,
+                                    __uint_as_float((tid < n) ? block_mask_t<4>(n0, n1, n2, q_x0, q_y0) : 0u));
+      if constexpr (SCORE) st.sid[buf][tid] = nid;
       if (__syncthreads_count(done) == 256) break;
       if (base != r0) {
         // checkpoint of the per-pixel prefix state at this batch boundary: lets the backward start a traversal
@@ -315,7 +319,7 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
       }
       for (int k = 0; k < kBatch / 64; ++k) {
         if (k * 64 >= n) break;
-        unsigned long long bits = __ballot((st.smask[buf][k * 64 + lane] >> wave) & 1u);
+        unsigned long long bits = __ballot((stage_mask(st.s2[buf][k * 64 + lane]) >> wave) & 1u);
         while (bits) {
           if (__ballot(!done) == 0ull) break;
           // next (up to) four candidates of this wave, in list order; slot s takes the s-th
@@ -361,7 +365,7 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
           Dp = fmaf(b.z, w, Dp);
           Wt += w;
           last = hit ? ((base - r0) + (uint32_t)j + 1u) : last;
-          if (SCORE) {
+          if constexpr (SCORE) {
             // the pixels of the wave that composite slot s's splat: the 16 lanes holding this slot
             const unsigned long long hm = __ballot(hit) & (0x1111111111111111ull << slot);
             float sc;
@@ -427,7 +431,7 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
                   const float4* __restrict__ splat, const float* __restrict__ bg, float* __restrict__ out_color,
                   float* __restrict__ out_da, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                   uint32_t* __restrict__ tile_depth, float* __restrict__ score, const int score_mode) {
-  __shared__ Stage st;
+  __shared__ Stage<SCORE> st;
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tile = (int)work[blockIdx.x];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -448,9 +452,10 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
   int buf = 0;
   for (uint32_t base = r0; base < r1; base += kBatch, buf ^= 1) {
     const int n = (int)min((uint32_t)kBatch, r1 - base);
-    st.s0[buf][tid] = n0; st.s1[buf][tid] = n1; st.s2[buf][tid] = n2;
-    st.smask[buf][tid] = (tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u;
-    if (SCORE) st.sid[buf][tid] = nid;
+    st.s0[buf][tid] = n0; st.s1[buf][tid] = n1;
+    st.s2[buf][tid] = make_float4(n2.x, n2.y, n2.z,
+                                  __uint_as_float((tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u));
+    if constexpr (SCORE) st.sid[buf][tid] = nid;
     if (__syncthreads_count(done) == 256) break;
     if (base != r0 && p.inside) {
       float* ck = ckpt + (size_t)(base / kBatch) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
@@ -466,7 +471,7 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
     }
     for (int k = 0; k < kBatch / 64; ++k) {
       if (k * 64 >= n) break;
-      unsigned long long bits = __ballot((st.smask[buf][k * 64 + lane] >> wave) & 1u);
+      unsigned long long bits = __ballot((stage_mask(st.s2[buf][k * 64 + lane]) >> wave) & 1u);
       while (bits) {
         if (__ballot(!done) == 0ull) break;
         const int j = k * 64 + __builtin_ctzll(bits);
@@ -483,7 +488,7 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
         done = done | stop;
         hit = hit & !stop;
         const float w = hit ? alpha * T : 0.0f;
-        if (SCORE) {
+        if constexpr (SCORE) {
           const unsigned long long hm = __ballot(hit);       // one atomic per (wave, splat), not per pixel
           if (hm) {
             float sc;
