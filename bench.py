@@ -210,9 +210,16 @@ def main():
                     traffic = traffic * per_launch if traffic is not None else None   # (stored per view)
                 except Exception:
                     traffic = None
+            # the whole path's algorithmic bytes per view (848 P + 124 N + 56 HW at K=16, D=3)
+            S_ = 12 * (D + 1) ** 2
+            e2e_bytes = P * (44 + S_) + P * 48 + N_pairs * 12 + N_pairs * 24 + N_pairs * 44 + H * W * 28 + \
+                N_pairs * 44 + H * W * 28 + P * 40 + P * (44 + S_ + 40) + P * (44 + 12 * K + 12)
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "avg_launch_us": round(avg_s * 1e6, 2), "views_per_launch": per_launch,
+                        "whole_path": {"algorithmic_bytes_per_view": int(e2e_bytes),
+                                       "achieved_GBps": round(e2e_bytes * world * args.steps * V / elapsed / 1e9 / world, 1),
+                                       "frac_of_hbm_peak": round(e2e_bytes * args.steps * V / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
                         "algorithmic_bytes": int(ab),
                         "stage_us_warmup": {s: round(v * 1e3, 2) for s, v in stage_ms.items()}}
 
