@@ -291,7 +291,10 @@ int gsr_forward_render_batch(int32_t n_views, const GsrView* views, const GsrGeo
   // capacity mode + equally spaced scratch buffers: emission and the ty pass of all views share their launches
   bool all_dev = true;
   for (int k = 0; k < n_views; ++k) all_dev = all_dev && bs[k].count_on_device && views[k].P == views[0].P;
-  if (!(all_dev && gsr_launch_binning_batch(n_views, views, geoms, n_pairs, bs, stream, prof) == GSR_OK)) {
+  // (the batched launcher answers GSR_EINVAL before launching anything when the layout does not qualify)
+  int brc = all_dev ? gsr_launch_binning_batch(n_views, views, geoms, n_pairs, bs, stream, prof) : GSR_EINVAL;
+  if (brc != GSR_OK && brc != GSR_EINVAL) return brc;
+  if (brc == GSR_EINVAL) {
     for (int k = 0; k < n_views; ++k) {
       const int rc = render_binning(&views[k], &geoms[k], n_pairs, &bs[k], stream, prof);
       if (rc) return rc;
