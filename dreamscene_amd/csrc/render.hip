@@ -257,6 +257,7 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
              uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_depth, float* __restrict__ score,
              const int score_mode) {
   __shared__ Stage<SCORE> st;
+  __shared__ uint8_t cand[4][kBatch];   // per wave: the batch's candidates for its 4x4 block, in list order
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = lane & 3, pl = lane >> 2;
@@ -317,22 +318,24 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
           n0 = r[0]; n1 = r[1]; n2 = r[2];
         }
       }
+      // this wave's candidates of the batch (entries whose reach mask has the wave's 4x4 block), compacted in list
+      // order into a byte list of its own: the compositing loop then reads "its" candidate with one LDS load instead
+      // of peeling four bits off a 64-bit scalar mask per step, and only the last step of a batch can be partial
+      int cnt = 0;
       for (int k = 0; k < kBatch / 64; ++k) {
         if (k * 64 >= n) break;
-        unsigned long long bits = __ballot((stage_mask(st.s2[buf][k * 64 + lane]) >> wave) & 1u);
-        while (bits) {
+        const bool m = (stage_mask(st.s2[buf][k * 64 + lane]) >> wave) & 1u;
+        const unsigned long long bal = __ballot(m);
+        if (m) cand[wave][cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint8_t)(k * 64 + lane);
+        cnt += (int)__popcll(bal);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      {
+        for (int i = 0; i < cnt; i += 4) {
           if (__ballot(!done) == 0ull) break;
-          // next (up to) four candidates of this wave, in list order; slot s takes the s-th
-          int jc[4];
-          int nv = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bool v = bits != 0ull;
-            jc[q] = v ? (k * 64 + (int)__builtin_ctzll(bits)) : (k * 64);
-            nv += (int)v;
-            bits &= bits - 1ull;
-          }
-          const int j = slot == 0 ? jc[0] : (slot == 1 ? jc[1] : (slot == 2 ? jc[2] : jc[3]));
+          const int nv = min(4, cnt - i);
+          const int j = (int)cand[wave][min(i + slot, cnt - 1)];
           const float4 a = st.s0[buf][j];
           const float4 b = st.s1[buf][j];
           const float4 c = st.s2[buf][j];
