@@ -333,7 +333,7 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
       __builtin_amdgcn_wave_barrier();
       {
         for (int i = 0; i < cnt; i += 4) {
-          if (__ballot(!done) == 0ull) break;
+          if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
           const int nv = min(4, cnt - i);
           const int j = (int)cand[wave][min(i + slot, cnt - 1)];
           const float4 a = st.s0[buf][j];
@@ -354,15 +354,12 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
           const float Pex = gsr_dpp<0x90>(P);
           const float T_before = (slot >= 1) ? T * Pex : T;
           const float test_T = T * P;
-          // the first slot (in list order) whose own contribution would drop T below the threshold stops the pixel
-          int sflag = (int)(g & (test_T < GSR_T_MIN));
-          {
-            const int u1 = gsr_dpp_i<0x90>(sflag);
-            sflag |= (slot >= 1) ? u1 : 0;
-            const int u2 = gsr_dpp_i<0x44>(sflag);
-            sflag |= (slot >= 2) ? u2 : 0;
-          }
-          const bool hit = g & (sflag == 0);
+          // the first slot (in list order) whose own contribution would drop T below the threshold stops the pixel:
+          // inclusive OR over the slots <= mine, formed on the scalar unit from the wave's 64-bit flag mask
+          unsigned long long stopm = __builtin_amdgcn_ballot_w64(g && (test_T < GSR_T_MIN));
+          stopm |= (stopm << 1) & 0xEEEEEEEEEEEEEEEEull;
+          stopm |= (stopm << 2) & 0xCCCCCCCCCCCCCCCCull;
+          const bool hit = g & !__builtin_amdgcn_inverse_ballot_w64(stopm);
           const float w = hit ? alpha * T_before : 0.0f;
           C0 = fmaf(b.w, w, C0); C1 = fmaf(c.x, w, C1); C2 = fmaf(c.y, w, C2);
           Dp = fmaf(b.z, w, Dp);
@@ -384,12 +381,16 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
             }
             if (hm != 0ull && lane == slot && slot < nv) unsafeAtomicAdd(score + st.sid[buf][j], sc);
           }
-          // T after the quad: the survivors' T(1-alpha) only decrease along the list -> quad minimum
-          float tn = hit ? test_T : T;
-          tn = fminf(tn, gsr_dpp<0xB1>(tn));              // quad_perm [1,0,3,2]
-          tn = fminf(tn, gsr_dpp<0x4E>(tn));              // quad_perm [2,3,0,1]
-          T = tn;
-          done = done | (gsr_dpp_i<0xFF>(sflag) != 0);    // slot 3 holds the OR over the quad
+          // T after the quad: the survivors' T(1-alpha) only decrease along the list -> quad minimum (T >= 1e-4 > 0:
+          // the order of positive floats is the order of their bit patterns, and v_min_u32 takes a DPP operand)
+          uint32_t tn = __float_as_uint(hit ? test_T : T);
+          tn = min(tn, (uint32_t)gsr_dpp_i<0xB1>((int)tn));   // quad_perm [1,0,3,2]
+          tn = min(tn, (uint32_t)gsr_dpp_i<0x4E>((int)tn));   // quad_perm [2,3,0,1]
+          T = __uint_as_float(tn);
+          unsigned long long quad_stop = (stopm >> 3) & 0x1111111111111111ull;   // slot 3 holds the OR over the quad
+          quad_stop |= quad_stop << 1;
+          quad_stop |= quad_stop << 2;
+          done = done | __builtin_amdgcn_inverse_ballot_w64(quad_stop);
         }
       }
     }
