@@ -325,7 +325,7 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
       for (int k = 0; k < kBatch / 64; ++k) {
         if (k * 64 >= n) break;
         const bool m = (stage_mask(st.s2[buf][k * 64 + lane]) >> wave) & 1u;
-        const unsigned long long bal = __ballot(m);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(m);
         if (m) cand[wave][cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint8_t)(k * 64 + lane);
         cnt += (int)__popcll(bal);
       }
@@ -477,7 +477,7 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
       if (k * 64 >= n) break;
       unsigned long long bits = __ballot((stage_mask(st.s2[buf][k * 64 + lane]) >> wave) & 1u);
       while (bits) {
-        if (__ballot(!done) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
         const int j = k * 64 + __builtin_ctzll(bits);
         bits &= bits - 1ull;
         const float4 a = st.s0[buf][j];
@@ -650,16 +650,19 @@ render_bwd_body(const int W, const int H, const uint32_t* __restrict__ items, co
       const int j = k * 64 + __builtin_ctzll(bits);
       bits &= bits - 1ull;
       const uint32_t pos = hi - 1u - (uint32_t)j;      // 0-based list position
-      const bool live = pos < last;
-      if (__ballot(live) == 0ull) continue;
+      const unsigned long long livem = __builtin_amdgcn_ballot_w64(pos < last);
+      if (livem == 0ull) continue;
       const float4 a = s0[j];
       const float4 b = s1[j];
       const float dx = a.x - pxf, dy = a.y - pyf;
       const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
       const float G = gsr_exp(power);
       const float alpha = fminf(GSR_ALPHA_MAX, b.y * G);
-      const bool hit = live && (power <= 0.0f) && (alpha >= GSR_ALPHA_MIN);
-      if (__ballot(hit) == 0ull) continue;
+      // the gates as 64-bit lane masks on the scalar unit
+      const unsigned long long hitm = livem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                                      __builtin_amdgcn_ballot_w64(alpha >= GSR_ALPHA_MIN);
+      if (hitm == 0ull) continue;
+      const bool hit = __builtin_amdgcn_inverse_ballot_w64(hitm);
       // per-lane factors of the 10 sums; lanes without a hit contribute zeros (only these three are cleared)
       float qv = 0.f, wv = 0.f, gdl = 0.f;
       if (hit) {
