@@ -19,7 +19,7 @@ SOURCES = {
     "api.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": ["-ffp-contract=off"],
-    "render.hip": [],
+    "render.hip": ["-fno-slp-vectorize"],
     "knn.hip": ["-ffp-contract=off"],
     "optim.hip": ["-ffp-contract=off"],
 }
