@@ -17,7 +17,7 @@ ARCH = "gfx950"
 # per-file extra flags: the files whose fp32 results feed integer artefacts are built without FMA contraction
 SOURCES = {
     "api.hip": [],
-    "preprocess.hip": ["-ffp-contract=off"],
+    "preprocess.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "binning.hip": ["-ffp-contract=off"],
     "render.hip": ["-fno-slp-vectorize"],
     "knn.hip": ["-ffp-contract=off"],
