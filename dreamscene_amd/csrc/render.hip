@@ -528,9 +528,13 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
 }
 
 // --------------------------------------------------------------------------------------------------------- K7
-// Transposed butterfly over the 64 lanes for 10 values (see file header). On return lane L holds, for
-// j = L & 3 (j < 3) and row r = L >> 4, the wave total of component comp(j, r) = 4 j + ((r & 1) << 1 | (r >> 1)):
-//   j = 0: rows -> v0 v2 v1 v3     j = 1: rows -> v4 v6 v5 v7     j = 2: rows -> v8 (pad) v9 (pad)
+// Transposed butterfly over the 64 lanes for 10 values (see file header): at every step a lane keeps one register of
+// a pair and hands the other one to its partner, so the number of live registers halves while the sums grow
+// (10 -> 5 by permlane32 swap, -> 3 by permlane16 swap, -> 2 by row_ror:8 = lane ^ 8, -> 1 by row_half_mirror =
+// lane ^ 7, then quad_perm xor 2 and xor 1: 8, 7, 2, 1 span the 16 lanes of a row). 25 VALU ops. On return lane L of
+// row r = L >> 4 holds the wave total of component 4 w + ((r & 1) << 1 | (r >> 1)), where w = 2 if L & 4, else
+// 1 if L & 8, else 0:
+//   w = 0: rows -> v0 v2 v1 v3     w = 1: rows -> v4 v6 v5 v7     w = 2: rows -> v8 (pad) v9 (pad)
 __device__ __forceinline__ float add_swap32(float a, float b) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -539,24 +543,20 @@ __device__ __forceinline__ float add_swap16(float a, float b) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float row_sum16(float v) {
-  v += gsr_dpp<0x128>(v);   // row_ror:8
-  v += gsr_dpp<0x124>(v);   // row_ror:4
-  v += gsr_dpp<0x122>(v);   // row_ror:2
-  v += gsr_dpp<0x121>(v);   // row_ror:1
-  return v;
-}
 __device__ __forceinline__ float reduce10(const float v[10], int lane) {
   const float c01 = add_swap32(v[0], v[1]);
   const float c23 = add_swap32(v[2], v[3]);
   const float c45 = add_swap32(v[4], v[5]);
   const float c67 = add_swap32(v[6], v[7]);
   const float c89 = add_swap32(v[8], v[9]);
-  const float d0 = row_sum16(add_swap16(c01, c23));
-  const float d1 = row_sum16(add_swap16(c45, c67));
-  const float d2 = row_sum16(add_swap16(c89, 0.f));
-  const int j = lane & 3;
-  return j == 0 ? d0 : (j == 1 ? d1 : d2);
+  const float A = add_swap16(c01, c23), B = add_swap16(c45, c67), C = add_swap16(c89, 0.f);
+  const bool b8 = lane & 8, b4 = lane & 4;
+  const float AB = (b8 ? B : A) + gsr_dpp<0x128>(b8 ? A : B);      // row_ror:8: lane ^ 8
+  const float Cp = C + gsr_dpp<0x128>(C);
+  float R = (b4 ? Cp : AB) + gsr_dpp<0x141>(b4 ? AB : Cp);         // row_half_mirror: lane ^ 7
+  R += gsr_dpp<0x4E>(R);                                           // quad_perm [2,3,0,1]
+  R += gsr_dpp<0xB1>(R);                                           // quad_perm [1,0,3,2]
+  return R;
 }
 
 // Accumulates into partials [P,12], with q = dL/dG * G per (pixel, splat) and d = centre - pixel:
@@ -638,9 +638,9 @@ render_bwd_body(const int W, const int H, const uint32_t* __restrict__ items, co
   }
 
   // lane -> (component slot, scale) of the single atomic that commits a splat's 10 sums (see reduce10)
-  const int rj = lane & 3, rr = lane >> 4;
-  const int comp = 4 * rj + (((rr & 1) << 1) | (rr >> 1));
-  const bool commit = ((lane & 15) < 3) && (comp < 10);
+  const int l16 = lane & 15, rr = lane >> 4;
+  const int comp = 4 * ((l16 & 4) ? 2 : ((l16 & 8) ? 1 : 0)) + (((rr & 1) << 1) | (rr >> 1));
+  const bool commit = (l16 == 0 || l16 == 4 || l16 == 8) && (comp < 10);
   __syncthreads();
 
   for (int k = 0; k < kBatch / 64; ++k) {
