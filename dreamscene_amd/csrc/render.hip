@@ -622,8 +622,7 @@ render_bwd_body(const int W, const int H, const uint32_t* __restrict__ items, co
   const float bg_dot = (bg0 * gC0 + bg1 * gC1) + bg2 * gC2;
 
   float T = Tf;
-  float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, rc0 = 0.f, rc1 = 0.f, rc2 = 0.f;
-  float last_z = 0.f, rec_z = 0.f, rec_a = 0.f;
+  float rc0 = 0.f, rc1 = 0.f, rc2 = 0.f, rec_z = 0.f, rec_a = 0.f;
   if (last > hi) {
     // this pixel keeps compositing beyond the segment: start from the forward's checkpoint at position hi
     const float* ck = ckpt + (size_t)((r0 + hi) / kBatch) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
@@ -671,18 +670,20 @@ render_bwd_body(const int W, const int H, const uint32_t* __restrict__ items, co
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
         T = T * inv;
         const float w = alpha * T;
-        float dL_dalpha;
-        rc0 = last_alpha * lc0 + (1.0f - last_alpha) * rc0; lc0 = b.w;
-        rc1 = last_alpha * lc1 + (1.0f - last_alpha) * rc1; lc1 = c.x;
-        rc2 = last_alpha * lc2 + (1.0f - last_alpha) * rc2; lc2 = c.y;
-        dL_dalpha = (b.w - rc0) * gC0 + (c.x - rc1) * gC1 + (c.y - rc2) * gC2;
-        rec_z = last_alpha * last_z + (1.0f - last_alpha) * rec_z; last_z = b.z;
+        // (rc, rec_z, rec_a) = what is composited behind this splat, normalised to start here; the splat is folded
+        // into them after use -- the same operations, in the same order, as the lineage's "fold the previous splat
+        // first" form, without carrying the previous splat's alpha / colour / depth along
+        float dL_dalpha = (b.w - rc0) * gC0 + (c.x - rc1) * gC1 + (c.y - rc2) * gC2;
         dL_dalpha += (b.z - rec_z) * gD;
-        rec_a = last_alpha + (1.0f - last_alpha) * rec_a;
         dL_dalpha += (1.0f - rec_a) * gA;
         dL_dalpha *= T;
-        last_alpha = alpha;
         dL_dalpha -= (Tf * inv) * bg_dot;
+        const float om = 1.0f - alpha;
+        rc0 = alpha * b.w + om * rc0;
+        rc1 = alpha * c.x + om * rc1;
+        rc2 = alpha * c.y + om * rc2;
+        rec_z = alpha * b.z + om * rec_z;
+        rec_a = alpha + om * rec_a;
         // raw moments of q = dL/dG * G over the pixels; K8 turns them into dL/dmean2D and dL/dconic
         qv = (b.y * dL_dalpha) * G;
         gdl = G * dL_dalpha;
