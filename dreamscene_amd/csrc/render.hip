@@ -622,18 +622,19 @@ render_bwd_body(const int W, const int H, const uint32_t* __restrict__ items, co
   const float bg_dot = (bg0 * gC0 + bg1 * gC1) + bg2 * gC2;
 
   float T = Tf;
-  float rc0 = 0.f, rc1 = 0.f, rc2 = 0.f, rec_z = 0.f, rec_a = 0.f;
+  float R = 0.f;
   if (last > hi) {
     // this pixel keeps compositing beyond the segment: start from the forward's checkpoint at position hi
     const float* ck = ckpt + (size_t)((r0 + hi) / kBatch) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
     const float Tc = ck[0];
     const float inv = 1.0f / Tc;
     T = Tc;
-    rc0 = ((color[pix] - Tf * bg0) - ck[256]) * inv;
-    rc1 = ((color[HW + pix] - Tf * bg1) - ck[512]) * inv;
-    rc2 = ((color[2 * HW + pix] - Tf * bg2) - ck[768]) * inv;
-    rec_z = (depth_alpha[pix] - ck[1024]) * inv;
-    rec_a = (depth_alpha[HW + pix] - ck[1280]) * inv;
+    const float rc0 = ((color[pix] - Tf * bg0) - ck[256]) * inv;
+    const float rc1 = ((color[HW + pix] - Tf * bg1) - ck[512]) * inv;
+    const float rc2 = ((color[2 * HW + pix] - Tf * bg2) - ck[768]) * inv;
+    const float rec_z = (depth_alpha[pix] - ck[1024]) * inv;
+    const float rec_a = (depth_alpha[HW + pix] - ck[1280]) * inv;
+    R = rc0 * gC0 + rc1 * gC1 + rc2 * gC2 + rec_z * gD + rec_a * gA;
   }
 
   // lane -> (component slot, scale) of the single atomic that commits a splat's 10 sums (see reduce10)
@@ -670,20 +671,13 @@ render_bwd_body(const int W, const int H, const uint32_t* __restrict__ items, co
         const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
         T = T * inv;
         const float w = alpha * T;
-        // (rc, rec_z, rec_a) = what is composited behind this splat, normalised to start here; the splat is folded
-        // into them after use -- the same operations, in the same order, as the lineage's "fold the previous splat
-        // first" form, without carrying the previous splat's alpha / colour / depth along
-        float dL_dalpha = (b.w - rc0) * gC0 + (c.x - rc1) * gC1 + (c.y - rc2) * gC2;
-        dL_dalpha += (b.z - rec_z) * gD;
-        dL_dalpha += (1.0f - rec_a) * gA;
-        dL_dalpha *= T;
+        // R = <(colour, depth, alpha) composited behind this splat, normalised to start here; upstream gradient>: the
+        // recurrence of the behind-state is linear, so its dot product with the pixel's upstream gradient can be
+        // carried instead of its five components (dL/dalpha only ever needs that dot product)
+        const float sdot = b.w * gC0 + c.x * gC1 + c.y * gC2 + b.z * gD + gA;
+        float dL_dalpha = (sdot - R) * T;
         dL_dalpha -= (Tf * inv) * bg_dot;
-        const float om = 1.0f - alpha;
-        rc0 = alpha * b.w + om * rc0;
-        rc1 = alpha * c.x + om * rc1;
-        rc2 = alpha * c.y + om * rc2;
-        rec_z = alpha * b.z + om * rec_z;
-        rec_a = alpha + om * rec_a;
+        R = alpha * sdot + (1.0f - alpha) * R;
         // raw moments of q = dL/dG * G over the pixels; K8 turns them into dL/dmean2D and dL/dconic
         qv = (b.y * dL_dalpha) * G;
         gdl = G * dL_dalpha;
