@@ -31,18 +31,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def algorithmic_bytes(stage: str, P: int, N: int, HW: int, K: int, D: int) -> float:
-    """Algorithmic HBM bytes of one launch of each stage (DESIGN.md 'bytes per unit')."""
+def algorithmic_bytes(stage: str, P: int, N: int, HW: int, K: int, D: int, views: int = 1) -> float:
+    """Algorithmic HBM bytes of ONE LAUNCH of each stage covering `views` views of the same Gaussians (SURVEY.md section 8d;
+    DESIGN.md 'bytes per unit'). The batched K1 / K8 read the parameter rows (and K8 writes the summed parameter
+    gradients) once per launch whatever the number of views; everything else is per view."""
     S = 12 * (D + 1) ** 2
+    V = views
     return {
-        "preprocess": P * (44 + S) + P * 48,
-        "scan": P * 4 / 256 * 2,
-        "duplicate": P * 20 + N * 12,
-        "sort": N * 24,                       # lower bound: one read + one write of (u64 key, u32 value)
-        "ranges": N * 8,
-        "render_fwd": N * 44 + HW * 28,
-        "render_bwd": N * 44 + HW * 28 + P * 40,
-        "preprocess_bwd": P * (44 + S + 40) + P * (44 + 12 * K + 12),
+        "preprocess": P * (44 + S) + V * P * 48,
+        "scan": V * (P * 4 / 256 * 2),
+        "duplicate": V * (P * 20 + N * 12),
+        "sort": V * (N * 24),                 # lower bound: one read + one write of (u64 key, u32 value)
+        "ranges": V * (N * 8),
+        "render_fwd": V * (N * 44 + HW * 28),
+        "render_bwd": V * (N * 44 + HW * 28 + P * 40),
+        "preprocess_bwd": P * (44 + S) + V * P * 40 + V * P * 12 + P * (44 + 12 * K),
     }[stage]
 
 
@@ -153,21 +156,23 @@ def main():
     prof = None
     if not args.no_roofline:
         prof = _lib.Profile()
-        R.PROFILE = prof
     for _ in range(args.warmup):
         step()
     sync()
     stage_ms = {}
     dominant = None
     if prof is not None:
-        if args.warmup == 0:
+        # stage pass (untimed, after the warmup so that first-launch costs stay out of it): every stage timer on
+        R.PROFILE = prof
+        n_stage = 8
+        for _ in range(n_stage):
             step()
-            sync()
+        sync()
         res = prof.collect()
-        n_views_prof = max(1, args.warmup) * V        # per view (a stage may be one launch per view or per batch)
+        n_views_prof = n_stage * V                    # per view (a stage may be one launch per view or per batch)
         stage_ms = {s: ms / n_views_prof for s, (ms, c) in res.items()}
         # the roofline entry is for the dominant single KERNEL: "sort" and "scan" are groups of small launches
-        # (18 and 2 per view) and are reported in stage_us_warmup only
+        # (18 and 2 per view) and are reported in stage_us only
         single = {k: v for k, v in stage_ms.items() if k not in ("sort", "scan")}
         dominant = max(single, key=single.get)
         prof.reset()
@@ -200,7 +205,7 @@ def main():
         if cnt:
             avg_s = ms / cnt * 1e-3                   # the stage timer brackets exactly one launch of the kernel
             per_launch = V if (V > 1 and not args.unbatched) else 1     # batched: one launch covers the step's V views
-            ab = algorithmic_bytes(dominant, P, N_pairs, H * W, K, D) * per_launch
+            ab = algorithmic_bytes(dominant, P, N_pairs, H * W, K, D, views=per_launch)
             achieved = ab / avg_s / 1e9
             traffic = None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -221,7 +226,7 @@ def main():
                                        "achieved_GBps": round(e2e_bytes * world * args.steps * V / elapsed / 1e9 / world, 1),
                                        "frac_of_hbm_peak": round(e2e_bytes * args.steps * V / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
                         "algorithmic_bytes": int(ab),
-                        "stage_us_warmup": {s: round(v * 1e3, 2) for s, v in stage_ms.items()}}
+                        "stage_us_per_view": {s: round(v * 1e3, 2) for s, v in stage_ms.items()}}
 
     cpu_baseline = None
     grad_err = None

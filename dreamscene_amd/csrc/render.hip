@@ -69,31 +69,21 @@ __device__ __forceinline__ TilePix tile_pixel(int tile, int gx, int W, int H) {
 
 // Can the splat pass the alpha gate anywhere on the W1 x W1 pixel block with origin (bx, by)?  Exact up to the
 // inflation of tau: minimum of the convex form q(d) = A dx^2 + 2 B dx dy + C dy^2 over the block's rectangle (in
-// d = centre - pixel coordinates) compared with tau. The minimum is 0 if the centre lies inside, else it sits on
-// one of the four edges, where q restricted to the edge is a 1-D parabola with a clamped vertex.
+// d = centre - pixel coordinates) compared with tau. A convex function whose free minimum (d = 0) lies outside the
+// rectangle takes its minimum on a face the centre sees from outside -- at most one vertical and one horizontal
+// face. ex / ey = the coordinate of the rectangle nearest to 0 on each axis (the facing face, or 0 when the centre
+// is inside that axis range, which only adds interior points); on each of the two lines q is a parabola with a
+// clamped vertex. Centre inside the rectangle: ex = ey = 0 and both candidates are 0.
 template <int W1>
-__device__ __forceinline__ bool block_reach(float A, float B, float C, float iA, float iC, float tau, float cx, float cy,
-                                            float bx, float by) {
+__device__ __forceinline__ bool block_reach(float A, float C, float B2, float nBiA, float nBiC, float tau, float cx,
+                                            float cy, float bx, float by) {
   const float dx1 = cx - bx, dx0 = dx1 - (float)(W1 - 1), dy1 = cy - by, dy0 = dy1 - (float)(W1 - 1);
-  if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
-  float qmin;
-  {
-    const float y = fminf(dy1, fmaxf(dy0, -B * dx0 * iC));
-    qmin = A * dx0 * dx0 + (2.f * B * dx0 + C * y) * y;
-  }
-  {
-    const float y = fminf(dy1, fmaxf(dy0, -B * dx1 * iC));
-    qmin = fminf(qmin, A * dx1 * dx1 + (2.f * B * dx1 + C * y) * y);
-  }
-  {
-    const float x = fminf(dx1, fmaxf(dx0, -B * dy0 * iA));
-    qmin = fminf(qmin, C * dy0 * dy0 + (2.f * B * dy0 + A * x) * x);
-  }
-  {
-    const float x = fminf(dx1, fmaxf(dx0, -B * dy1 * iA));
-    qmin = fminf(qmin, C * dy1 * dy1 + (2.f * B * dy1 + A * x) * x);
-  }
-  return qmin <= tau;
+  const float ex = __builtin_amdgcn_fmed3f(dx0, 0.f, dx1), ey = __builtin_amdgcn_fmed3f(dy0, 0.f, dy1);
+  const float y = __builtin_amdgcn_fmed3f(dy0, nBiC * ex, dy1);
+  const float q1 = A * ex * ex + (B2 * ex + C * y) * y;
+  const float x = __builtin_amdgcn_fmed3f(dx0, nBiA * ey, dx1);
+  const float q2 = C * ey * ey + (B2 * ey + A * x) * x;
+  return fminf(q1, q2) <= tau;
 }
 
 // 4-bit mask over the 2x2 grid of W1 x W1 blocks with origin (x0, y0): bit (wave index) set = the splat can reach it.
@@ -103,13 +93,14 @@ __device__ __forceinline__ uint32_t block_mask_t(const float4 q0, const float4 q
   const float tau = q2.z;
   if (!(tau >= 0.f)) return 0u;
   const float A = q0.z, B = q0.w, C = q1.x;
-  const float iA = 1.0f / A, iC = 1.0f / C;
+  // vertex of q along a vertical line dx = e: dy = -B e / C; along a horizontal line dy = e: dx = -B e / A
+  const float nBiA = -B * __builtin_amdgcn_rcpf(A), nBiC = -B * __builtin_amdgcn_rcpf(C), B2 = 2.f * B;
   const float x0 = (float)x0i, y0 = (float)y0i;
   uint32_t m = 0;
-  m |= (uint32_t)block_reach<W1>(A, B, C, iA, iC, tau, q0.x, q0.y, x0, y0);
-  m |= (uint32_t)block_reach<W1>(A, B, C, iA, iC, tau, q0.x, q0.y, x0 + (float)W1, y0) << 1;
-  m |= (uint32_t)block_reach<W1>(A, B, C, iA, iC, tau, q0.x, q0.y, x0, y0 + (float)W1) << 2;
-  m |= (uint32_t)block_reach<W1>(A, B, C, iA, iC, tau, q0.x, q0.y, x0 + (float)W1, y0 + (float)W1) << 3;
+  m |= (uint32_t)block_reach<W1>(A, C, B2, nBiA, nBiC, tau, q0.x, q0.y, x0, y0);
+  m |= (uint32_t)block_reach<W1>(A, C, B2, nBiA, nBiC, tau, q0.x, q0.y, x0 + (float)W1, y0) << 1;
+  m |= (uint32_t)block_reach<W1>(A, C, B2, nBiA, nBiC, tau, q0.x, q0.y, x0, y0 + (float)W1) << 2;
+  m |= (uint32_t)block_reach<W1>(A, C, B2, nBiA, nBiC, tau, q0.x, q0.y, x0 + (float)W1, y0 + (float)W1) << 3;
   return m;
 }
 
@@ -331,14 +322,25 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      {
+      if (cnt > 0) {
+        // software pipeline over the LDS: the records of step i+4 and the candidate index of step i+8 are requested
+        // while step i is being composited (a wave's own loads would otherwise sit in front of every step)
+        const int cl = cnt - 1;
+        int jn = (int)cand[wave][min(slot, cl)];
+        int jnn = (int)cand[wave][min(4 + slot, cl)];
+        float4 an = st.s0[buf][jn], bn = st.s1[buf][jn];
+        float2 cn = *reinterpret_cast<const float2*>(&st.s2[buf][jn]);
         for (int i = 0; i < cnt; i += 4) {
           if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
           const int nv = min(4, cnt - i);
-          const int j = (int)cand[wave][min(i + slot, cnt - 1)];
-          const float4 a = st.s0[buf][j];
-          const float4 b = st.s1[buf][j];
-          const float4 c = st.s2[buf][j];
+          const int j = jn;
+          const float4 a = an;
+          const float4 b = bn;
+          const float2 c = cn;
+          jn = jnn;
+          jnn = (int)cand[wave][min(i + 8 + slot, cl)];
+          an = st.s0[buf][jn]; bn = st.s1[buf][jn];
+          cn = *reinterpret_cast<const float2*>(&st.s2[buf][jn]);
           const float dx = a.x - pxf, dy = a.y - pyf;
           const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
           const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
