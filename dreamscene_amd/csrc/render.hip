@@ -266,7 +266,8 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
     const float pxf = (float)px, pyf = (float)py;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
 
-    bool done = !inside;
+    // pixels that are finished, as a 64-bit lane mask of the wave: all the gate logic below runs on the scalar unit
+    unsigned long long donem = __builtin_amdgcn_ballot_w64(!inside);
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
     uint32_t last = 0;
 
@@ -284,7 +285,7 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
       st.s2[buf][tid] = make_float4(n2.x, n2.y, n2.z,
                                     __uint_as_float((tid < n) ? block_mask_t<4>(n0, n1, n2, q_x0, q_y0) : 0u));
       if constexpr (SCORE) st.sid[buf][tid] = nid;
-      if (__syncthreads_count(done) == 256) break;
+      if (__syncthreads_count(__builtin_amdgcn_inverse_ballot_w64(donem)) == 256) break;
       if (base != r0) {
         // checkpoint of the per-pixel prefix state at this batch boundary: lets the backward start a traversal
         // at any multiple of 256 list entries (k_render_bwd splits deep tiles into independent segments)
@@ -331,7 +332,7 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
         float4 an = st.s0[buf][jn], bn = st.s1[buf][jn];
         float2 cn = *reinterpret_cast<const float2*>(&st.s2[buf][jn]);
         for (int i = 0; i < cnt; i += 4) {
-          if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+          if (donem == ~0ull) break;
           const int nv = min(4, cnt - i);
           const int j = jn;
           const float4 a = an;
@@ -344,7 +345,11 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
           const float dx = a.x - pxf, dy = a.y - pyf;
           const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
           const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
-          const bool g = (slot < nv) & (power <= 0.0f) & (alpha >= GSR_ALPHA_MIN) & !done;
+          // lanes whose slot holds a candidate: the low nv lanes of every quad
+          const unsigned long long nvm = 0x1111111111111111ull * (unsigned long long)((1u << nv) - 1u);
+          const unsigned long long gm = nvm & ~donem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                                        __builtin_amdgcn_ballot_w64(alpha >= GSR_ALPHA_MIN);
+          const bool g = __builtin_amdgcn_inverse_ballot_w64(gm);
           // inclusive product of (1 - alpha) over the quad's gated slots
           float P = g ? (1.0f - alpha) : 1.0f;
           {
@@ -358,10 +363,10 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
           const float test_T = T * P;
           // the first slot (in list order) whose own contribution would drop T below the threshold stops the pixel:
           // inclusive OR over the slots <= mine, formed on the scalar unit from the wave's 64-bit flag mask
-          unsigned long long stopm = __builtin_amdgcn_ballot_w64(g && (test_T < GSR_T_MIN));
+          unsigned long long stopm = gm & __builtin_amdgcn_ballot_w64(test_T < GSR_T_MIN);
           stopm |= (stopm << 1) & 0xEEEEEEEEEEEEEEEEull;
           stopm |= (stopm << 2) & 0xCCCCCCCCCCCCCCCCull;
-          const bool hit = g & !__builtin_amdgcn_inverse_ballot_w64(stopm);
+          const bool hit = __builtin_amdgcn_inverse_ballot_w64(gm & ~stopm);
           const float w = hit ? alpha * T_before : 0.0f;
           C0 = fmaf(b.w, w, C0); C1 = fmaf(c.x, w, C1); C2 = fmaf(c.y, w, C2);
           Dp = fmaf(b.z, w, Dp);
@@ -392,7 +397,7 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
           unsigned long long quad_stop = (stopm >> 3) & 0x1111111111111111ull;   // slot 3 holds the OR over the quad
           quad_stop |= quad_stop << 1;
           quad_stop |= quad_stop << 2;
-          done = done | __builtin_amdgcn_inverse_ballot_w64(quad_stop);
+          donem |= quad_stop;
         }
       }
     }
@@ -445,7 +450,7 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
   const int tile_x0 = p.bx - (wave & 1) * 8, tile_y0 = p.by - (wave >> 1) * 8;
   const float pxf = (float)p.px, pyf = (float)p.py;
   const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
-  bool done = !p.inside;
+  unsigned long long donem = __builtin_amdgcn_ballot_w64(!p.inside);   // finished pixels, as a lane mask
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
   uint32_t last = 0;
   uint32_t nid = 0;
@@ -462,7 +467,7 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
     st.s2[buf][tid] = make_float4(n2.x, n2.y, n2.z,
                                   __uint_as_float((tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u));
     if constexpr (SCORE) st.sid[buf][tid] = nid;
-    if (__syncthreads_count(done) == 256) break;
+    if (__syncthreads_count(__builtin_amdgcn_inverse_ballot_w64(donem)) == 256) break;
     if (base != r0 && p.inside) {
       float* ck = ckpt + (size_t)(base / kBatch) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
       ck[0] = T; ck[256] = C0; ck[512] = C1; ck[768] = C2; ck[1024] = Dp; ck[1280] = Wt;
@@ -479,7 +484,7 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
       if (k * 64 >= n) break;
       unsigned long long bits = __ballot((stage_mask(st.s2[buf][k * 64 + lane]) >> wave) & 1u);
       while (bits) {
-        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        if (donem == ~0ull) break;
         const int j = k * 64 + __builtin_ctzll(bits);
         bits &= bits - 1ull;
         const float4 a = st.s0[buf][j];
@@ -489,10 +494,11 @@ render_fwd_tile_body(const int W, const int H, const uint32_t* __restrict__ work
         const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
         const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
         const float test_T = T * (1.0f - alpha);
-        bool hit = !done & (power <= 0.0f) & (alpha >= GSR_ALPHA_MIN);
-        const bool stop = hit & (test_T < GSR_T_MIN);
-        done = done | stop;
-        hit = hit & !stop;
+        const unsigned long long gm = ~donem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+                                      __builtin_amdgcn_ballot_w64(alpha >= GSR_ALPHA_MIN);
+        const unsigned long long stopm = gm & __builtin_amdgcn_ballot_w64(test_T < GSR_T_MIN);
+        donem |= stopm;
+        const bool hit = __builtin_amdgcn_inverse_ballot_w64(gm & ~stopm);
         const float w = hit ? alpha * T : 0.0f;
         if constexpr (SCORE) {
           const unsigned long long hm = __ballot(hit);       // one atomic per (wave, splat), not per pixel
