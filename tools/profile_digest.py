@@ -55,7 +55,9 @@ def main(tag, scene_key=None):
     per_stage = defaultdict(float)
     # per VIEW: the bench line says how many views the run rendered (a batched launch covers several views)
     vps = (bench.get("config", {}) or {}).get("views_per_step_per_gpu", 1) if bench else 1
-    n_fwd = max(1, n_views * vps) if bench else max(1, len([1 for n in agg if "k_render_fwd" in n for _ in agg[n]]))
+    # (counted from the trace itself: one k_render_bwd launch per step, whatever warm-up / stage passes bench.py ran)
+    n_bwd_launches = sum(len(v) for n, v in agg.items() if "k_render_bwd" in n)
+    n_fwd = max(1, n_bwd_launches * vps)
     for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         lines.append(f"{n[:86]:86s} {len(v):6d} {sum(v)/len(v)/1e3:9.2f} {min(v)/1e3:9.2f} {max(v)/1e3:9.2f} "
                      f"{sum(v)/1e6:9.3f} {100*sum(v)/tot:6.2f}")
