@@ -180,9 +180,11 @@ def main():
         prof.set_sampling(3)             # ... of every 3rd launch (two event records per launch are not free)
 
     sync()
+    R.HOST_WAIT_S[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    host_wait_s = R.HOST_WAIT_S[0]                   # of which: blocked on the pair counts of the projection
     host_enqueue_s = time.perf_counter() - t0        # the host is done enqueueing; the GPU may still be working
     sync()
     elapsed = time.perf_counter() - t0
@@ -247,6 +249,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 4),
+            "host_wait_ms_per_step": round(host_wait_s / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

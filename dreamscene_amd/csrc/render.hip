@@ -323,25 +323,14 @@ render_fwd_body(const int W, const int H, const uint32_t* __restrict__ work, flo
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (cnt > 0) {
-        // software pipeline over the LDS: the records of step i+4 and the candidate index of step i+8 are requested
-        // while step i is being composited (a wave's own loads would otherwise sit in front of every step)
-        const int cl = cnt - 1;
-        int jn = (int)cand[wave][min(slot, cl)];
-        int jnn = (int)cand[wave][min(4 + slot, cl)];
-        float4 an = st.s0[buf][jn], bn = st.s1[buf][jn];
-        float2 cn = *reinterpret_cast<const float2*>(&st.s2[buf][jn]);
+      {
         for (int i = 0; i < cnt; i += 4) {
           if (donem == ~0ull) break;
           const int nv = min(4, cnt - i);
-          const int j = jn;
-          const float4 a = an;
-          const float4 b = bn;
-          const float2 c = cn;
-          jn = jnn;
-          jnn = (int)cand[wave][min(i + 8 + slot, cl)];
-          an = st.s0[buf][jn]; bn = st.s1[buf][jn];
-          cn = *reinterpret_cast<const float2*>(&st.s2[buf][jn]);
+          const int j = (int)cand[wave][min(i + slot, cnt - 1)];
+          const float4 a = st.s0[buf][j];
+          const float4 b = st.s1[buf][j];
+          const float2 c = *reinterpret_cast<const float2*>(&st.s2[buf][j]);
           const float dx = a.x - pxf, dy = a.y - pyf;
           const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
           const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));

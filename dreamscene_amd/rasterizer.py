@@ -16,6 +16,7 @@ PyTorch is used for device memory, streams and autograd plumbing only; all arith
 from __future__ import annotations
 
 import ctypes as C
+import time
 from typing import NamedTuple, Optional
 
 import torch
@@ -119,6 +120,9 @@ _WORKSPACES = {}
 FORWARD_MODE = "auto"
 # forward compositing variant (GsrBinning.fwd_mode): None = choose per call from the previous view's statistics
 FWD_MODE: Optional[int] = None
+# seconds this process has spent blocked on the projection's pair count (bench.py reports it per step: how much of a
+# step the host is idle, i.e. how far the path is from being bound by host-side enqueueing)
+HOST_WAIT_S = [0.0]
 
 
 def _workspace(dev, stream) -> _Workspace:
@@ -329,7 +333,9 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                 event.record(torch.cuda.current_stream(dev))
                 L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), cap, C.byref(b), C.byref(im), stream,
                                                prof), "gsr_forward_render")
-            event.synchronize()              # projection finished long before the render was even enqueued
+            t_wait = time.perf_counter()
+            event.synchronize()              # (the render is already enqueued behind the projection: the GPU stays busy)
+            HOST_WAIT_S[0] += time.perf_counter() - t_wait
             N = int(pinned[pidx].item()) if P > 0 else 0
             keep_bufs = (buf,)
             view_src = {k: (buf, offs[k]) for k in offs}
