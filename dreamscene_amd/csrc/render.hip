@@ -264,6 +264,22 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
     const bool inside = (px < W) && (py < H);
     const float pxf = (float)px, pyf = (float)py;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+    if (r0 == r1) {
+      // empty tile (most of the image around an object): background only. The workgroup of quarter 0 writes the whole
+      // 16x16 tile, one pixel per thread; the other three leave (a quarter's full prologue / fold / store path costs
+      // ~100 instructions per wave, and four fifths of C3's workgroups are of this kind).
+      if (quarter == 0) {
+        const int ex = tx * GSR_TILE + (tid & 15), ey = ty * GSR_TILE + (tid >> 4);
+        if (ex < W && ey < H) {
+          const size_t pix = (size_t)ey * W + ex, HW = (size_t)H * W;
+          final_T[pix] = 1.0f;
+          n_contrib[pix] = 0u;
+          out_color[pix] = bg0; out_color[HW + pix] = bg1; out_color[2 * HW + pix] = bg2;
+          out_da[pix] = 0.f; out_da[HW + pix] = 0.f;
+        }
+      }
+      return;
+    }
 
     // pixels that are finished, as a 64-bit lane mask of the wave: all the gate logic below runs on the scalar unit
     unsigned long long donem = __builtin_amdgcn_ballot_w64(!inside);
