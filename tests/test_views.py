@@ -8,13 +8,16 @@ from tests.util import settings_for, small_scene, tol_ok
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,D,use_arena,noisy_scales", [(16, 3, False, False), (4, 1, True, False), (16, 3, False, True)])
-def test_batched_views_match_sequential(built_lib, K, D, use_arena, noisy_scales):
+@pytest.mark.parametrize("K,D,use_arena,noisy_scales,V", [(16, 3, False, False, 4), (4, 1, True, False, 4),
+                                                           (16, 3, False, True, 4), (16, 3, False, False, 3),
+                                                           (9, 2, True, False, 7)])
+def test_batched_views_match_sequential(built_lib, K, D, use_arena, noisy_scales, V):
+    """(V = 3, 7: the compositing kernels map workgroup b to item b / V of view b % V -- not only powers of two.)"""
     from dreamscene_amd import multiview, rasterizer as R, synth
     from dreamscene_amd.rasterizer import GaussianRasterizer
     from dreamscene_amd.views import GaussianRasterizerViews
     dev = torch.device("cuda:0")
-    P, H, W, V = 1500, 112, 144, 4
+    P, H, W = 1500, 112, 144
     g, _ = small_scene(P=P, H=H, W=W, K=K, seed=17)
     cams = synth.object_cameras(V + 1, H, W, radius=3.0)[1:]
     # per-view background and active SH degree (scene_render's bg / sh_deg augmentation draws them per view)
