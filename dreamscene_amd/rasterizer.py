@@ -333,9 +333,12 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                 event.record(torch.cuda.current_stream(dev))
                 L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), cap, C.byref(b), C.byref(im), stream,
                                                prof), "gsr_forward_render")
-            t_wait = time.perf_counter()
-            event.synchronize()              # (the render is already enqueued behind the projection: the GPU stays busy)
-            HOST_WAIT_S[0] += time.perf_counter() - t_wait
+            if batch is None or not batch.get("synced", [False])[0]:
+                t_wait = time.perf_counter()
+                event.synchronize()          # (the render is already enqueued behind the projection: the GPU stays busy)
+                HOST_WAIT_S[0] += time.perf_counter() - t_wait
+                if batch is not None and "synced" in batch:
+                    batch["synced"][0] = True     # one wait covers the pair counts of all views of the batch
             N = int(pinned[pidx].item()) if P > 0 else 0
             keep_bufs = (buf,)
             view_src = {k: (buf, offs[k]) for k in offs}

@@ -58,12 +58,13 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
     with torch.cuda.device(dev):
         big = ws.scratch("proj_scratch_batch", stride * V)
         sort_of = _sort_slices(ws, V)
+        synced = [False]          # the first generator to resume waits for the projection; the others find it done
         if ws.batch_pinned is None:
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
         gens = [R._forward_steps(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp, False,
                                  want_aux, None, None,
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
-                                      event=ws.event, sort=sort_of(k)))
+                                      event=ws.event, sort=sort_of(k), synced=synced))
                 for k, s in enumerate(settings_list)]
         results = _drive_batch(lib, ws, gens, V, dev, stream, prof)
     return results
@@ -130,11 +131,12 @@ def _views_forward_scene(lib, settings_list, scenes, want_aux):
     with torch.cuda.device(dev):
         big = ws.scratch("proj_scratch_batch", stride * V)
         sort_of = _sort_slices(ws, V)
+        synced = [False]          # the first generator to resume waits for the projection; the others find it done
         if ws.batch_pinned is None:
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
         gens = [R._forward_steps(s, None, None, None, None, None, None, None, False, want_aux, None, scenes[k],
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
-                                      event=ws.event, sort=sort_of(k)))
+                                      event=ws.event, sort=sort_of(k), synced=synced))
                 for k, s in enumerate(settings_list)]
         return _drive_batch(lib, ws, gens, V, dev, stream, prof)
 
