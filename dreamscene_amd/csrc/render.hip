@@ -1,23 +1,25 @@
 // render.hip -- K6 front-to-back alpha compositing and K7 its reverse-order backward, gfx950 (wave64).
 //
-// One 256-thread workgroup per 16x16 pixel tile; each of the 4 waves owns an 8x8 pixel block.
-//  * Splat records (3 x float4, written by K1) are gathered by list index 256 at a time into a double-buffered
-//    LDS stage: the gather of batch b+1 is issued before batch b is consumed, so its L2/HBM latency is hidden
-//    behind compute, with ONE workgroup barrier per batch.
-//  * At staging time every thread classifies "its" splat against the four 8x8 blocks using the conservative
-//    extents K1 stored (region where alpha can reach 1/255). Each wave turns that into a 64-bit ballot per 64
-//    staged splats and then walks only the set bits with scalar code: splats that cannot touch the wave's pixels
-//    cost no vector instructions at all. The exact per-pixel gates of the rasterizer (power > 0, alpha < 1/255,
-//    T < 1e-4) are still evaluated unchanged on the survivors, so results are identical to the plain traversal.
-//  * K7 reduces the 10 per-splat gradient components over the wave's 64 pixels with a transposed butterfly
-//    (v_permlane32_swap / v_permlane16_swap halve the register count while crossing lane halves / rows, DPP
-//    row rotations finish inside the 16-lane rows): 28 VALU ops instead of 60, and the 10 sums land in 10
-//    different lanes so that ONE global_atomic_add_f32 instruction commits all of them.
-//  * Load balance: tiles differ in cost by orders of magnitude (empty / silhouette / deep), and a static
-//    blockIdx -> tile map leaves most CUs idle behind a few heavy ones (measured: VALU 27-50 % busy, all on a
-//    subset of CUs). Both kernels are therefore PERSISTENT: a fixed number of workgroups per CU pull work items
-//    from a global atomic counter, and the items are pre-ordered heaviest-first (k_work_order: bucket sort of the
-//    tiles by log2 of list length for K6, by the tile's deepest contributor for K7).
+// Work items, not tiles: K6 takes one 8x8 pixel quarter of a 16x16 tile per 256-thread workgroup (four lanes share a
+// pixel and take four consecutive candidates of the list per step; a whole-tile variant with one pixel per lane serves
+// scenes of thousands of shallow tiles), K7 one (tile, 256-entry segment) with one 8x8 block per wave, restarted from
+// the per-pixel checkpoints K6 leaves at every 256-entry boundary.
+//  * Splat records (3 x float4, written by K1) are gathered by list index 256 at a time into an LDS stage (double-
+//    buffered in K6: the gather of batch b+1 is issued before batch b is consumed, ONE workgroup barrier per batch).
+//  * At staging time every thread tests "its" splat EXACTLY against the four pixel blocks of the workgroup (minimum of
+//    the conic form over the block rectangle vs the splat's tau: block_reach). K6's waves compact the survivors of their
+//    block into a byte list in LDS; K7's waves walk a 64-bit ballot with scalar code. Splats that cannot touch a wave's
+//    pixels cost it no vector instructions; the per-pixel gates (power > 0, alpha < 1/255, T < 1e-4) are evaluated
+//    unchanged on the survivors, as 64-bit lane masks on the scalar unit.
+//  * K7 reduces the 10 per-splat gradient sums over the wave's 64 pixels with a transposed butterfly (25 VALU ops,
+//    reduce10) that leaves them in 10 different lanes: ONE global_atomic_add_f32 instruction commits a splat.
+//  * Load balance: tiles differ in cost by orders of magnitude (empty / silhouette / deep). The work lists are ordered
+//    heaviest-first on the device (k_work_order_fwd / _bwd) and workgroup b simply takes item b: the hardware
+//    dispatcher hands workgroups out in index order as slots free up, i.e. longest-processing-time-first scheduling.
+//    Several views share a launch through a 1-D grid over (item, view) -- see the kernel wrappers below.
+//  * Both kernels are bound by VALU issue (SQ counters: > 80 % of the issue slots): the code below is shaped by
+//    instruction count (scalar lane masks, v_med3, v_rcp, integer min on float bits, no packed fp32 -- the file is built
+//    with -fno-slp-vectorize, see build.py and DESIGN.md).
 // Semantics: SURVEY.md Appendix A.2 / A.3, SEMANTICS.md; outputs as consumed at scene_gaussian.py:1012-1032.
 #include "gsr_common.h"
 
