@@ -16,8 +16,8 @@
 // A Gaussian's pairs with a given tx are its tiles ty = y0..y1-1, contiguous in emission order, so the position of
 // the strip (Gaussian s, column tx) in the tx-sorted list is  colstart[tx] + sum over Gaussians s' < s (depth
 // order) covering tx of h(s')  -- a per-column prefix sum over the depth-ordered rectangles. k_col_hist / k_radix_scan
-// / k_col_plan compute it per run of 256 Gaussians (and N falls out), k_emit_cols writes every pair straight to its
-// tx-sorted position (one lane per tile column walks the run's rectangles), and the remaining pass (by ty, 1-byte
+// / k_col_plan compute it per run of 64 Gaussians (and N falls out), k_emit_cols writes every pair straight to its
+// tx-sorted position (one wave per run; the run's pairs are the wave's elements), and the remaining pass (by ty, 1-byte
 // keys, workgroups aligned to column starts) also yields the tile ranges: the first workgroup of column tx knows,
 // for every ty, the final position of the first pair of tile (ty, tx).
 // The sorted value list and the tile ranges are bit-exact against oracle/gsr_oracle.c (orc_bin_sort); the
