@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--scene", choices=["object", "indoor"], default="object")
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--views-per-step", type=int, default=4)
+    ap.add_argument("--init-opacity", action="store_true",
+                    help="object scene in the reference's initial state: every Gaussian at opacity 0.1 "
+                         "(gs_renderer.py:598; ~87 layers blend before T < 1e-4 stops a pixel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fwd-mode", type=int, default=None, help="force the forward compositing variant (0 / 1)")
@@ -84,7 +87,7 @@ def main():
     H = W = args.res
     if args.scene == "object":
         K, D = 16, args.sh_degree
-        g = synth.g_object(args.gaussians, seed=0, K=K)
+        g = synth.g_object(args.gaussians, seed=0, K=K, init_opacity=args.init_opacity)
         cams = synth.object_cameras(8, H, W)
         workload = f"C3: G-object {args.gaussians} Gaussians (K=16, SH degree {D}), 1 orbit view/GPU @{W}x{H}, fwd+bwd"
     else:

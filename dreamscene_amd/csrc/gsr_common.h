@@ -67,6 +67,14 @@ __device__ __forceinline__ int32_t gsr_f2i_sat(float x) {
   return (int32_t)x;
 }
 
+// The same conversion as ONE instruction: v_cvt_i32_f32 truncates, saturates and maps NaN to 0 by definition (a C++
+// cast is undefined out of range, so the instruction is named explicitly).
+__device__ __forceinline__ int32_t gsr_f2i_sat_fast(float x) {
+  int32_t i;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+  return i;
+}
+
 // ---- wave64 cross-lane reductions on DPP (no LDS traffic) ---------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = true>
 __device__ __forceinline__ float gsr_dpp(float v) {

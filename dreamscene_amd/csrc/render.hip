@@ -23,33 +23,45 @@
 // Semantics: SURVEY.md Appendix A.2 / A.3, SEMANTICS.md; outputs as consumed at scene_gaussian.py:1012-1032.
 #include "gsr_common.h"
 
-// exp() in the compositing loops. The hard gates (alpha < 1/255, T < 1e-4) make the result sensitive to the last
-// bits of exp: with the 2-instruction __expf (error ~ 5e-7 relative, from rounding x*log2(e)) about one pixel per
-// 10^6 lands on the other side of a gate w.r.t. the oracle at the benchmark size; with a ~1 ulp exp none does.
-// GSR_EXP_MODE: 0 = __expf, 1 = compensated exp2 (default: the product x*log2(e) carried in two floats, 6
-// instructions, ~1 ulp), 2 = libm-grade expf.
-#ifndef GSR_EXP_MODE
-#define GSR_EXP_MODE 1
-#endif
-
+// exp() and the quadratic form of the compositing loops are DEFINED operation by operation (SEMANTICS.md section 4) and
+// evaluated identically here and in oracle/gsr_oracle.c (orc_exp, orc_power): the hard gates (power > 0,
+// alpha < 1/255, T < 1e-4) are discontinuities, and any rounding difference in front of them puts about one
+// (pixel, splat) pair per 10^6 pixels on the other side. With IEEE operations only (no v_exp_f32, whose bits are the
+// hardware's) both sides produce the same bits, so n_contrib and final_T are bit-exact against the oracle.
+//   exp:   t = x * float(log2 e); n = rint(t); f = t - n; p = Horner degree 5 in f (fma); result = ldexp(p, int(n))
+//          (10 full-rate VALU operations; the former compensated v_exp_f32 version took 6 incl. one transcendental)
+//   power: dx * (hA dx + nB dy) + (hC dy) dy with hA = -A/2, nB = -B, hC = -C/2 formed (exactly) when a splat is
+//          staged: 3 multiplies + 2 fma per evaluation instead of 5 + 2.
 namespace {
 
 constexpr int kBatch = 256;
 
+// One IEEE rounding per operation, never contracted into an FMA (HIP's __fmul_rn / __fsub_rn are plain operators and
+// WOULD be contracted under the default -ffp-contract=fast; the pragma removes the `contract` flag from the
+// instructions generated inside these functions, and inlining keeps instruction flags).
+__device__ __forceinline__ float gsr_mul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float gsr_sub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
 __device__ __forceinline__ float gsr_exp(float x) {
-#if GSR_EXP_MODE == 0
-  return __expf(x);
-#elif GSR_EXP_MODE == 1
-  constexpr float kL2eHi = 1.44269502162933349609375f;       // float(log2(e))
-  constexpr float kL2eLo = 1.925963033500011e-08f;           // log2(e) - float(log2(e))
-  constexpr float kLn2 = 0.693147180559945309f;
-  const float t = x * kL2eHi;
-  const float lo = __fmaf_rn(x, kL2eLo, __fmaf_rn(x, kL2eHi, -t));   // what the rounded product dropped
-  const float e = __builtin_amdgcn_exp2f(t);
-  return __fmaf_rn(e, lo * kLn2, e);                                  // 2^(t+lo) = 2^t (1 + lo ln 2 + ...)
-#else
-  return expf(x);
-#endif
+  const float t = gsr_mul(x, 1.44269502162933349609375f);
+  const float n = __builtin_rintf(t);
+  const float f = gsr_sub(t, n);
+  float p = 0.001326472731307149f;
+  p = __fmaf_rn(p, f, 0.009671512991189957f);
+  p = __fmaf_rn(p, f, 0.05550733581185341f);
+  p = __fmaf_rn(p, f, 0.24022242426872253f);
+  p = __fmaf_rn(p, f, 0.6931470036506653f);
+  p = __fmaf_rn(p, f, 1.0f);
+  return __builtin_amdgcn_ldexpf(p, gsr_f2i_sat_fast(n));
+}
+// power from the staged (hA, nB, hC) = (-A/2, -B, -C/2)
+__device__ __forceinline__ float gsr_power(float hA, float nB, float hC, float dx, float dy) {
+  return __fmaf_rn(dx, __fmaf_rn(hA, dx, gsr_mul(nB, dy)), gsr_mul(gsr_mul(hC, dy), dy));
 }
 
 struct TilePix {
@@ -239,8 +251,9 @@ __device__ __forceinline__ uint32_t stage_mask(const float4& s2row) { return __f
 //     of the earlier slots' (1-alpha)) -- a 2-step quad scan on DPP quad_perm, no LDS; the T < 1e-4 stop is an
 //     OR-scan over the quad; the new T is the quad-min of the survivors' T(1-alpha);
 //   * colour / depth / alpha partial sums stay per lane and are folded over the quad once, at the end.
-// 4x more (and 4x finer) work items, 4x shorter dependency chains, tighter 4x4 culling; same gates in the same
-// list order (the only numerical change is the association of the running product inside a quad, ulp-level).
+// 4x more (and 4x finer) work items, tighter 4x4 culling; same gates in the same list order on the same bits (the
+// transmittance is multiplied up in list order inside the quad; only the colour / depth / alpha SUMS associate
+// differently from a sequential loop, at the 1e-7 level).
 template <bool SCORE>
 __device__ __forceinline__ void
 render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* __restrict__ work, float* __restrict__ ckpt,
@@ -298,7 +311,9 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
     int buf = 0;
     for (uint32_t base = r0; base < r1; base += kBatch, buf ^= 1) {
       const int n = (int)min((uint32_t)kBatch, r1 - base);
-      st.s0[buf][tid] = n0; st.s1[buf][tid] = n1;
+      // staged with the conic as (hA, nB, hC) = (-A/2, -B, -C/2): what gsr_power takes (exact scalings)
+      st.s0[buf][tid] = make_float4(n0.x, n0.y, -0.5f * n0.z, -n0.w);
+      st.s1[buf][tid] = make_float4(-0.5f * n1.x, n1.y, n1.z, n1.w);
       st.s2[buf][tid] = make_float4(n2.x, n2.y, n2.z,
                                     __uint_as_float((tid < n) ? block_mask_t<4>(n0, n1, n2, q_x0, q_y0) : 0u));
       if constexpr (SCORE) st.sid[buf][tid] = nid;
@@ -349,24 +364,28 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
           const float4 b = st.s1[buf][j];
           const float2 c = *reinterpret_cast<const float2*>(&st.s2[buf][j]);
           const float dx = a.x - pxf, dy = a.y - pyf;
-          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
+          const float power = gsr_power(a.z, a.w, b.x, dx, dy);
+          const float alpha = fminf(GSR_ALPHA_MAX, gsr_mul(b.y, gsr_exp(power)));
           // lanes whose slot holds a candidate: the low nv lanes of every quad
           const unsigned long long nvm = 0x1111111111111111ull * (unsigned long long)((1u << nv) - 1u);
           const unsigned long long gm = nvm & ~donem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                         __builtin_amdgcn_ballot_w64(alpha >= GSR_ALPHA_MIN);
           const bool g = __builtin_amdgcn_inverse_ballot_w64(gm);
-          // inclusive product of (1 - alpha) over the quad's gated slots
-          float P = g ? (1.0f - alpha) : 1.0f;
+          // transmittance after this slot, multiplied up in LIST ORDER -- ((T f0) f1) f2 ... with f = 1 - alpha of a
+          // gated slot, 1 otherwise -- so that it carries the bits of the sequential recurrence T <- T (1 - alpha) (the
+          // T < 1e-4 stop is a hard gate: SEMANTICS.md section 4). Three dependent quad steps: after step k slot k is final.
+          const float fgate = g ? gsr_sub(1.0f, alpha) : 1.0f;
+          float test_T = gsr_mul(T, fgate);
           {
-            const float t1 = gsr_dpp<0x90>(P);           // quad_perm [0,0,1,2]: value of slot-1
-            P = (slot >= 1) ? P * t1 : P;
-            const float t2 = gsr_dpp<0x44>(P);           // quad_perm [0,1,0,1]: value of slot-2
-            P = (slot >= 2) ? P * t2 : P;
+            const float t1 = gsr_dpp<0x90>(test_T);      // quad_perm [0,0,1,2]: value of slot-1
+            test_T = (slot >= 1) ? gsr_mul(t1, fgate) : test_T;
+            const float t2 = gsr_dpp<0x90>(test_T);
+            test_T = (slot >= 2) ? gsr_mul(t2, fgate) : test_T;
+            const float t3 = gsr_dpp<0x90>(test_T);
+            test_T = (slot >= 3) ? gsr_mul(t3, fgate) : test_T;
           }
-          const float Pex = gsr_dpp<0x90>(P);
-          const float T_before = (slot >= 1) ? T * Pex : T;
-          const float test_T = T * P;
+          const float Tprev = gsr_dpp<0x90>(test_T);
+          const float T_before = (slot >= 1) ? Tprev : T;
           // the first slot (in list order) whose own contribution would drop T below the threshold stops the pixel:
           // inclusive OR over the slots <= mine, formed on the scalar unit from the wave's 64-bit flag mask
           unsigned long long stopm = gm & __builtin_amdgcn_ballot_w64(test_T < GSR_T_MIN);
@@ -469,7 +488,8 @@ render_fwd_tile_body(const uint32_t item, const int W, const int H, const uint32
   int buf = 0;
   for (uint32_t base = r0; base < r1; base += kBatch, buf ^= 1) {
     const int n = (int)min((uint32_t)kBatch, r1 - base);
-    st.s0[buf][tid] = n0; st.s1[buf][tid] = n1;
+    st.s0[buf][tid] = make_float4(n0.x, n0.y, -0.5f * n0.z, -n0.w);      // conic staged as (hA, nB, hC)
+    st.s1[buf][tid] = make_float4(-0.5f * n1.x, n1.y, n1.z, n1.w);
     st.s2[buf][tid] = make_float4(n2.x, n2.y, n2.z,
                                   __uint_as_float((tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u));
     if constexpr (SCORE) st.sid[buf][tid] = nid;
@@ -497,9 +517,9 @@ render_fwd_tile_body(const uint32_t item, const int W, const int H, const uint32
         const float4 b = st.s1[buf][j];
         const float4 c = st.s2[buf][j];
         const float dx = a.x - pxf, dy = a.y - pyf;
-        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-        const float alpha = fminf(GSR_ALPHA_MAX, b.y * gsr_exp(power));
-        const float test_T = T * (1.0f - alpha);
+        const float power = gsr_power(a.z, a.w, b.x, dx, dy);
+        const float alpha = fminf(GSR_ALPHA_MAX, gsr_mul(b.y, gsr_exp(power)));
+        const float test_T = gsr_mul(T, gsr_sub(1.0f, alpha));
         const unsigned long long gm = ~donem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                       __builtin_amdgcn_ballot_w64(alpha >= GSR_ALPHA_MIN);
         const unsigned long long stopm = gm & __builtin_amdgcn_ballot_w64(test_T < GSR_T_MIN);
@@ -619,7 +639,9 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       const float4* r = splat + 3 * (size_t)nid;
       n0 = r[0]; n1 = r[1]; n2 = r[2];
     }
-    s0[tid] = n0; s1[tid] = n1; s2[tid] = n2;
+    s0[tid] = make_float4(n0.x, n0.y, -0.5f * n0.z, -n0.w);              // conic staged as (hA, nB, hC)
+    s1[tid] = make_float4(-0.5f * n1.x, n1.y, n1.z, n1.w);
+    s2[tid] = n2;
     sid[tid] = nid;
     smask[tid] = (tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u;
   }
@@ -668,9 +690,9 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       const float4 a = s0[j];
       const float4 b = s1[j];
       const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+      const float power = gsr_power(a.z, a.w, b.x, dx, dy);
       const float G = gsr_exp(power);
-      const float alpha = fminf(GSR_ALPHA_MAX, b.y * G);
+      const float alpha = fminf(GSR_ALPHA_MAX, gsr_mul(b.y, G));
       // the gates as 64-bit lane masks on the scalar unit
       const unsigned long long hitm = livem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                       __builtin_amdgcn_ballot_w64(alpha >= GSR_ALPHA_MIN);

@@ -57,6 +57,37 @@ static int32_t f2i_sat(float x) {
   return (int32_t)x;
 }
 static int32_t imin(int32_t a, int32_t b) { return a < b ? a : b; }
+
+/* exp() of the compositing loops -- THE definition (SEMANTICS.md section 4): 2^(x log2 e) with a round-to-nearest
+ * split t = n + f, f in [-1/2, 1/2], a degree-5 polynomial in Horner form and an exact scaling by 2^n. IEEE
+ * operations only (one rounding per *, -, fmaf; rintf = round-half-even; ldexpf exact), so render.hip evaluates the
+ * very same expression tree (v_mul, v_rndne, v_sub, 5 x v_fma, v_cvt_i32, v_ldexp) and the two agree BIT FOR BIT --
+ * which is what keeps the hard gates (alpha >= 1/255, T >= 1e-4) on the same side in both. Accuracy: <= 1.7e-7
+ * relative from the polynomial + the rounding of t (<= 6e-8 |t|), the class of the lineage's __expf. exp(0) = 1. */
+#define EXP_L2E 1.44269502162933349609375f /* float(log2 e) */
+#define EXP_C1 0.6931470036506653f
+#define EXP_C2 0.24022242426872253f
+#define EXP_C3 0.05550733581185341f
+#define EXP_C4 0.009671512991189957f
+#define EXP_C5 0.001326472731307149f
+static float orc_exp(float x) {
+  const float t = x * EXP_L2E;
+  const float n = rintf(t);
+  const float f = t - n;
+  float p = EXP_C5;
+  p = fmaf(p, f, EXP_C4);
+  p = fmaf(p, f, EXP_C3);
+  p = fmaf(p, f, EXP_C2);
+  p = fmaf(p, f, EXP_C1);
+  p = fmaf(p, f, 1.0f);
+  return ldexpf(p, f2i_sat(n));
+}
+/* The quadratic form of the compositing loops, with its rounding points fixed (SEMANTICS.md section 4):
+ * power = dx (hA dx + nB dy) + (hC dy) dy with hA = -A/2, nB = -B, hC = -C/2 (exact), two fused multiply-adds. */
+static float orc_power(float A, float B, float C, float dx, float dy) {
+  const float hA = -0.5f * A, nB = -B, hC = -0.5f * C;
+  return fmaf(dx, fmaf(hA, dx, nB * dy), (hC * dy) * dy);
+}
 static int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
 
 static void quat_to_R(const float* q, float R[9]) {
@@ -275,9 +306,9 @@ void orc_render_fwd(const OrcView* v, const uint32_t* ranges, const uint32_t* po
         const uint32_t g = point_list[j];
         const float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
         const float* co = conic_opacity + 4 * g;
-        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        const float power = orc_power(co[0], co[1], co[2], dx, dy);
         if (power > 0.0f) continue;
-        const float alpha = fminf(ALPHA_MAX, co[3] * expf(power));
+        const float alpha = fminf(ALPHA_MAX, co[3] * orc_exp(power));
         if (alpha < ALPHA_MIN) continue;
         const float test_T = T * (1.0f - alpha);
         if (test_T < T_MIN) break;
@@ -324,9 +355,9 @@ void orc_render_bwd(const OrcView* v, const uint32_t* ranges, const uint32_t* po
         const uint32_t g = point_list[a0 + k];
         const float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
         const float* co = conic_opacity + 4 * g;
-        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        const float power = orc_power(co[0], co[1], co[2], dx, dy);
         if (power > 0.0f) continue;
-        const float G = expf(power);
+        const float G = orc_exp(power);
         const float alpha = fminf(ALPHA_MAX, co[3] * G);
         if (alpha < ALPHA_MIN) continue;
         T = T / (1.0f - alpha);

@@ -51,9 +51,9 @@ def _check_forward(out, f, P):
     scale_d = max(1.0, float(np.abs(f["depth_alpha"]).max()))
     assert e_img <= TOL, f"image err {e_img}"
     assert e_da <= TOL * scale_d, f"depth/alpha err {e_da}"
-    assert err(out["final_T"].cpu().numpy(), f["final_T"]) <= TOL
-    nc = out["n_contrib"].cpu().numpy().view(np.uint32)
-    assert (nc != f["n_contrib"]).mean() <= 1e-4, "n_contrib differs on more than 0.01% of pixels"
+    # the gates (power > 0, alpha < 1/255, T < 1e-4) see the same bits in both implementations (SEMANTICS.md section 4/6)
+    assert np.array_equal(out["final_T"].cpu().numpy().view(np.uint32), f["final_T"].view(np.uint32)), "final_T bits"
+    assert np.array_equal(out["n_contrib"].cpu().numpy().view(np.uint32), f["n_contrib"]), "n_contrib"
 
 
 @pytest.mark.parametrize("D,K", [(0, 16), (1, 4), (2, 9), (3, 16)])
@@ -201,9 +201,8 @@ def test_edge_cases(built_lib, c_oracle):
 
 def test_long_lists_multi_batch(built_lib, c_oracle):
     """Per-tile lists of thousands of entries (many 256-splat staging rounds), early termination inside deep
-    lists, and the backward starting from the tile's max contributor. Integer artefacts stay bit-exact; float
-    outputs within 1e-5 except for the rare pixels where a hard gate (alpha < 1/255, T < 1e-4) falls on the other
-    side of a rounding difference -- counted and bounded here, explained in DESIGN.md 'gates'."""
+    lists, and the backward starting from the tile's max contributor. Integer artefacts, n_contrib and final_T
+    bit-exact (the hard gates see identical bits, SEMANTICS.md section 4/6); float outputs within 1e-5, no allowance."""
     from dreamscene_amd import rasterizer as R, synth
     P, H, W, K, D = 60000, 192, 192, 16, 3
     g = synth.g_object(P, seed=77, K=K)
@@ -219,11 +218,10 @@ def test_long_lists_multi_batch(built_lib, c_oracle):
     assert np.array_equal(out["keys_sorted"].cpu().numpy().view(np.uint64), f["keys"])
     assert np.array_equal(out["ranges"].cpu().numpy().view(np.uint32), f["ranges"])
     d_img = np.abs(out["color"].cpu().numpy() - f["image"]).max(axis=0)
-    flips = (out["n_contrib"].cpu().numpy().view(np.uint32) != f["n_contrib"])
-    bad = d_img > TOL
-    print(f"pixels over 1e-5: {bad.sum()} of {bad.size}; n_contrib differs at {flips.sum()}; max err {d_img.max():.3e}")
-    assert bad.mean() <= 2e-4, "more than 0.02% of pixels exceed 1e-5"
-    assert d_img.max() <= 5e-3      # a flipped gate moves a pixel by at most ~alpha_min * T * |c - behind|
+    assert np.array_equal(out["n_contrib"].cpu().numpy().view(np.uint32), f["n_contrib"]), "n_contrib"
+    assert np.array_equal(out["final_T"].cpu().numpy().view(np.uint32), f["final_T"].view(np.uint32)), "final_T bits"
+    print(f"max image err {d_img.max():.3e}")
+    assert d_img.max() <= TOL
     gi, gda = synth.upstream_grads(H, W, 3)
     o = R.rasterize_backward_raw(st, torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV))
     b = c_oracle.backward(v, f, gi, gda, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
@@ -232,9 +230,8 @@ def test_long_lists_multi_batch(built_lib, c_oracle):
         a, r = o[hk].cpu().numpy().reshape(-1), np.asarray(b[ok]).reshape(-1)
         e = np.abs(a - r)
         scale = max(1.0, float(np.abs(r).max()))
-        frac = float((e > TOL * scale).mean())
-        print(f"{hk}: max err {e.max():.3e} (max|ref| {np.abs(r).max():.3e}), frac over tol {frac:.2e}")
-        assert frac <= 2e-4 and e.max() <= 1e-3 * scale
+        print(f"{hk}: max err {e.max():.3e} (max|ref| {np.abs(r).max():.3e})")
+        assert e.max() <= TOL * scale
 
 
 def test_capacity_mode_matches_exact(built_lib):
@@ -351,10 +348,10 @@ def test_more_than_65536_tiles(built_lib, c_oracle):
     assert np.array_equal(out["point_list"].cpu().numpy().view(np.uint32), f["point_list"])
     assert np.array_equal(out["ranges"].cpu().numpy().view(np.uint32), f["ranges"])
     assert np.array_equal(out["keys_sorted"].cpu().numpy().view(np.uint64), f["keys"])
-    # 17 M pixels x ~100 gate evaluations each: a handful of (pixel, splat) pairs may sit on the other side of a hard
-    # gate (SEMANTICS.md section 6); bound their number and size instead of the plain max
+    # 17 M pixels x ~100 gate evaluations each, all on the same side of every hard gate as the oracle
+    assert np.array_equal(out["n_contrib"].cpu().numpy().view(np.uint32), f["n_contrib"]), "n_contrib"
     d_img = np.abs(out["color"].cpu().numpy() - f["image"]).max(axis=0)
-    assert (d_img > TOL).mean() <= 1e-5 and d_img.max() <= 5e-3, ((d_img > TOL).sum(), d_img.max())
+    assert d_img.max() <= TOL, d_img.max()
 
 
 def test_score_mode_alpha_T(built_lib, c_oracle):
