@@ -167,6 +167,7 @@ static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geo
   if (!aligned16(geom->splat)) return GSR_EINVAL;
   if (geom->scratch_bytes < gsr_project_scratch_bytes(v->P)) return GSR_ESCRATCH;
   hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(geom->splat);
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS);
     rc = gsr_launch_preprocess(*v, *g, *geom, stream);
@@ -212,6 +213,7 @@ int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGa
   }
   if (v0.P == 0) return GSR_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(geoms[0].splat);
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS);
     bool same_view_consts = true;
@@ -272,6 +274,7 @@ int gsr_forward_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs, 
   int rc = check_render(v, geom, n_pairs, b, img);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(img->color);
   rc = render_binning(v, geom, n_pairs, b, stream, prof);
   if (rc) return rc;
   rc = gsr_launch_work_order_fwd(1, v, b, img, stream);
@@ -288,6 +291,7 @@ int gsr_forward_render_batch(int32_t n_views, const GsrView* views, const GsrGeo
     if (views[k].image_height != views[0].image_height || views[k].image_width != views[0].image_width) return GSR_EINVAL;
   }
   hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(imgs[0].color);
   // capacity mode + equally spaced scratch buffers: emission and the ty pass of all views share their launches
   bool all_dev = true;
   for (int k = 0; k < n_views; ++k) all_dev = all_dev && bs[k].count_on_device && views[k].P == views[0].P;
@@ -361,6 +365,7 @@ int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, c
   if (rc) return rc;
   if (v->P == 0) return GSR_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(out->partials);
   rc = gsr_launch_work_order_bwd(1, v, b, img, stream);
   if (rc) return rc;
   rc = backward_render(v, geom, b, img, ig, out, stream, prof);
@@ -392,6 +397,7 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   }
   if (views[0].P == 0) return GSR_OK;
   hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(outs[0].partials);
   if (per_view_scales)       // every view then needs its own scale gradient buffer
     for (int k = 0; k < n_views; ++k)
       for (int j = 0; j < k; ++j)

@@ -24,6 +24,27 @@ extern thread_local int gsr_tls_hip_error;
     }                                          \
   } while (0)
 
+// Every entry point runs on the device that owns the caller's buffers, whatever the calling thread's current device is
+// (hipSetDevice from the pointer attributes per call); the previous device is restored on return.
+struct GsrDeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit GsrDeviceGuard(const void* device_ptr) {
+    hipPointerAttribute_t a;
+    if (!device_ptr || hipPointerGetAttributes(&a, device_ptr) != hipSuccess) {
+      (void)hipGetLastError();   // not a pointer the runtime knows: leave the current device alone
+      return;
+    }
+    if (hipGetDevice(&prev) != hipSuccess || a.device == prev) return;
+    changed = hipSetDevice(a.device) == hipSuccess;
+  }
+  ~GsrDeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+  GsrDeviceGuard(const GsrDeviceGuard&) = delete;
+  GsrDeviceGuard& operator=(const GsrDeviceGuard&) = delete;
+};
+
 struct GsrProfile {
   static constexpr int kMax = 4096;
   hipEvent_t ev[kMax][2];

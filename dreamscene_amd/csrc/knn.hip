@@ -154,6 +154,11 @@ k_knn_query(const float* __restrict__ pts, int n, const int* __restrict__ bbox, 
   out[me] = (b0 + b1 + b2) / 3.0f;
 }
 
+// bbox[0..2] = +INT_MAX (running minima), bbox[3..5] = INT_MIN (running maxima)
+__global__ void k_knn_init(int* __restrict__ bbox) {
+  if (threadIdx.x < 6) bbox[threadIdx.x] = threadIdx.x < 3 ? 0x7FFFFFFF : (int)0x80000000;
+}
+
 }  // namespace
 
 extern "C" size_t gsr_knn_scratch_bytes(int32_t n) {
@@ -173,6 +178,7 @@ extern "C" int gsr_knn_mean_dist2(const float* points, int32_t n, float* out, vo
   if (n == 0) return GSR_OK;
   if (!scratch || scratch_bytes < gsr_knn_scratch_bytes(n)) return GSR_ESCRATCH;
   hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(points);
   const uint64_t m = (uint64_t)n;
   char* b = (char*)scratch;
   uint32_t* k0 = (uint32_t*)b; b += align256(m * 4);
@@ -187,8 +193,7 @@ extern "C" int gsr_knn_mean_dist2(const float* points, int32_t n, float* out, vo
   R = std::max(1, std::min(kMaxR, R));
   // the device recomputes R the same way from n (cbrtf): keep one cell of slack per axis for rounding
   const size_t cells = (size_t)std::min<uint64_t>((uint64_t)(R + 1) * (R + 1) * (R + 1), (uint64_t)kMaxR * kMaxR * kMaxR);
-  static const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-  GSR_HIP(hipMemcpyAsync(bbox, init, sizeof init, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_knn_init, dim3(1), dim3(64), 0, stream, bbox);   // (min, max) sentinels: no host->device copy
   GSR_HIP(hipMemsetAsync(ranges, 0, cells * 8, stream));
   const int nb = (n + 255) / 256;
   hipLaunchKernelGGL(k_knn_bbox, dim3(std::min(nb, 1024)), dim3(256), 0, stream, points, n, bbox);

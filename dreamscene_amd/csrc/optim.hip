@@ -95,6 +95,7 @@ extern "C" int gsr_adam_step(const GsrAdamGroup* groups, int32_t n_groups, int32
   t.n = n;
   for (int i = n; i <= GSR_MAX_ADAM_GROUPS; ++i) t.fblk[i] = blk;
   if (blk == 0) return GSR_OK;
+  GsrDeviceGuard dev(t.param[0]);
   hipLaunchKernelGGL(k_adam, dim3((uint32_t)blk), dim3(256), 0, (hipStream_t)stream_, t, (float)(1.0 - beta1), (float)beta2,
                      (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (int)zero_grad);
   GSR_HIP(hipGetLastError());

@@ -1273,6 +1273,9 @@ struct K8Views {
   const float* scale_noise[GSR_MAX_BATCH_VIEWS];
   const float* sh_noise[GSR_MAX_BATCH_VIEWS];
   const float* dL_dscales_out[GSR_MAX_BATCH_VIEWS];
+  // bit k set: view k's densification statistics count (the reference's trainers use the LAST view of a step only,
+  // object_trainer.py:386-390; a caller sets the stat_* pointers on the GsrGrads entries of the views that count)
+  uint32_t stat_mask;
 };
 
 template <int KT, bool PVS>   // PVS: per-view scales
@@ -1396,7 +1399,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
 #pragma unroll
         for (int k = 0; k < 9; ++k) dS[k] += dSv[k];
       }
-      if (out.stat_denom) {
+      if (out.stat_denom && ((vb.stat_mask >> vv) & 1u)) {
         out.stat_xyz_gradient_accum[i] += sqrtf(gndx * gndx + gndy * gndy);
         out.stat_denom[i] += 1.0f;
         out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)vb.radii[vv][i]);
@@ -1578,7 +1581,7 @@ k_preprocess_bwd_views_scene(const GsrView v, const SceneTab sc, const SceneGrad
       for (int k = 0; k < 3; ++k) dsraw[k] += ds_v[k] * dsc[k];
 #pragma unroll
       for (int k = 0; k < 4; ++k) drot[k] += dr_v[k];
-      if (out.stat_denom) {
+      if (out.stat_denom && ((vb.stat_mask >> vv) & 1u)) {
         out.stat_xyz_gradient_accum[i] += sqrtf(gndx * gndx + gndy * gndy);
         out.stat_denom[i] += 1.0f;
         out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)vb.radii[vv][i]);
@@ -1778,13 +1781,25 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
     vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy; vb.sh_degree[k] = views[k].sh_degree;
     vb.radii[k] = geoms[k].radii; vb.partials[k] = outs[k].partials; vb.dL_dmeans2D[k] = outs[k].dL_dmeans2D;
   }
+  // densification statistics: the views whose GsrGrads entry names the statistics tensors (all the same ones)
+  GsrGrads out0 = outs[0];
+  out0.stat_max_radii2D = nullptr; out0.stat_xyz_gradient_accum = nullptr; out0.stat_denom = nullptr;
+  for (int k = 0; k < n_views; ++k) {
+    if (!outs[k].stat_denom) continue;
+    if (out0.stat_denom && (outs[k].stat_denom != out0.stat_denom || outs[k].stat_max_radii2D != out0.stat_max_radii2D ||
+                            outs[k].stat_xyz_gradient_accum != out0.stat_xyz_gradient_accum))
+      return GSR_EINVAL;
+    out0.stat_max_radii2D = outs[k].stat_max_radii2D; out0.stat_xyz_gradient_accum = outs[k].stat_xyz_gradient_accum;
+    out0.stat_denom = outs[k].stat_denom;
+    vb.stat_mask |= 1u << k;
+  }
   const GsrView& v = views[0];
   const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
   if (g.scene) {
     SceneTab t; SceneGradTab gt;
     const uint32_t nbs = scene_tables(*g.scene, outs[0].scene, t, gt);
 #define GSR_LAUNCH_K8VS(KT) \
-  hipLaunchKernelGGL(k_preprocess_bwd_views_scene<KT>, dim3(nbs), dim3(256), lds, stream, v, t, gt, vb, outs[0])
+  hipLaunchKernelGGL(k_preprocess_bwd_views_scene<KT>, dim3(nbs), dim3(256), lds, stream, v, t, gt, vb, out0)
     switch (v.sh_stride) {
       case 16: GSR_LAUNCH_K8VS(16); break;
       case 9: GSR_LAUNCH_K8VS(9); break;
@@ -1799,9 +1814,9 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
   const uint32_t nb = gsr_num_blocks(v.P);
 #define GSR_LAUNCH_K8V(KT)                                                                                       \
   if (vb.per_view_scales)                                                                                        \
-    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, outs[0]);  \
-  else                                                                                                           \
-    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, false>), dim3(nb), dim3(256), lds, stream, v, g, vb, outs[0])
+    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, out0);  \
+  else                                                                                                        \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, false>), dim3(nb), dim3(256), lds, stream, v, g, vb, out0)
   switch (v.sh_stride) {
     case 16: GSR_LAUNCH_K8V(16); break;
     case 9: GSR_LAUNCH_K8V(9); break;

@@ -1,9 +1,11 @@
 """Host-side pieces of the post-raster epilogue that are not per-step kernels.
 
 * `DensifyStats`: the three per-Gaussian statistics tensors of GaussianModel (`max_radii2D`, `xyz_gradient_accum`,
-  `denom`; gs_renderer.py:612-613, 1061-1065) updated INSIDE the rasterizer backward (K8) for the view rendered under
-  `with stats.collect():` -- instead of five boolean-mask indexing kernels after `loss.backward()`
-  (object_trainer.py:386-390).
+  `denom`; gs_renderer.py:612-613, 1061-1065) updated INSIDE the rasterizer backward (K8) for the views whose FORWARD
+  runs under `with stats.collect(context):` -- instead of five boolean-mask indexing kernels after `loss.backward()`
+  (object_trainer.py:386-390). With several views per call the LAST view counts (that is what the reference's trainers
+  do with the loop's last viewspace_points / visibility_filter / radii); `views="all"` or a list of indices opts in to
+  more (then denom grows once per counted view and max_radii2D is the maximum over them).
 * `importance_prune_mask`: the 3D-Gaussian-filtering threshold of `calculate_v_imp_score` + `prune_gaussians`
   (scene_gaussian.py:1046-1061, gs_renderer.py:1082-1087) with two k-th order statistics instead of two full sorts.
 """
@@ -22,15 +24,20 @@ class DensifyStats:
         self.xyz_gradient_accum = torch.zeros(P, dtype=torch.float32, device=device)
         self.denom = torch.zeros(P, dtype=torch.float32, device=device)
 
+    def tensors(self) -> tuple:
+        return (self.max_radii2D, self.xyz_gradient_accum, self.denom)
+
     @contextlib.contextmanager
-    def collect(self):
-        """Views whose BACKWARD runs inside this block update the statistics (visible Gaussians only)."""
-        prev = R.DENSIFY_STATS
-        R.DENSIFY_STATS = (self.max_radii2D, self.xyz_gradient_accum, self.denom)
+    def collect(self, context: "R.RasterContext", views=None):
+        """Rasterizer calls using `context` whose FORWARD runs inside this block update the statistics in their backward
+        (visible Gaussians only; the forward takes a snapshot of the context, so the backward may run later and on
+        autograd's thread). views: for multi-view calls, which views count -- None = the last one, "all", or indices."""
+        prev = (context.densify_stats, context.stats_views)
+        context.densify_stats, context.stats_views = self.tensors(), views
         try:
             yield self
         finally:
-            R.DENSIFY_STATS = prev
+            context.densify_stats, context.stats_views = prev
 
     def mean_grad(self) -> torch.Tensor:
         """grads = xyz_gradient_accum / denom with NaN -> 0 (gs_renderer.py:1035-1036)."""

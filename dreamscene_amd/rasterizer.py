@@ -16,8 +16,9 @@ PyTorch is used for device memory, streams and autograd plumbing only; all arith
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import time
-from typing import NamedTuple, Optional
+from typing import NamedTuple, Optional, Sequence
 
 import torch
 
@@ -39,29 +40,56 @@ class GaussianRasterizationSettings(NamedTuple):
     score_flag: bool = False
 
 
-# important_score weight (the fork's exact definition is unpinned, SEMANTICS.md): 0 = opacity per contributing
-# (pixel, splat) pair [default, the LightGaussian global-significance hit term], 1 = alpha*T.
-SCORE_MODE = 0
-# optional GsrProfile handle (bench.py sets it to collect per-kernel HIP-event timings)
-PROFILE: Optional[L.Profile] = None
-# optional multiview.GradArena: when set, the autograd backward writes the parameter gradients of the view
-# straight into the arena's flat buffer (zero-copy hand-off to the RCCL all-reduce) and returns views of it
-GRAD_ARENA = None
-# Optional (max_radii2D, xyz_gradient_accum, denom) fp32 tensors with P elements: the backward of the NEXT rasterized
-# view updates them for its visible Gaussians inside K8 (what the trainers do with radii / visibility_filter /
-# viewspace_points.grad after backward, object_trainer.py:386-390). Set it for the view whose statistics count.
-DENSIFY_STATS = None
-# with a GRAD_ARENA: False = this view's gradients overwrite the arena, True = they are ADDED to it on the device
-# (sum over the views of one optimizer step before a single all-reduce)
-ACCUMULATE = False
+@dataclasses.dataclass
+class RasterContext:
+    """Everything that steers a rasterizer call beyond the reference's 12 settings fields. One object per
+    GaussianRasterizer (or per call of the raw functions); the autograd Functions take a SNAPSHOT of it at forward time
+    and the backward -- which autograd runs on its own thread -- reads only that snapshot: nothing here is a module
+    global, two rasterizers with different contexts can run forward / backward concurrently.
+
+    score_mode     important_score weight (the fork's exact definition is unpinned, SEMANTICS.md section 4):
+                   0 = opacity per contributing (pixel, splat) pair [default, LightGaussian's hit term], 1 = alpha * T
+    profile        optional GsrProfile handle (bench.py: per-kernel HIP-event timings)
+    grad_arena     optional multiview.GradArena: the backward writes the parameter gradients of the view straight into
+                   the arena's flat buffer (zero-copy hand-off to the exchange) and returns NO parameter gradients to
+                   autograd (param.grad is left alone: the arena is where they live; returning views of it would make
+                   loss.backward() add the arena to .grad a second time)
+    accumulate     with an arena: False = this call's gradients overwrite the arena, True = they are ADDED on the
+                   device (sum over the views of one optimizer step before a single exchange)
+    densify_stats  optional (max_radii2D, xyz_gradient_accum, denom) fp32 [P] tensors updated inside K8 for the visible
+                   Gaussians of the call's view (object_trainer.py:386-390); several views per call: `stats_views`
+    stats_views    indices of the views of a multi-view call whose statistics count; None = the LAST view only, which is
+                   what the reference's trainers do (the loop's last viewspace_points / visibility_filter / radii)
+    forward_mode   "auto": speculate the pair capacity from previous calls and enqueue the whole forward without draining
+                   the GPU (exact re-run if it was too small); "sync": always the exact two-phase forward
+    fwd_variant    forward compositing variant (GsrBinning.fwd_mode): None = per call from the previous view's statistics
+    """
+    score_mode: int = 0
+    profile: Optional[L.Profile] = None
+    grad_arena: Optional[object] = None
+    accumulate: bool = False
+    densify_stats: Optional[tuple] = None
+    stats_views: Optional[Sequence[int]] = None
+    forward_mode: str = "auto"
+    fwd_variant: Optional[int] = None
+
+    def snapshot(self) -> "RasterContext":
+        return dataclasses.replace(self)
+
+
+DEFAULT_CONTEXT = RasterContext()
+# seconds this process has spent blocked on the projection's pair count (a statistic, not a switch; bench.py reports it
+# per step: how much of a step the host is idle, i.e. how far the path is from being bound by host-side enqueueing)
+HOST_WAIT_S = [0.0]
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _prep(t: Optional[torch.Tensor], name: str, dev: torch.device) -> Optional[torch.Tensor]:
-    """fp32, contiguous, on `dev`, 16-byte aligned base (what the ABI requires)."""
+def _prep(t: Optional[torch.Tensor], name: str, dev: torch.device, align: int = 16) -> Optional[torch.Tensor]:
+    """fp32, contiguous, on `dev`, base aligned to `align` bytes (the ABI wants 16 for shs / rotations / splat rows; the
+    other inputs are read element-wise, e.g. the [k] slices of per-view scales [V,P,3] with P % 4 != 0)."""
     if t is None:
         return None
     if t.device != dev:
@@ -69,24 +97,25 @@ def _prep(t: Optional[torch.Tensor], name: str, dev: torch.device) -> Optional[t
     if t.dtype != torch.float32:
         t = t.float()
     t = t.contiguous()
-    if t.data_ptr() % 16:
+    if t.data_ptr() % align:
         t = t.clone()
     return t
 
 
-def _view_struct(s: GaussianRasterizationSettings, P: int, K: int, bg, vm, pm, cp) -> L.GsrView:
+def _view_struct(s: GaussianRasterizationSettings, P: int, K: int, bg, vm, pm, cp, score_mode: int = 0) -> L.GsrView:
     v = L.GsrView()
     v.P, v.sh_stride, v.sh_degree = P, K, int(s.sh_degree)
     v.image_height, v.image_width = int(s.image_height), int(s.image_width)
     v.tanfovx, v.tanfovy, v.scale_modifier = float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier)
-    v.prefiltered, v.score_mode = int(bool(s.prefiltered)), int(SCORE_MODE)
+    v.prefiltered, v.score_mode = int(bool(s.prefiltered)), int(score_mode)
     v.bg, v.viewmatrix, v.projmatrix, v.campos = bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr()
     return v
 
 
 class _State:
     """Everything the backward needs; tensors are kept alive here (the C side owns nothing)."""
-    __slots__ = ("view", "gauss", "geom", "binning", "images", "keep", "P", "K", "N", "dev", "cam_grads", "scene")
+    __slots__ = ("view", "gauss", "geom", "binning", "images", "keep", "P", "K", "N", "dev", "cam_grads", "scene",
+                 "versions")
 
 
 class _Workspace:
@@ -115,14 +144,6 @@ class _Workspace:
 
 
 _WORKSPACES = {}
-# "auto": speculate the pair capacity from previous calls and enqueue the whole forward without draining the GPU
-# (falls back to an exact re-run if the speculation was too small); "sync": always the exact two-phase forward.
-FORWARD_MODE = "auto"
-# forward compositing variant (GsrBinning.fwd_mode): None = choose per call from the previous view's statistics
-FWD_MODE: Optional[int] = None
-# seconds this process has spent blocked on the projection's pair count (bench.py reports it per step: how much of a
-# step the host is idle, i.e. how far the path is from being bound by host-side enqueueing)
-HOST_WAIT_S = [0.0]
 
 
 def _workspace(dev, stream) -> _Workspace:
@@ -139,9 +160,10 @@ def _align(n: int, a: int = 256) -> int:
 
 def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
                           rotations, cov3D_precomp, want_keys: bool = False, want_aux: bool = True,
-                          mode: Optional[str] = None, scene: Optional[dict] = None):
+                          mode: Optional[str] = None, scene: Optional[dict] = None,
+                          rc: Optional[RasterContext] = None):
     gen = _forward_steps(s, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, want_keys,
-                         want_aux, mode, scene, None)
+                         want_aux, mode, scene, None, rc or DEFAULT_CONTEXT)
     try:
         next(gen)
     except StopIteration as e:
@@ -150,7 +172,7 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
 
 
 def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
-                   rotations, cov3D_precomp, want_keys, want_aux, mode, scene, batch):
+                   rotations, cov3D_precomp, want_keys, want_aux, mode, scene, batch, rc: RasterContext):
     """Generator behind rasterize_forward_raw. With batch = dict(scratch=<this view's slice of the batch's projection
     scratch>, pinned=<pinned int64 [V]>, index=k, event=<Event>) it allocates and binds, YIELDS (view struct, geom struct)
     for the caller to run gsr_forward_project_batch / gsr_forward_render_batch over all views, and continues when resumed.
@@ -208,7 +230,7 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     means3D = _prep(means3D, "means3D", dev)
     opacities = _prep(opacities, "opacities", dev)
     shs, colors_precomp = _prep(shs, "shs", dev), _prep(colors_precomp, "colors_precomp", dev)
-    scales, rotations = _prep(scales, "scales", dev), _prep(rotations, "rotations", dev)
+    scales, rotations = _prep(scales, "scales", dev, align=4), _prep(rotations, "rotations", dev)
     cov3D_precomp = _prep(cov3D_precomp, "cov3D_precomp", dev)
     bg = _prep(s.bg.reshape(-1), "bg", dev)
     vm = _prep(s.viewmatrix.reshape(-1), "viewmatrix", dev)
@@ -220,7 +242,7 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
 
     st = _State()
     st.P, st.K, st.dev = P, K, dev
-    st.view = _view_struct(s, P, K, bg, vm, pm, cp)
+    st.view = _view_struct(s, P, K, bg, vm, pm, cp, rc.score_mode)
     g = L.GsrGaussians()
     g.means3D, g.opacities, g.shs, g.colors_precomp = _ptr(means3D), _ptr(opacities), _ptr(shs), _ptr(colors_precomp)
     g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp)
@@ -231,12 +253,12 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
 
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = _workspace(dev, stream)
-    prof = PROFILE.handle if PROFILE is not None else None
+    prof = rc.profile.handle if rc.profile is not None else None
     i32 = torch.int32
     Pm = max(P, 1)
     nb = lib.gsr_num_blocks(P)
     tiles = lib.gsr_num_tiles(H, W)
-    mode = mode or FORWARD_MODE
+    mode = mode or rc.forward_mode
     hint = ws.hint.get((P, H, W)) if mode == "auto" else None
     if batch is not None and hint is None:
         raise RuntimeError("batched forward needs a capacity hint (render the views once unbatched first)")
@@ -286,7 +308,7 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
             # whole-tile items when thousands of shallow tiles saturate the machine, quarter items otherwise
             last_active, last_n = ws.last_stats.get((P, H, W), (0, 0))
             act = int(ws.stats_pinned[0]) if last_active is None else last_active
-            b.fwd_mode = int(FWD_MODE if FWD_MODE is not None else
+            b.fwd_mode = int(rc.fwd_variant if rc.fwd_variant is not None else
                              (act >= 2048 and last_n > 0 and last_n / max(act, 1) < 1024))
             b.stats_host = ws.stats_pinned.data_ptr()
             im.final_T, im.n_contrib, im.tile_depth = ptrs["final_T"], ptrs["n_contrib"], ptrs["tile_depth"]
@@ -365,8 +387,15 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     # scratch is dead after the forward; everything else is kept for backward
     b.scratch, b.scratch_bytes, b.keys_sorted = None, 0, None
     geom.scratch, geom.scratch_bytes, geom.sorted_idx = None, 0, None
+    color_alias, da_alias = color.detach(), depth_alpha.detach()
     st.keep = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, bg, vm, pm, cp, radii,
-               keep_bufs, color.detach(), depth_alpha.detach())
+               keep_bufs, color_alias, da_alias)
+    _track(st, [("means3D", means3D), ("opacities", opacities), ("shs", shs), ("colors_precomp", colors_precomp),
+                ("scales", scales), ("rotations", rotations), ("cov3D_precomp", cov3D_precomp), ("bg", bg),
+                ("viewmatrix", vm), ("projmatrix", pm), ("campos", cp), ("rendered image", color_alias),
+                ("depth_alpha", da_alias)] +
+           ([(f"model {m} leaf {j}", t) for m, row in enumerate(sc_keep[:-1]) for j, t in enumerate(row)]
+            if sc_keep is not None else []))
     # ^ backward re-reads the output image (suffix sums from checkpoints). DETACHED aliases on purpose: the objects
     #   returned to autograd acquire grad_fn -> ctx -> this state; keeping them here would close a reference cycle
     #   and defer every free to Python's cyclic GC (measured: memory bloat and 5x slowdown after ~500 views).
@@ -385,29 +414,52 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     return out, st
 
 
-def _bind_stats(gr, P: int, dev) -> None:
-    if DENSIFY_STATS is None:
+def _bind_stats(gr, stats, P: int, dev) -> None:
+    """stats: None or the (max_radii2D, xyz_gradient_accum, denom) tensors K8 updates for this view's visible Gaussians."""
+    if stats is None:
         return
     ptrs = []
-    for t in DENSIFY_STATS:
+    for t in stats:
         if t.numel() != P or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
-            raise ValueError("DENSIFY_STATS tensors must be contiguous fp32 with P elements on the view's device")
+            raise ValueError("densify_stats tensors must be contiguous fp32 with P elements on the view's device")
         ptrs.append(t.data_ptr())
     gr.stat_max_radii2D, gr.stat_xyz_gradient_accum, gr.stat_denom = ptrs
 
 
-def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, model_grads, accumulate: bool,
-                    dL_dscales_out=None) -> dict:
-    """Backward of a scene forward: the parameter gradients are written (or, with accumulate, ADDED) straight into
-    per-model tensors shaped like the raw leaves. model_grads: list of 6-tuples (None entries are allocated here)."""
-    lib = L.load()
-    dev, P, K = st.dev, st.P, st.K
+def _stat_views(V: int, stats, stats_views) -> set:
+    """The views of a V-view call whose densification statistics count: the last one unless told otherwise (the
+    reference's trainers use the last view of the step only, object_trainer.py:386-390)."""
+    if stats is None:
+        return set()
+    if stats_views is None:
+        return {V - 1}
+    if isinstance(stats_views, str):
+        if stats_views != "all":
+            raise ValueError("stats_views is None (last view), 'all' or a sequence of view indices")
+        return set(range(V))
+    sv = {int(k) % V for k in stats_views}
+    return sv
+
+
+def _check_versions(st: _State) -> None:
+    """K7 / K8 re-read the forward's inputs and outputs through raw pointers (no save_for_backward), so autograd's own
+    version check does not see them: an in-place edit between forward and backward would silently corrupt gradients."""
+    for name, t, ver in st.versions:
+        if t._version != ver:
+            raise RuntimeError(f"rasterizer backward: `{name}` was modified in place after the forward (version {ver} -> "
+                               f"{t._version}); its memory is re-read by the backward. Clone it before editing.")
+
+
+def _track(st: _State, named) -> None:
+    st.versions = [(n, t, t._version) for n, t in named if t is not None]
+
+
+def _model_grad_rows(sc_struct, leaves_of, model_grads, accumulate, K, dev):
+    """Per model: the 6 gradient tensors the kernels write (given ones are validated, missing ones allocated)."""
     f32 = torch.float32
-    sc_struct, sc_keep = st.scene
-    sg = L.GsrSceneGrads()
     outs = []
     for m in range(sc_struct.n_models):
-        leaves = sc_keep[m]
+        leaves = leaves_of[m]
         given = model_grads[m] if model_grads is not None else (None,) * 6
         row = []
         for t, gt in zip(leaves, given):
@@ -421,10 +473,24 @@ def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, mod
             elif gt.shape != t.shape or gt.dtype != f32 or not gt.is_contiguous() or gt.device != dev:
                 raise ValueError("model gradient tensors must match the raw leaves (shape, fp32, contiguous, device)")
             row.append(gt)
+        outs.append(tuple(row))
+    return outs
+
+
+def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, model_grads, accumulate: bool,
+                    dL_dscales_out=None, stats=None, profile=None) -> dict:
+    """Backward of a scene forward: the parameter gradients are written (or, with accumulate, ADDED) straight into
+    per-model tensors shaped like the raw leaves. model_grads: list of 6-tuples (None entries are allocated here)."""
+    lib = L.load()
+    dev, P, K = st.dev, st.P, st.K
+    f32 = torch.float32
+    sc_struct, sc_keep = st.scene
+    sg = L.GsrSceneGrads()
+    outs = _model_grad_rows(sc_struct, sc_keep, model_grads, accumulate, K, dev)
+    for m, row in enumerate(outs):
         mg = sg.models[m]
         mg.xyz, mg.scaling, mg.rotation, mg.opacity = _ptr(row[0]), _ptr(row[1]), _ptr(row[2]), _ptr(row[3])
         mg.features_dc, mg.features_rest = _ptr(row[4]), (_ptr(row[5]) if K > 1 else None)
-        outs.append(tuple(row))
     o = dict(dL_dmeans2D=torch.empty((P, 3), dtype=f32, device=dev), model_grads=outs,
              dL_dview=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
              dL_dproj=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
@@ -437,12 +503,12 @@ def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, mod
     gr.accumulate = int(bool(accumulate))
     dL_dscales_out = _prep(dL_dscales_out, "dL_dscales_out", dev)
     sg.dL_dscales_out = _ptr(dL_dscales_out)
-    _bind_stats(gr, P, dev)
+    _bind_stats(gr, stats, P, dev)
     gr.scene = C.pointer(sg)
     ig = L.GsrImageGrads()
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
     stream = torch.cuda.current_stream(dev).cuda_stream
-    prof = PROFILE.handle if PROFILE is not None else None
+    prof = profile.handle if profile is not None else None
     with torch.cuda.device(dev):
         L.check(lib.gsr_backward(C.byref(st.view), C.byref(st.gauss), C.byref(st.geom), C.byref(st.binning),
                                  C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
@@ -451,13 +517,16 @@ def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, mod
 
 
 def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool = False, arena=None,
-                           accumulate: bool = False, model_grads=None, dL_dscales_out=None) -> dict:
+                           accumulate: bool = False, model_grads=None, dL_dscales_out=None, stats=None,
+                           profile=None) -> dict:
     lib = L.load()
     dev, P, K = st.dev, st.P, st.K
+    _check_versions(st)
     dL_dcolor = _prep(dL_dcolor, "dL_dcolor", dev)
     dL_ddepth_alpha = _prep(dL_ddepth_alpha, "dL_ddepth_alpha", dev)
     if st.scene is not None:
-        return _backward_scene(st, dL_dcolor, dL_ddepth_alpha, cam_grads, model_grads, accumulate, dL_dscales_out)
+        return _backward_scene(st, dL_dcolor, dL_ddepth_alpha, cam_grads, model_grads, accumulate, dL_dscales_out,
+                               stats, profile)
     g = st.gauss
     f32 = torch.float32
     av = {}
@@ -483,11 +552,11 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
         setattr(gr, k, _ptr(t))
     gr.partials = partials.data_ptr()
     gr.accumulate = int(bool(accumulate and arena is not None))
-    _bind_stats(gr, P, dev)
+    _bind_stats(gr, stats, P, dev)
     ig = L.GsrImageGrads()
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
     stream = torch.cuda.current_stream(dev).cuda_stream
-    prof = PROFILE.handle if PROFILE is not None else None
+    prof = profile.handle if profile is not None else None
     with torch.cuda.device(dev):
         L.check(lib.gsr_backward(C.byref(st.view), C.byref(g), C.byref(st.geom), C.byref(st.binning),
                                  C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
@@ -496,34 +565,20 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
 
 
 def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, model_grads=None, accumulate: bool = False,
-                                       dL_dscales_outs=None) -> dict:
+                                       dL_dscales_outs=None, stats=None, stats_views=None, profile=None) -> dict:
     """Backward of several views of the same SCENE (raw leaves, rasterize_forward_raw(scene=...) per view or batched):
     K7 per view, one K8 pass over all views; the gradients of the raw leaves are the sums over the views, written to (or,
     with accumulate, added to) one tensor per leaf. dL_dscales_outs: per view, the gradient arriving through the returned
-    scales (or None)."""
+    scales (or None). stats / stats_views: see RasterContext."""
     lib = L.load()
     V = len(states)
     st0 = states[0]
     dev, P, K = st0.dev, st0.P, st0.K
     f32 = torch.float32
+    for st in states:
+        _check_versions(st)
     sc0, keep0 = st0.scene
-    outs = []
-    for m in range(sc0.n_models):
-        leaves = keep0[m]
-        given = model_grads[m] if model_grads is not None else (None,) * 6
-        row = []
-        for t, gt in zip(leaves, given):
-            if t is None or (t.numel() == 0 and gt is None):
-                row.append(None if t is None else torch.zeros_like(t))
-                continue
-            if gt is None:
-                if accumulate:
-                    raise ValueError("accumulate=True needs the gradient tensors to add to")
-                gt = torch.empty_like(t)
-            elif gt.shape != t.shape or gt.dtype != f32 or not gt.is_contiguous() or gt.device != dev:
-                raise ValueError("model gradient tensors must match the raw leaves (shape, fp32, contiguous, device)")
-            row.append(gt)
-        outs.append(tuple(row))
+    outs = _model_grad_rows(sc0, keep0, model_grads, accumulate, K, dev)
     m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
     partials = torch.empty((V, max(P, 1), 12), dtype=f32, device=dev)
     views = (L.GsrView * V)(*[st.view for st in states])
@@ -535,6 +590,7 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
     grs = (L.GsrGrads * V)()
     sgs = [L.GsrSceneGrads() for _ in range(V)]
     keep = []
+    counted = _stat_views(V, stats, stats_views)
     for k in range(V):
         gc, gda = _prep(dL_dcolors[k], "dL_dcolor", dev), _prep(dL_ddepth_alphas[k], "dL_ddepth_alpha", dev)
         gso = _prep(dL_dscales_outs[k], "dL_dscales_out", dev) if dL_dscales_outs is not None else None
@@ -549,24 +605,30 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
         grs[k].dL_dmeans2D = m2d[k].data_ptr()
         grs[k].partials = partials[k].data_ptr()
         grs[k].accumulate = int(bool(accumulate))
-        _bind_stats(grs[k], P, dev)
+        if k in counted:
+            _bind_stats(grs[k], stats, P, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    prof = PROFILE.handle if PROFILE is not None else None
+    prof = profile.handle if profile is not None else None
     with torch.cuda.device(dev):
         L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof), "gsr_backward_views")
     return dict(dL_dmeans2D=m2d[:, :P], model_grads=outs)
 
 
-def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=None, accumulate: bool = False) -> dict:
+def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=None, accumulate: bool = False,
+                                 stats=None, stats_views=None, per_view_scales: Optional[bool] = None,
+                                 profile=None) -> dict:
     """Backward of several views of the same Gaussians through gsr_backward_views: K7 per view, one K8 pass over all
     views. Returns the SUMMED parameter gradients (written to / added to the arena's views when given) and the per-view
-    means2D gradients [V,P,3]."""
+    means2D gradients [V,P,3]. per_view_scales (default: whether the views' scales are different tensors): every view has
+    its own scales tensor, `dL_dscales` is then [V,P,3]."""
     lib = L.load()
     V = len(states)
     st0 = states[0]
     dev, P, K = st0.dev, st0.P, st0.K
     g = st0.gauss
     f32 = torch.float32
+    for st in states:
+        _check_versions(st)
     av = {}
     if arena is not None:
         if arena.P != P or (g.shs and arena.K != K) or arena.flat.device != dev:
@@ -581,7 +643,8 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
              dL_dscales=new(P, 3, name="scales") if g.scales else None,
              dL_drotations=new(P, 4, name="rotations") if g.rotations else None,
              dL_dcov3D=new(P, 6) if g.cov3D_precomp else None)
-    per_view_scales = any(st.gauss.scales != g.scales for st in states)
+    if per_view_scales is None:
+        per_view_scales = any(st.gauss.scales != g.scales for st in states)
     if per_view_scales:        # every view has its own scales tensor -> its own scale gradient
         o["dL_dscales"] = torch.empty((V, P, 3), dtype=f32, device=dev)
     m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
@@ -594,6 +657,7 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
     igs = (L.GsrImageGrads * V)()
     grs = (L.GsrGrads * V)()
     keep = []
+    counted = _stat_views(V, stats, stats_views)
     for k in range(V):
         gc, gda = _prep(dL_dcolors[k], "dL_dcolor", dev), _prep(dL_ddepth_alphas[k], "dL_ddepth_alpha", dev)
         keep += [gc, gda]
@@ -605,9 +669,10 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         grs[k].dL_dmeans2D = m2d[k].data_ptr()
         grs[k].partials = partials[k].data_ptr()
         grs[k].accumulate = int(bool(accumulate and arena is not None))
-        _bind_stats(grs[k], P, dev)
+        if k in counted:
+            _bind_stats(grs[k], stats, P, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    prof = PROFILE.handle if PROFILE is not None else None
+    prof = profile.handle if profile is not None else None
     with torch.cuda.device(dev):
         L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof),
                 "gsr_backward_views")
@@ -616,12 +681,19 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
 
 
 class _RasterizeGaussians(torch.autograd.Function):
+    """viewmatrix / projmatrix / campos are the settings' own tensors, passed once more as explicit inputs so that autograd
+    can deliver dL/dviewmatrix (+ projmatrix, campos) to callers that optimise the camera (BASELINE.json north_star); the
+    reference's call sites never ask for them (camera tensors without requires_grad, utils/cam_utils.py:196-210)."""
+
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                projmatrix, campos, settings, rc):
         out, st = rasterize_forward_raw(settings, means3D, opacities, shs, colors_precomp, scales, rotations,
-                                        cov3D_precomp, want_aux=False)
-        ctx.st = st
+                                        cov3D_precomp, want_aux=False, rc=rc)
+        ctx.st, ctx.rc = st, rc
         ctx.opac_shape = opacities.shape
+        ctx.cam_shapes = (viewmatrix.shape, projmatrix.shape, campos.shape)
+        ctx.cam_grads = any(ctx.needs_input_grad[8:11])
         ctx.set_materialize_grads(False)       # no zero tensors for outputs nobody differentiates (radii is [P] int32)
         ctx.mark_non_differentiable(out["radii"])
         if settings.score_flag:
@@ -631,7 +703,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        st = ctx.st
+        st, rc = ctx.st, ctx.rc
         if len(grads) == 4:
             _, g_color, _, g_da = grads
         else:
@@ -641,15 +713,26 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_color = torch.zeros((3, H, W), dtype=torch.float32, device=st.dev)
         if g_da is None:
             g_da = torch.zeros((2, H, W), dtype=torch.float32, device=st.dev)
-        o = rasterize_backward_raw(st, g_color, g_da, arena=GRAD_ARENA, accumulate=ACCUMULATE)
+        o = rasterize_backward_raw(st, g_color, g_da, cam_grads=ctx.cam_grads, arena=rc.grad_arena,
+                                   accumulate=rc.accumulate, stats=rc.densify_stats, profile=rc.profile)
+        cam = (None, None, None)
+        if ctx.cam_grads:
+            cam = tuple(o[k].reshape(sh) for k, sh in zip(("dL_dview", "dL_dproj", "dL_dcampos"), ctx.cam_shapes))
+        if rc.grad_arena is not None:      # the parameter gradients live in the arena, not in .grad (RasterContext)
+            return (None, o["dL_dmeans2D"], None, o["dL_dcolors"], None, None, None, o["dL_dcov3D"], *cam, None, None)
         return (o["dL_dmeans3D"], o["dL_dmeans2D"], o["dL_dshs"], o["dL_dcolors"],
-                o["dL_dopacities"].reshape(ctx.opac_shape), o["dL_dscales"], o["dL_drotations"], o["dL_dcov3D"], None)
+                o["dL_dopacities"].reshape(ctx.opac_shape), o["dL_dscales"], o["dL_drotations"], o["dL_dcov3D"],
+                *cam, None, None)
 
 
 class GaussianRasterizer(torch.nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings):
+    """Drop-in for diff_gaussian_rasterization.GaussianRasterizer (scene_gaussian.py:966, 1012-1021). `context` (optional,
+    not part of the reference's interface) carries the extras of this repo -- see RasterContext."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings, context: Optional[RasterContext] = None):
         super().__init__()
         self.raster_settings = raster_settings
+        self.context = context
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
@@ -658,5 +741,7 @@ class GaussianRasterizer(torch.nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        s = self.raster_settings
+        rc = (self.context or DEFAULT_CONTEXT).snapshot()
         return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                         cov3D_precomp, self.raster_settings)
+                                         cov3D_precomp, s.viewmatrix, s.projmatrix, s.campos, s, rc)

@@ -16,6 +16,7 @@ is the index torch.cat over the models would give. `scene_render` below restates
 """
 from __future__ import annotations
 
+import dataclasses
 import math
 import random
 from typing import List, Optional, Sequence
@@ -25,9 +26,25 @@ import torch
 from . import rasterizer as R
 
 LEAVES = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
-# Optional: per-model tuples of 6 tensors the backward ADDS this view's gradients to (device-side accumulation over
-# the views of one optimizer step, like rasterizer.GRAD_ARENA); the autograd outputs are then None for the leaves.
-MODEL_GRAD_BUFFERS: Optional[List[tuple]] = None
+
+
+@dataclasses.dataclass
+class SceneContext(R.RasterContext):
+    """RasterContext + model_grad_buffers: optional per-model tuples of 6 tensors the backward ADDS this call's gradients
+    to (device-side accumulation over the views of one optimizer step, the scene path's counterpart of grad_arena); the
+    autograd outputs are then None for the leaves."""
+    model_grad_buffers: Optional[List[tuple]] = None
+
+    def snapshot(self) -> "SceneContext":
+        return dataclasses.replace(self)
+
+
+def _scene_rc(context) -> SceneContext:
+    if context is None:
+        return SceneContext()
+    if isinstance(context, SceneContext):
+        return context.snapshot()
+    return SceneContext(**{f.name: getattr(context, f.name) for f in dataclasses.fields(R.RasterContext)})
 
 
 def _leaves(model) -> tuple:
@@ -40,11 +57,11 @@ def _leaves(model) -> tuple:
 
 class _RasterizeModels(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, settings, scale_noise, sh_noise, means2D, *leaves):
+    def forward(ctx, settings, rc, scale_noise, sh_noise, means2D, *leaves):
         models = [tuple(leaves[6 * m:6 * m + 6]) for m in range(len(leaves) // 6)]
         out, st = R.rasterize_forward_raw(settings, None, None, None, None, None, None, None, want_aux=False,
-                                          scene=dict(models=models, scale_noise=scale_noise, sh_noise=sh_noise))
-        ctx.st = st
+                                          scene=dict(models=models, scale_noise=scale_noise, sh_noise=sh_noise), rc=rc)
+        ctx.st, ctx.rc = st, rc
         ctx.n_leaves = len(leaves)
         ctx.set_materialize_grads(False)       # no zero tensors for outputs nobody differentiates (radii is [P] int32)
         ctx.mark_non_differentiable(out["radii"])
@@ -62,35 +79,37 @@ class _RasterizeModels(torch.autograd.Function):
             g_color = torch.zeros((3, H, W), dtype=torch.float32, device=st.dev)
         if g_da is None:
             g_da = torch.zeros((2, H, W), dtype=torch.float32, device=st.dev)
-        bufs = MODEL_GRAD_BUFFERS
+        rc = ctx.rc
+        bufs = rc.model_grad_buffers
         o = R.rasterize_backward_raw(st, g_color, g_da, model_grads=bufs, accumulate=bufs is not None,
-                                     dL_dscales_out=g_scales)
+                                     dL_dscales_out=g_scales, stats=rc.densify_stats, profile=rc.profile)
         flat = []
         for row in o["model_grads"]:
             flat.extend([None] * 6 if bufs is not None else row)
-        return (None, None, None, o["dL_dmeans2D"], *flat)
+        return (None, None, None, None, o["dL_dmeans2D"], *flat)
 
 
 def rasterize_models(settings, models: Sequence, means2D: torch.Tensor, scale_noise: Optional[torch.Tensor] = None,
-                     sh_noise: Optional[torch.Tensor] = None):
+                     sh_noise: Optional[torch.Tensor] = None, context=None):
     """One view of several GaussianModels through the fused path. Returns what GaussianRasterizer returns, plus the
-    activated (and augmented) scales [P,3] (differentiable: the trainers put a loss on them)."""
+    activated (and augmented) scales [P,3] (differentiable: the trainers put a loss on them).
+    context: a RasterContext / SceneContext (optional)."""
     flat = []
     for m in models:
         flat.extend(_leaves(m))
-    return _RasterizeModels.apply(settings, scale_noise, sh_noise, means2D, *flat)
+    return _RasterizeModels.apply(settings, _scene_rc(context), scale_noise, sh_noise, means2D, *flat)
 
 
 class _RasterizeModelsViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, settings_list, scale_noise, sh_noise, means2D, *leaves):
+    def forward(ctx, settings_list, rc, scale_noise, sh_noise, means2D, *leaves):
         from .views import rasterize_views_forward_raw
         V = len(settings_list)
         models = [tuple(leaves[6 * m:6 * m + 6]) for m in range(len(leaves) // 6)]
         scenes = [dict(models=models, scale_noise=None if scale_noise is None else scale_noise[k],
                        sh_noise=None if sh_noise is None else sh_noise[k]) for k in range(V)]
-        res = rasterize_views_forward_raw(settings_list, None, None, None, None, None, None, None, scenes=scenes)
-        ctx.states = [st for _, st in res]
+        res = rasterize_views_forward_raw(settings_list, None, None, None, None, None, None, None, scenes=scenes, rc=rc)
+        ctx.states, ctx.rc = [st for _, st in res], rc
         ctx.set_materialize_grads(False)
         outs = []
         for o, _ in res:
@@ -107,17 +126,20 @@ class _RasterizeModelsViews(torch.autograd.Function):
         gcs = [grads[4 * k] if grads[4 * k] is not None else z(3) for k in range(V)]
         gdas = [grads[4 * k + 2] if grads[4 * k + 2] is not None else z(2) for k in range(V)]
         gss = [grads[4 * k + 3] for k in range(V)]
-        bufs = MODEL_GRAD_BUFFERS
+        rc = ctx.rc
+        bufs = rc.model_grad_buffers
         o = R.rasterize_backward_views_scene_raw(sts, gcs, gdas, model_grads=bufs, accumulate=bufs is not None,
-                                                 dL_dscales_outs=gss if any(g is not None for g in gss) else None)
+                                                 dL_dscales_outs=gss if any(g is not None for g in gss) else None,
+                                                 stats=rc.densify_stats, stats_views=rc.stats_views, profile=rc.profile)
         flat = []
         for row in o["model_grads"]:
             flat.extend([None] * 6 if bufs is not None else row)
-        return (None, None, None, o["dL_dmeans2D"], *flat)
+        return (None, None, None, None, o["dL_dmeans2D"], *flat)
 
 
 def rasterize_models_views(settings_list, models: Sequence, means2D: torch.Tensor,
-                           scale_noise: Optional[torch.Tensor] = None, sh_noise: Optional[torch.Tensor] = None):
+                           scale_noise: Optional[torch.Tensor] = None, sh_noise: Optional[torch.Tensor] = None,
+                           context=None):
     """The views of one optimizer step of several GaussianModels in one call (raw leaves, activations and per-view noise
     fused: scale_noise [V,P,3], sh_noise [V,P,K,3] N(0,1) samples or None). means2D: [V,P,3] zeros. Returns a list of
     (image, radii, depth_alpha, scales) per view; the parameter gradients are the sums over the views."""
@@ -125,7 +147,10 @@ def rasterize_models_views(settings_list, models: Sequence, means2D: torch.Tenso
     for m in models:
         flat.extend(_leaves(m))
     V = len(settings_list)
-    out = _RasterizeModelsViews.apply(tuple(settings_list), scale_noise, sh_noise, means2D, *flat)
+    from .views import _uniform
+    if not _uniform(list(settings_list)):
+        raise ValueError("rasterize_models_views: all views of a call must have the same image size and scale_modifier")
+    out = _RasterizeModelsViews.apply(tuple(settings_list), _scene_rc(context), scale_noise, sh_noise, means2D, *flat)
     return [tuple(out[4 * k:4 * k + 4]) for k in range(V)]
 
 

@@ -25,16 +25,23 @@ from . import rasterizer as R
 MAX_VIEWS = 16
 
 
+def _uniform(settings_list) -> bool:
+    s0 = settings_list[0]
+    return all(int(s.image_height) == int(s0.image_height) and int(s.image_width) == int(s0.image_width) and
+               float(s.scale_modifier) == float(s0.scale_modifier) for s in settings_list)
+
+
 def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs, colors_precomp, scales, rotations,
-                                cov3D_precomp, want_aux: bool = False, scenes=None):
+                                cov3D_precomp, want_aux: bool = False, scenes=None, rc=None):
     """Forward of V views. Returns [(outputs, state)] like rasterize_forward_raw per view.
     scales: [P,3] shared by the views, or [V,P,3] (every view its own, e.g. with the trainers' per-view scale noise).
     scenes: instead of the tensors, one `scene` dict per view (rasterize_forward_raw): the same models' raw leaves,
     per-view noise samples."""
     lib = L.load()
+    rc = rc or R.DEFAULT_CONTEXT
     V = len(settings_list)
     if scenes is not None:
-        return _views_forward_scene(lib, settings_list, scenes, want_aux)
+        return _views_forward_scene(lib, settings_list, scenes, want_aux, rc)
     per_view = scales is not None and scales.dim() == 3
     if per_view and scales.shape[0] != V:
         raise ValueError(f"per-view scales must be [V,P,3] with V = {V}")
@@ -44,16 +51,15 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
     s0 = settings_list[0]
     dev = means3D.device
     P, H, W = int(means3D.shape[0]), int(s0.image_height), int(s0.image_width)
-    same = all(int(s.image_height) == H and int(s.image_width) == W and s.scale_modifier == s0.scale_modifier
-               for s in settings_list)
+    same = _uniform(settings_list)
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = R._workspace(dev, stream)
-    batched = (1 < V <= MAX_VIEWS and same and P > 0 and R.FORWARD_MODE == "auto" and ws.hint.get((P, H, W)) is not None
+    batched = (1 < V <= MAX_VIEWS and same and P > 0 and rc.forward_mode == "auto" and ws.hint.get((P, H, W)) is not None
                and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24) and not any(s.score_flag for s in settings_list))
     if not batched:
         return [R.rasterize_forward_raw(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp,
-                                        want_aux=want_aux) for k, s in enumerate(settings_list)]
-    prof = R.PROFILE.handle if R.PROFILE is not None else None
+                                        want_aux=want_aux, rc=rc) for k, s in enumerate(settings_list)]
+    prof = rc.profile.handle if rc.profile is not None else None
     stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
     with torch.cuda.device(dev):
         big = ws.scratch("proj_scratch_batch", stride * V)
@@ -64,7 +70,7 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
         gens = [R._forward_steps(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp, False,
                                  want_aux, None, None,
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
-                                      event=ws.event, sort=sort_of(k), synced=synced))
+                                      event=ws.event, sort=sort_of(k), synced=synced), rc)
                 for k, s in enumerate(settings_list)]
         results = _drive_batch(lib, ws, gens, V, dev, stream, prof)
     return results
@@ -108,25 +114,24 @@ def _drive_batch(lib, ws, gens, V, dev, stream, prof):
     return results
 
 
-def _views_forward_scene(lib, settings_list, scenes, want_aux):
+def _views_forward_scene(lib, settings_list, scenes, want_aux, rc):
     V = len(settings_list)
     s0 = settings_list[0]
     models = scenes[0]["models"]
     dev = models[0][0].device
     P = sum(int(m[0].shape[0]) for m in models)
     H, W = int(s0.image_height), int(s0.image_width)
-    same = all(int(s.image_height) == H and int(s.image_width) == W and s.scale_modifier == s0.scale_modifier
-               for s in settings_list)
+    same = _uniform(settings_list)
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = R._workspace(dev, stream)
     K = 1 + (int(models[0][5].shape[1]) if models[0][5] is not None and models[0][5].numel() > 0 else 0)
-    batched = (1 < V <= MAX_VIEWS and same and P > 0 and R.FORWARD_MODE == "auto" and ws.hint.get((P, H, W)) is not None
+    batched = (1 < V <= MAX_VIEWS and same and P > 0 and rc.forward_mode == "auto" and ws.hint.get((P, H, W)) is not None
                and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24) and K in (1, 4, 9, 16)
                and not any(s.score_flag for s in settings_list))
     if not batched:
-        return [R.rasterize_forward_raw(s, None, None, None, None, None, None, None, want_aux=want_aux, scene=sc)
+        return [R.rasterize_forward_raw(s, None, None, None, None, None, None, None, want_aux=want_aux, scene=sc, rc=rc)
                 for s, sc in zip(settings_list, scenes)]
-    prof = R.PROFILE.handle if R.PROFILE is not None else None
+    prof = rc.profile.handle if rc.profile is not None else None
     stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
     with torch.cuda.device(dev):
         big = ws.scratch("proj_scratch_batch", stride * V)
@@ -136,18 +141,19 @@ def _views_forward_scene(lib, settings_list, scenes, want_aux):
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
         gens = [R._forward_steps(s, None, None, None, None, None, None, None, False, want_aux, None, scenes[k],
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
-                                      event=ws.event, sort=sort_of(k), synced=synced))
+                                      event=ws.event, sort=sort_of(k), synced=synced), rc)
                 for k, s in enumerate(settings_list)]
         return _drive_batch(lib, ws, gens, V, dev, stream, prof)
 
 
 class _RasterizeViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings_list, rc):
         res = rasterize_views_forward_raw(settings_list, means3D, opacities, shs, colors_precomp, scales, rotations,
-                                          cov3D_precomp)
-        ctx.states = [st for _, st in res]
+                                          cov3D_precomp, rc=rc)
+        ctx.states, ctx.rc = [st for _, st in res], rc
         ctx.opac_shape = opacities.shape
+        ctx.per_view_scales = scales is not None and scales.dim() == 3      # [V,P,3]: every view its own scales
         ctx.set_materialize_grads(False)       # no zero tensors for outputs nobody differentiates (radii is [P] int32)
         outs = []
         for o, _ in res:
@@ -157,24 +163,39 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        sts = ctx.states
+        sts, rc = ctx.states, ctx.rc
         V = len(sts)
-        st0 = sts[0]
-        H, W, dev = st0.view.image_height, st0.view.image_width, st0.dev
         gcs, gdas = [], []
-        for k in range(V):
+        for k, st in enumerate(sts):
+            H, W, dev = st.view.image_height, st.view.image_width, st.dev
             g_color, g_da = grads[3 * k], grads[3 * k + 2]
             gcs.append(g_color if g_color is not None else torch.zeros((3, H, W), dtype=torch.float32, device=dev))
             gdas.append(g_da if g_da is not None else torch.zeros((2, H, W), dtype=torch.float32, device=dev))
-        o = R.rasterize_backward_views_raw(sts, gcs, gdas, arena=R.GRAD_ARENA, accumulate=R.ACCUMULATE)
+        o = R.rasterize_backward_views_raw(sts, gcs, gdas, arena=rc.grad_arena, accumulate=rc.accumulate,
+                                           stats=rc.densify_stats, stats_views=rc.stats_views,
+                                           per_view_scales=ctx.per_view_scales, profile=rc.profile)
+        if rc.grad_arena is not None:      # the parameter gradients live in the arena, not in .grad (RasterContext)
+            return (None, o["dL_dmeans2D"], None, o["dL_dcolors"], None,
+                    o["dL_dscales"] if ctx.per_view_scales else None, None, o["dL_dcov3D"], None, None)
         return (o["dL_dmeans3D"], o["dL_dmeans2D"], o["dL_dshs"], o["dL_dcolors"],
-                o["dL_dopacities"].reshape(ctx.opac_shape), o["dL_dscales"], o["dL_drotations"], o["dL_dcov3D"], None)
+                o["dL_dopacities"].reshape(ctx.opac_shape), o["dL_dscales"], o["dL_drotations"], o["dL_dcov3D"], None, None)
 
 
 class GaussianRasterizerViews(torch.nn.Module):
-    def __init__(self, raster_settings_list):
+    """The V views of one optimizer step through one call. All views must have the same image size and scale_modifier
+    (the batched backward is one pass over all views); per view may differ: camera, background, active SH degree, and
+    the scales ([V,P,3]). context: see rasterizer.RasterContext (densify_stats count for the LAST view unless
+    context.stats_views says otherwise -- what the reference's trainers do, object_trainer.py:386-390)."""
+
+    def __init__(self, raster_settings_list, context=None):
         super().__init__()
         self.raster_settings_list = list(raster_settings_list)
+        self.context = context
+        if not self.raster_settings_list:
+            raise ValueError("at least one view")
+        if not _uniform(self.raster_settings_list):
+            raise ValueError("GaussianRasterizerViews: all views of a call must have the same image_height, image_width "
+                             "and scale_modifier (render differently sized views with separate GaussianRasterizer calls)")
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None) -> List[tuple]:
@@ -186,6 +207,9 @@ class GaussianRasterizerViews(torch.nn.Module):
         V = len(self.raster_settings_list)
         if means2D.shape[0] != V:
             raise ValueError(f"means2D must be [V,P,3] with V = {V} views")
+        if any(s.score_flag for s in self.raster_settings_list):
+            raise ValueError("score_flag views return a 4-tuple: render them with GaussianRasterizer")
+        rc = (self.context or R.DEFAULT_CONTEXT).snapshot()
         flat = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                     tuple(self.raster_settings_list))
+                                     tuple(self.raster_settings_list), rc)
         return [tuple(flat[3 * k:3 * k + 3]) for k in range(V)]

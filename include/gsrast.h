@@ -274,9 +274,11 @@ int gsr_backward(const GsrView*, const GsrGaussians*, const GsrGeom*, const GsrB
  * every parameter row once, loops over the views and writes the summed parameter gradients once (supported for shs with
  * K in {1,4,9,16} + scales/rotations without camera gradients; other combinations run K8 view by view with the same
  * result). All arrays have n_views entries. Per view: outs[k].partials and outs[k].dL_dmeans2D (and dL_dview / dL_dproj /
- * dL_dcampos); the parameter gradient pointers, `accumulate` and the stat_* pointers are taken from outs[0] (give every
- * entry the same ones): the SUM over the views is written (accumulate = 0) or added (accumulate = 1) there, and the
- * statistics are updated once per view that saw the Gaussian. With per-view `scales` (see gsr_forward_project_batch)
+ * dL_dcampos, stat_*); the parameter gradient pointers and `accumulate` are taken from outs[0] (give every
+ * entry the same ones): the SUM over the views is written (accumulate = 0) or added (accumulate = 1) there. The
+ * densification statistics are updated for the views whose entry sets the stat_* pointers (all such entries must name
+ * the same three tensors) -- the reference's trainers count the LAST view of a step only (object_trainer.py:386-390) --
+ * once per such view that saw the Gaussian. With per-view `scales` (see gsr_forward_project_batch)
  * every outs[k].dL_dscales is its own [P,3] buffer and receives view k's scale gradient (never accumulated). With a
  * scene every outs[k].scene names the SAME model gradient tensors (summed over the views) and its own dL_dscales_out. */
 int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians* gaussians /* [n_views] */,

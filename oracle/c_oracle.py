@@ -23,22 +23,35 @@ class OrcView(C.Structure):
                 ("campos", C.c_float * 3), ("prefiltered", C.c_int32), ("score_mode", C.c_int32)]
 
 
+_SO_OMP = os.path.join(_HERE, "_build", "libgsr_oracle_omp.so")
+
+
 def build(force: bool = False) -> str:
+    """Builds the scalar checker and the all-core timing build (same source, -DORC_OMP -fopenmp)."""
     src = os.path.join(_HERE, "gsr_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "_build/libgsr_oracle.so"])
+    mk = os.path.join(_HERE, "Makefile")
+    for so, target in ((_SO, "_build/libgsr_oracle.so"), (_SO_OMP, "_build/libgsr_oracle_omp.so")):
+        if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(mk)):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "-B", target])
     return _SO
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(build())
-        _lib.orc_bin_sort.restype = C.c_uint64
-    return _lib
+def lib(omp: bool = False):
+    """omp=False: the scalar, deterministic checker. omp=True: the all-core build, for timing the CPU path only."""
+    if omp not in _libs:
+        build()
+        L = C.CDLL(_SO_OMP if omp else _SO)
+        L.orc_bin_sort.restype = C.c_uint64
+        L.orc_threads.restype = C.c_int
+        _libs[omp] = L
+    return _libs[omp]
+
+
+def threads(omp: bool = False) -> int:
+    return int(lib(omp).orc_threads())
 
 
 def _p(a: Optional[np.ndarray]):
@@ -63,9 +76,9 @@ def make_view(P, M, D, H, W, tanfovx, tanfovy, bg, view, proj, campos, scale_mod
 
 
 def forward(view: OrcView, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-            cov3D_precomp=None, score: bool = False) -> dict:
+            cov3D_precomp=None, score: bool = False, omp: bool = False) -> dict:
     """Full forward K1-K6. Returns every intermediate (the bit-exact artefacts included)."""
-    L = lib()
+    L = lib(omp)
     P, H, W = view.P, view.H, view.W
     means3D, opacities = _f32(means3D), _f32(opacities)
     shs, colors_precomp, scales, rotations, cov3D_precomp = map(_f32, (shs, colors_precomp, scales, rotations, cov3D_precomp))
@@ -97,8 +110,8 @@ def forward(view: OrcView, means3D, opacities, shs=None, colors_precomp=None, sc
 
 
 def backward(view: OrcView, fwd: dict, dL_dimage, dL_ddepth_alpha, means3D, shs=None, scales=None, rotations=None,
-             cov3D_precomp=None, cam_grads: bool = False) -> dict:
-    L = lib()
+             cov3D_precomp=None, cam_grads: bool = False, omp: bool = False) -> dict:
+    L = lib(omp)
     P, M = view.P, view.M
     means3D = _f32(means3D)
     shs, scales, rotations, cov3D_precomp = map(_f32, (shs, scales, rotations, cov3D_precomp))

@@ -16,11 +16,25 @@
  * is what makes those artefacts bit-exact between this oracle and the GPU (SEMANTICS.md "op order").
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * Built twice (oracle/Makefile): libgsr_oracle.so -- scalar, one thread, deterministic: THE checker; and
+ * libgsr_oracle_omp.so (-DORC_OMP -fopenmp) -- the same arithmetic per (pixel, splat) with the outer loops spread over
+ * the host's cores, used ONLY by bench.py to time the CPU path on all cores (cpu_baseline.cores = threads used). In
+ * the OpenMP build the per-Gaussian sums of the backward are formed per tile first (different association), so its
+ * gradients equal the scalar build's to fp32 summation order, not bit for bit.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef ORC_OMP
+#include <omp.h>
+#define ORC_PARALLEL_FOR _Pragma("omp parallel for schedule(dynamic, 16)")
+int orc_threads(void) { return omp_get_max_threads(); }
+#else
+#define ORC_PARALLEL_FOR
+int orc_threads(void) { return 1; }
+#endif
 
 
 
@@ -154,6 +168,7 @@ void orc_preprocess(const OrcView* v, const float* means3D, const float* scales,
   const int gx = (W + BLOCK - 1) / BLOCK, gy = (H + BLOCK - 1) / BLOCK;
   const float fx = (float)W / (2.0f * v->tanfovx), fy = (float)H / (2.0f * v->tanfovy);
   const float limx = 1.3f * v->tanfovx, limy = 1.3f * v->tanfovy;
+  ORC_PARALLEL_FOR
   for (int i = 0; i < P; ++i) {
     radii[i] = 0; tiles_touched[i] = 0;
     depth[i] = 0; xy[2 * i] = xy[2 * i + 1] = 0;
@@ -259,6 +274,51 @@ uint64_t orc_bin_sort(int32_t P, int32_t H, int32_t W, const int32_t* rect, cons
         ++off;
       }
   }
+#ifdef ORC_OMP
+  /* Same order as the stable 64-bit sort below, spread over the cores: stable counting sort by tile id (emission order
+   * = Gaussian index order inside a tile), then every tile's segment stably LSD-sorted by the 32 depth bits. */
+  {
+    const size_t nt = (size_t)gx * gy;
+    uint64_t* k2 = (uint64_t*)malloc((N ? N : 1) * sizeof(uint64_t));
+    uint32_t* v2 = (uint32_t*)malloc((N ? N : 1) * sizeof(uint32_t));
+    size_t* start = (size_t*)calloc(nt + 1, sizeof(size_t));
+    for (uint64_t j = 0; j < N; ++j) start[(keys[j] >> 32) + 1]++;
+    for (size_t t = 0; t < nt; ++t) start[t + 1] += start[t];
+    size_t* cur = (size_t*)malloc(nt * sizeof(size_t));
+    memcpy(cur, start, nt * sizeof(size_t));
+    for (uint64_t j = 0; j < N; ++j) {
+      const size_t d = cur[keys[j] >> 32]++;
+      k2[d] = keys[j]; v2[d] = vals[j];
+    }
+    memset(ranges, 0, nt * 2 * sizeof(uint32_t));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (size_t t = 0; t < nt; ++t) {
+      const size_t a = start[t], n = start[t + 1] - start[t];
+      if (!n) continue;
+      uint64_t *ka = k2 + a, *kb = keys + a;
+      uint32_t *va = v2 + a, *vb = vals + a;
+      for (int pass = 0; pass < 4; ++pass) {
+        size_t cnt[257];
+        memset(cnt, 0, sizeof cnt);
+        const int sh = 8 * pass;
+        for (size_t j = 0; j < n; ++j) cnt[((ka[j] >> sh) & 255) + 1]++;
+        for (int b = 0; b < 256; ++b) cnt[b + 1] += cnt[b];
+        for (size_t j = 0; j < n; ++j) {
+          const size_t d = cnt[(ka[j] >> sh) & 255]++;
+          kb[d] = ka[j]; vb[d] = va[j];
+        }
+        uint64_t* tk = ka; ka = kb; kb = tk;
+        uint32_t* tv = va; va = vb; vb = tv;
+      }
+      /* 4 passes: back in k2/v2 -> copy to the output arrays */
+      memcpy(keys + a, k2 + a, n * sizeof(uint64_t));
+      memcpy(vals + a, v2 + a, n * sizeof(uint32_t));
+      ranges[2 * t] = (uint32_t)a; ranges[2 * t + 1] = (uint32_t)(a + n);
+    }
+    free(k2); free(v2); free(start); free(cur);
+    return N;
+  }
+#endif
   /* stable LSD radix sort on all 64 key bits */
   uint64_t* k2 = (uint64_t*)malloc((N ? N : 1) * sizeof(uint64_t));
   uint32_t* v2 = (uint32_t*)malloc((N ? N : 1) * sizeof(uint32_t));
@@ -289,107 +349,182 @@ uint64_t orc_bin_sort(int32_t P, int32_t H, int32_t W, const int32_t* rect, cons
 }
 
 /* --------------------------------------------------------------------------------------------------- K6 */
+static void fwd_pixel(const OrcView* v, int px, int py, const uint32_t* ranges, const uint32_t* point_list,
+                      const float* xy, const float* conic_opacity, const float* rgb, const float* depth,
+                      float* out_image, float* out_depth_alpha, float* final_T, uint32_t* n_contrib,
+                      float* important_score) {
+  const int W = v->W, H = v->H;
+  const int gx = (W + BLOCK - 1) / BLOCK;
+  const int tile = (py / BLOCK) * gx + (px / BLOCK);
+  const uint32_t a0 = ranges[2 * tile], a1 = ranges[2 * tile + 1];
+  const float pxf = (float)px, pyf = (float)py;
+  float T = 1.0f, C[3] = {0, 0, 0}, Dp = 0.0f, Wt = 0.0f;
+  uint32_t contributor = 0, last = 0;
+  for (uint32_t j = a0; j < a1; ++j) {
+    ++contributor;
+    const uint32_t g = point_list[j];
+    const float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
+    const float* co = conic_opacity + 4 * g;
+    const float power = orc_power(co[0], co[1], co[2], dx, dy);
+    if (power > 0.0f) continue;
+    const float alpha = fminf(ALPHA_MAX, co[3] * orc_exp(power));
+    if (alpha < ALPHA_MIN) continue;
+    const float test_T = T * (1.0f - alpha);
+    if (test_T < T_MIN) break;
+    const float w = alpha * T;
+    for (int c = 0; c < 3; ++c) C[c] += rgb[3 * g + c] * w;
+    Dp += depth[g] * w;
+    Wt += w;
+    if (important_score) {
+      const float sc = (v->score_mode == 0) ? co[3] : w;
+#ifdef ORC_OMP
+#pragma omp atomic
+#endif
+      important_score[g] += sc;
+    }
+    T = test_T;
+    last = contributor;
+  }
+  const size_t pix = (size_t)py * W + px;
+  final_T[pix] = T;
+  n_contrib[pix] = last;
+  for (int c = 0; c < 3; ++c) out_image[(size_t)c * H * W + pix] = C[c] + T * v->bg[c];
+  out_depth_alpha[pix] = Dp;
+  out_depth_alpha[(size_t)H * W + pix] = Wt;
+}
+
 void orc_render_fwd(const OrcView* v, const uint32_t* ranges, const uint32_t* point_list, const float* xy,
                     const float* conic_opacity, const float* rgb, const float* depth, float* out_image,
                     float* out_depth_alpha, float* final_T, uint32_t* n_contrib, float* important_score) {
   const int W = v->W, H = v->H;
-  const int gx = (W + BLOCK - 1) / BLOCK;
+#ifdef ORC_OMP
+  const int gx = (W + BLOCK - 1) / BLOCK, gy = (H + BLOCK - 1) / BLOCK;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int tile = 0; tile < gx * gy; ++tile) {
+    const int ty = tile / gx, tx = tile - ty * gx;
+    for (int py = ty * BLOCK; py < (ty + 1) * BLOCK && py < H; ++py)
+      for (int px = tx * BLOCK; px < (tx + 1) * BLOCK && px < W; ++px)
+        fwd_pixel(v, px, py, ranges, point_list, xy, conic_opacity, rgb, depth, out_image, out_depth_alpha, final_T,
+                  n_contrib, important_score);
+  }
+#else
   for (int py = 0; py < H; ++py)
-    for (int px = 0; px < W; ++px) {
-      const int tile = (py / BLOCK) * gx + (px / BLOCK);
-      const uint32_t a0 = ranges[2 * tile], a1 = ranges[2 * tile + 1];
-      const float pxf = (float)px, pyf = (float)py;
-      float T = 1.0f, C[3] = {0, 0, 0}, Dp = 0.0f, Wt = 0.0f;
-      uint32_t contributor = 0, last = 0;
-      for (uint32_t j = a0; j < a1; ++j) {
-        ++contributor;
-        const uint32_t g = point_list[j];
-        const float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
-        const float* co = conic_opacity + 4 * g;
-        const float power = orc_power(co[0], co[1], co[2], dx, dy);
-        if (power > 0.0f) continue;
-        const float alpha = fminf(ALPHA_MAX, co[3] * orc_exp(power));
-        if (alpha < ALPHA_MIN) continue;
-        const float test_T = T * (1.0f - alpha);
-        if (test_T < T_MIN) break;
-        const float w = alpha * T;
-        for (int c = 0; c < 3; ++c) C[c] += rgb[3 * g + c] * w;
-        Dp += depth[g] * w;
-        Wt += w;
-        if (important_score) important_score[g] += (v->score_mode == 0) ? co[3] : w;
-        T = test_T;
-        last = contributor;
-      }
-      const size_t pix = (size_t)py * W + px;
-      final_T[pix] = T;
-      n_contrib[pix] = last;
-      for (int c = 0; c < 3; ++c) out_image[(size_t)c * H * W + pix] = C[c] + T * v->bg[c];
-      out_depth_alpha[pix] = Dp;
-      out_depth_alpha[(size_t)H * W + pix] = Wt;
-    }
+    for (int px = 0; px < W; ++px)
+      fwd_pixel(v, px, py, ranges, point_list, xy, conic_opacity, rgb, depth, out_image, out_depth_alpha, final_T,
+                n_contrib, important_score);
+#endif
 }
 
 /* --------------------------------------------------------------------------------------------------- K7 */
 /* Accumulates (+=) into dL_dxy_ndc[P,2] (already scaled to d/d(ndc): x0.5W, x0.5H), dL_dconic[P,3]
- * (true partials w.r.t. conic a,b,c), dL_dopacity[P], dL_drgb[P,3], dL_ddepth[P]. Caller zeroes them. */
+ * (true partials w.r.t. conic a,b,c), dL_dopacity[P], dL_drgb[P,3], dL_ddepth[P]. Caller zeroes them.
+ * bwd_pixel: one pixel's reverse traversal; the sums go to row `g` of the five arrays (scalar build) or, when `local`
+ * is set, to row k = position in the tile's list (OpenMP build: per-tile sums first, merged afterwards). */
+static void bwd_pixel(const OrcView* v, int px, int py, const uint32_t* ranges, const uint32_t* point_list,
+                      const float* xy, const float* conic_opacity, const float* rgb, const float* depth,
+                      const float* final_T, const uint32_t* n_contrib, const float* dL_dimage,
+                      const float* dL_ddepth_alpha, float* dL_dxy_ndc, float* dL_dconic, float* dL_dopacity,
+                      float* dL_drgb, float* dL_ddepth, int local) {
+  const int W = v->W, H = v->H;
+  const int gx = (W + BLOCK - 1) / BLOCK;
+  const float sx = 0.5f * (float)W, sy = 0.5f * (float)H;
+  const int tile = (py / BLOCK) * gx + (px / BLOCK);
+  const uint32_t a0 = ranges[2 * tile];
+  const size_t pix = (size_t)py * W + px;
+  const float pxf = (float)px, pyf = (float)py;
+  const float Tf = final_T[pix];
+  float T = Tf;
+  const float gC[3] = {dL_dimage[pix], dL_dimage[(size_t)H * W + pix], dL_dimage[(size_t)2 * H * W + pix]};
+  const float gD = dL_ddepth_alpha[pix], gA = dL_ddepth_alpha[(size_t)H * W + pix];
+  const float bg_dot = (v->bg[0] * gC[0] + v->bg[1] * gC[1]) + v->bg[2] * gC[2];
+  float last_alpha = 0, last_c[3] = {0, 0, 0}, rec_c[3] = {0, 0, 0}, last_z = 0, rec_z = 0, rec_a = 0;
+  for (uint32_t k = n_contrib[pix]; k-- > 0;) {
+    const uint32_t g = point_list[a0 + k];
+    const size_t r = local ? (size_t)k : (size_t)g;
+    const float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
+    const float* co = conic_opacity + 4 * g;
+    const float power = orc_power(co[0], co[1], co[2], dx, dy);
+    if (power > 0.0f) continue;
+    const float G = orc_exp(power);
+    const float alpha = fminf(ALPHA_MAX, co[3] * G);
+    if (alpha < ALPHA_MIN) continue;
+    T = T / (1.0f - alpha);
+    const float w = alpha * T;
+    float dL_dalpha = 0.0f;
+    for (int c = 0; c < 3; ++c) {
+      rec_c[c] = last_alpha * last_c[c] + (1.0f - last_alpha) * rec_c[c];
+      last_c[c] = rgb[3 * g + c];
+      dL_dalpha += (rgb[3 * g + c] - rec_c[c]) * gC[c];
+      dL_drgb[3 * r + c] += w * gC[c];
+    }
+    rec_z = last_alpha * last_z + (1.0f - last_alpha) * rec_z;
+    last_z = depth[g];
+    dL_dalpha += (depth[g] - rec_z) * gD;
+    dL_ddepth[r] += w * gD;
+    rec_a = last_alpha + (1.0f - last_alpha) * rec_a;
+    dL_dalpha += (1.0f - rec_a) * gA;
+    dL_dalpha *= T;
+    last_alpha = alpha;
+    dL_dalpha += (-Tf / (1.0f - alpha)) * bg_dot;
+    const float dL_dG = co[3] * dL_dalpha;
+    const float gdx = G * dx, gdy = G * dy;
+    const float dG_ddx = -gdx * co[0] - gdy * co[1];
+    const float dG_ddy = -gdy * co[2] - gdx * co[1];
+    dL_dxy_ndc[2 * r] += dL_dG * dG_ddx * sx;
+    dL_dxy_ndc[2 * r + 1] += dL_dG * dG_ddy * sy;
+    dL_dconic[3 * r] += -0.5f * gdx * dx * dL_dG;
+    dL_dconic[3 * r + 1] += -gdx * dy * dL_dG;
+    dL_dconic[3 * r + 2] += -0.5f * gdy * dy * dL_dG;
+    dL_dopacity[r] += G * dL_dalpha;
+  }
+}
+
 void orc_render_bwd(const OrcView* v, const uint32_t* ranges, const uint32_t* point_list, const float* xy,
                     const float* conic_opacity, const float* rgb, const float* depth, const float* final_T,
                     const uint32_t* n_contrib, const float* dL_dimage, const float* dL_ddepth_alpha,
                     float* dL_dxy_ndc, float* dL_dconic, float* dL_dopacity, float* dL_drgb, float* dL_ddepth) {
   const int W = v->W, H = v->H;
-  const int gx = (W + BLOCK - 1) / BLOCK;
-  const float sx = 0.5f * (float)W, sy = 0.5f * (float)H;
-  for (int py = 0; py < H; ++py)
-    for (int px = 0; px < W; ++px) {
-      const int tile = (py / BLOCK) * gx + (px / BLOCK);
-      const uint32_t a0 = ranges[2 * tile];
-      const size_t pix = (size_t)py * W + px;
-      const float pxf = (float)px, pyf = (float)py;
-      const float Tf = final_T[pix];
-      float T = Tf;
-      const float gC[3] = {dL_dimage[pix], dL_dimage[(size_t)H * W + pix], dL_dimage[(size_t)2 * H * W + pix]};
-      const float gD = dL_ddepth_alpha[pix], gA = dL_ddepth_alpha[(size_t)H * W + pix];
-      const float bg_dot = (v->bg[0] * gC[0] + v->bg[1] * gC[1]) + v->bg[2] * gC[2];
-      float last_alpha = 0, last_c[3] = {0, 0, 0}, rec_c[3] = {0, 0, 0}, last_z = 0, rec_z = 0, rec_a = 0;
-      for (uint32_t k = n_contrib[pix]; k-- > 0;) {
-        const uint32_t g = point_list[a0 + k];
-        const float dx = xy[2 * g] - pxf, dy = xy[2 * g + 1] - pyf;
-        const float* co = conic_opacity + 4 * g;
-        const float power = orc_power(co[0], co[1], co[2], dx, dy);
-        if (power > 0.0f) continue;
-        const float G = orc_exp(power);
-        const float alpha = fminf(ALPHA_MAX, co[3] * G);
-        if (alpha < ALPHA_MIN) continue;
-        T = T / (1.0f - alpha);
-        const float w = alpha * T;
-        float dL_dalpha = 0.0f;
-        for (int c = 0; c < 3; ++c) {
-          rec_c[c] = last_alpha * last_c[c] + (1.0f - last_alpha) * rec_c[c];
-          last_c[c] = rgb[3 * g + c];
-          dL_dalpha += (rgb[3 * g + c] - rec_c[c]) * gC[c];
-          dL_drgb[3 * g + c] += w * gC[c];
+#ifdef ORC_OMP
+  const int gx = (W + BLOCK - 1) / BLOCK, gy = (H + BLOCK - 1) / BLOCK;
+#pragma omp parallel
+  {
+    float* loc = NULL;
+    size_t loc_cap = 0;
+#pragma omp for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+      const uint32_t a0 = ranges[2 * tile], a1 = ranges[2 * tile + 1];
+      const size_t n = a1 - a0;
+      if (!n) continue;
+      if (n > loc_cap) { free(loc); loc_cap = n + n / 2; loc = (float*)malloc(loc_cap * 10 * sizeof(float)); }
+      memset(loc, 0, n * 10 * sizeof(float));
+      float *lxy = loc, *lcon = loc + 2 * n, *lop = loc + 5 * n, *lrgb = loc + 6 * n, *ldep = loc + 9 * n;
+      const int ty = tile / gx, tx = tile - ty * gx;
+      for (int py = ty * BLOCK; py < (ty + 1) * BLOCK && py < H; ++py)
+        for (int px = tx * BLOCK; px < (tx + 1) * BLOCK && px < W; ++px)
+          bwd_pixel(v, px, py, ranges, point_list, xy, conic_opacity, rgb, depth, final_T, n_contrib, dL_dimage,
+                    dL_ddepth_alpha, lxy, lcon, lop, lrgb, ldep, 1);
+      for (size_t k = 0; k < n; ++k) {     /* the tile's sums -> the Gaussians' rows */
+        const size_t g = point_list[a0 + k];
+        const float add[10] = {lxy[2 * k], lxy[2 * k + 1], lcon[3 * k], lcon[3 * k + 1], lcon[3 * k + 2], lop[k],
+                               lrgb[3 * k], lrgb[3 * k + 1], lrgb[3 * k + 2], ldep[k]};
+        float* dst[10] = {dL_dxy_ndc + 2 * g, dL_dxy_ndc + 2 * g + 1, dL_dconic + 3 * g, dL_dconic + 3 * g + 1,
+                          dL_dconic + 3 * g + 2, dL_dopacity + g, dL_drgb + 3 * g, dL_drgb + 3 * g + 1,
+                          dL_drgb + 3 * g + 2, dL_ddepth + g};
+        for (int c = 0; c < 10; ++c) {
+          if (add[c] == 0.0f) continue;
+#pragma omp atomic
+          *dst[c] += add[c];
         }
-        rec_z = last_alpha * last_z + (1.0f - last_alpha) * rec_z;
-        last_z = depth[g];
-        dL_dalpha += (depth[g] - rec_z) * gD;
-        dL_ddepth[g] += w * gD;
-        rec_a = last_alpha + (1.0f - last_alpha) * rec_a;
-        dL_dalpha += (1.0f - rec_a) * gA;
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-Tf / (1.0f - alpha)) * bg_dot;
-        const float dL_dG = co[3] * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddx = -gdx * co[0] - gdy * co[1];
-        const float dG_ddy = -gdy * co[2] - gdx * co[1];
-        dL_dxy_ndc[2 * g] += dL_dG * dG_ddx * sx;
-        dL_dxy_ndc[2 * g + 1] += dL_dG * dG_ddy * sy;
-        dL_dconic[3 * g] += -0.5f * gdx * dx * dL_dG;
-        dL_dconic[3 * g + 1] += -gdx * dy * dL_dG;
-        dL_dconic[3 * g + 2] += -0.5f * gdy * dy * dL_dG;
-        dL_dopacity[g] += G * dL_dalpha;
       }
     }
+    free(loc);
+  }
+#else
+  for (int py = 0; py < H; ++py)
+    for (int px = 0; px < W; ++px)
+      bwd_pixel(v, px, py, ranges, point_list, xy, conic_opacity, rgb, depth, final_T, n_contrib, dL_dimage,
+                dL_ddepth_alpha, dL_dxy_ndc, dL_dconic, dL_dopacity, dL_drgb, dL_ddepth, 0);
+#endif
 }
 
 /* --------------------------------------------------------------------------------------------------- K8 */
@@ -407,6 +542,9 @@ void orc_preprocess_bwd(const OrcView* v, const float* means3D, const float* sca
   const float fx = (float)W / (2.0f * v->tanfovx), fy = (float)H / (2.0f * v->tanfovy);
   const float limx = 1.3f * v->tanfovx, limy = 1.3f * v->tanfovy;
   const float mod = v->scale_modifier;
+#ifdef ORC_OMP
+#pragma omp parallel for schedule(dynamic, 64) if (!dL_dview && !dL_dproj && !dL_dcampos)
+#endif
   for (int i = 0; i < P; ++i) {
     for (int k = 0; k < 3; ++k) { dL_dmeans3D[3 * i + k] = 0; dL_dmeans2D[3 * i + k] = 0; }
     if (dL_dscales) for (int k = 0; k < 3; ++k) dL_dscales[3 * i + k] = 0;

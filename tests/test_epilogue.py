@@ -87,9 +87,10 @@ def test_densify_stats_fused_into_backward(built_lib, fused_scene):
     """stats.collect(): K8 updates max_radii2D / xyz_gradient_accum / denom exactly as the trainer's indexing ops would
     (object_trainer.py:386-390, gs_renderer.py:1061-1065), for two views in a row."""
     from dreamscene_amd import densify, scene, synth
-    from dreamscene_amd.rasterizer import GaussianRasterizer
+    from dreamscene_amd.rasterizer import GaussianRasterizer, RasterContext
     from tests.util import settings_for, small_scene
     dev = torch.device("cuda:0")
+    rc = RasterContext()
     g, _ = small_scene(P=900, H=96, W=96, K=16, seed=9)
     P = 900
     cams = synth.object_cameras(3, 96, 96, radius=3.0)
@@ -104,14 +105,14 @@ def test_densify_stats_fused_into_backward(built_lib, fused_scene):
     for cam in cams[1:]:
         s = settings_for(cam, [1, 1, 1], 3, dev)
         m2d = torch.zeros((P, 3), device=dev, requires_grad=True)
-        if fused_scene:
-            img, radii, da, _ = scene.rasterize_models(s, [model], m2d)
-        else:
-            img, radii, da = GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2d, shs=t["shs"],
-                                                    opacities=t["opacities"], scales=t["scales"],
-                                                    rotations=t["rotations"])
-        with stats.collect():
-            ((img * gi).sum() + (da * gda).sum()).backward()
+        with stats.collect(rc):      # the FORWARD inside the block takes the snapshot; the backward may run anywhere
+            if fused_scene:
+                img, radii, da, _ = scene.rasterize_models(s, [model], m2d, context=rc)
+            else:
+                img, radii, da = GaussianRasterizer(s, context=rc)(means3D=t["means3D"], means2D=m2d, shs=t["shs"],
+                                                                    opacities=t["opacities"], scales=t["scales"],
+                                                                    rotations=t["rotations"])
+        ((img * gi).sum() + (da * gda).sum()).backward()
         vis = radii > 0
         exp_r[vis] = torch.max(exp_r[vis], radii[vis].float())
         exp_a[vis] += torch.norm(m2d.grad[vis, :2], dim=-1)

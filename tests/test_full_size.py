@@ -51,11 +51,11 @@ def _scene(cfg):
     return g, [cams[i] for i in cfg["cams"]]
 
 
-def _forward(g_dev, cam, bg, D, want_keys=True):
+def _forward(g_dev, cam, bg, D, want_keys=True, rc=None):
     from dreamscene_amd import rasterizer as R
     s = settings_for(cam, bg, D, DEV)
     out, st = R.rasterize_forward_raw(s, g_dev["means3D"], g_dev["opacities"], g_dev["shs"], None, g_dev["scales"],
-                                      g_dev["rotations"], None, want_keys=want_keys)
+                                      g_dev["rotations"], None, want_keys=want_keys, rc=rc)
     torch.cuda.synchronize()
     return out, st
 
@@ -150,13 +150,10 @@ def test_full_size_properties(built_lib, name):
     #    per call from the previous view's statistics; the two differ in the association of the transmittance product)
     st2 = None
     for mode in (0, 1):
-        R.FWD_MODE = mode
-        try:
-            out_w, st2 = _forward(g_dev, cam, white, D)
-            out_b, _ = _forward(g_dev, cam, black, D, want_keys=False)
-            out_r, _ = _forward(g_dev, cam, white, D)
-        finally:
-            R.FWD_MODE = None
+        rc = R.RasterContext(fwd_variant=mode)
+        out_w, st2 = _forward(g_dev, cam, white, D, rc=rc)
+        out_b, _ = _forward(g_dev, cam, black, D, want_keys=False, rc=rc)
+        out_r, _ = _forward(g_dev, cam, white, D, rc=rc)
         da = out_w["depth_alpha"]
         assert float((da[1] + out_w["final_T"] - 1.0).abs().max()) <= 1e-5, "alpha + final_T != 1"
         assert float(((out_w["color"] - out_b["color"]) - out_w["final_T"][None]).abs().max()) <= 1e-6, "bg term != final_T"

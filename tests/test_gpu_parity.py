@@ -19,14 +19,14 @@ def _to_dev(g):
     return {k: torch.tensor(v, device=DEV) for k, v in g.items()}
 
 
-def _run_hip(g, cam, bg, D, score=False, want_keys=True, **over):
+def _run_hip(g, cam, bg, D, score=False, want_keys=True, rc=None, **over):
     from dreamscene_amd import rasterizer as R
     s = settings_for(cam, bg, D, DEV, score_flag=score)
     t = _to_dev(g)
     kw = dict(shs=t.get("shs"), colors_precomp=t.get("colors_precomp"), scales=t.get("scales"),
               rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"))
     out, st = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], kw["shs"], kw["colors_precomp"], kw["scales"],
-                                      kw["rotations"], kw["cov3D_precomp"], want_keys=want_keys)
+                                      kw["rotations"], kw["cov3D_precomp"], want_keys=want_keys, rc=rc)
     torch.cuda.synchronize()
     return out, st
 
@@ -66,13 +66,13 @@ def test_forward_vs_c_oracle(built_lib, c_oracle, D, K):
     _check_forward(out, f, 2000)
 
 
-def _grad_check(g, cam, bg, D, c_oracle, colors=False, cov=False, seed=0, tol=TOL):
+def _grad_check(g, cam, bg, D, c_oracle, colors=False, cov=False, seed=0, tol=TOL, rc=None):
     from dreamscene_amd import rasterizer as R, synth
     P = g["means3D"].shape[0]
     K = g["shs"].shape[1] if "shs" in g else 0
     H, W = cam.image_height, cam.image_width
     gi, gda = synth.upstream_grads(H, W, seed)
-    out, st = _run_hip(g, cam, bg, D, want_keys=False)
+    out, st = _run_hip(g, cam, bg, D, want_keys=False, rc=rc)
     o = R.rasterize_backward_raw(st, torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV), cam_grads=True)
     torch.cuda.synchronize()
     v = oracle_view(c_oracle, cam, P, K, D, bg)
@@ -358,14 +358,10 @@ def test_score_mode_alpha_T(built_lib, c_oracle):
     from dreamscene_amd import rasterizer as R
     g, cam = small_scene(P=900, H=64, W=64, K=16, seed=77)
     bg = np.ones(3, np.float32)
-    old = R.SCORE_MODE
-    try:
-        R.SCORE_MODE = 1
-        s = settings_for(cam, bg, 2, DEV, score_flag=True)
-        t = _to_dev(g)
-        out, _ = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None)
-    finally:
-        R.SCORE_MODE = old
+    s = settings_for(cam, bg, 2, DEV, score_flag=True)
+    t = _to_dev(g)
+    out, _ = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None,
+                                     rc=R.RasterContext(score_mode=1))
     v = oracle_view(c_oracle, cam, 900, 16, 2, bg, score_mode=1)
     f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
                          score=True)
@@ -377,34 +373,30 @@ def test_whole_tile_forward_variant(built_lib, c_oracle):
     """GsrBinning.fwd_mode = 1 (one work item per tile, one pixel per lane): same parity bars as the default variant,
     including the checkpoints the segmented backward starts from and the score output."""
     from dreamscene_amd import rasterizer as R, synth
-    old = R.FWD_MODE
-    try:
-        R.FWD_MODE = 1
-        g, cam = small_scene(P=2000, H=128, W=112, K=16, seed=13)
-        bg = np.array([1.0, 0.4, 0.1], np.float32)
-        out, _ = _run_hip(g, cam, bg, 3)
-        v = oracle_view(c_oracle, cam, 2000, 16, 3, bg)
-        f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
-        _check_forward(out, f, 2000)
-        _grad_check(g, cam, bg, 3, c_oracle)
-        # deep lists: multi-segment backward from this variant's checkpoints
-        P, H, W = 30000, 128, 128
-        g = synth.g_object(P, seed=78, K=16)
-        g["scales"] = (g["scales"] * 1.5).astype(np.float32)
-        cam = synth.object_cameras(3, H, W, radius=3.2)[2]
-        rep = _grad_check(g, cam, np.ones(3, np.float32), 3, c_oracle)
-        assert rep
-        s = settings_for(cam, np.ones(3, np.float32), 3, DEV, score_flag=True)
-        t = _to_dev(g)
-        o, _ = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None)
-        v = oracle_view(c_oracle, cam, P, 16, 3, np.ones(3, np.float32))
-        f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
-                             score=True)
-        assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 512
-        ref = f["important_score"]
-        assert err(o["score"].cpu().numpy(), ref) <= 1e-4 * max(1.0, float(ref.max()))
-    finally:
-        R.FWD_MODE = old
+    rc = R.RasterContext(fwd_variant=1)
+    g, cam = small_scene(P=2000, H=128, W=112, K=16, seed=13)
+    bg = np.array([1.0, 0.4, 0.1], np.float32)
+    out, _ = _run_hip(g, cam, bg, 3, rc=rc)
+    v = oracle_view(c_oracle, cam, 2000, 16, 3, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    _check_forward(out, f, 2000)
+    _grad_check(g, cam, bg, 3, c_oracle, rc=rc)
+    # deep lists: multi-segment backward from this variant's checkpoints
+    P, H, W = 30000, 128, 128
+    g = synth.g_object(P, seed=78, K=16)
+    g["scales"] = (g["scales"] * 1.5).astype(np.float32)
+    cam = synth.object_cameras(3, H, W, radius=3.2)[2]
+    rep = _grad_check(g, cam, np.ones(3, np.float32), 3, c_oracle, rc=rc)
+    assert rep
+    s = settings_for(cam, np.ones(3, np.float32), 3, DEV, score_flag=True)
+    t = _to_dev(g)
+    o, _ = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None, rc=rc)
+    v = oracle_view(c_oracle, cam, P, 16, 3, np.ones(3, np.float32))
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
+                         score=True)
+    assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 512
+    ref = f["important_score"]
+    assert err(o["score"].cpu().numpy(), ref) <= 1e-4 * max(1.0, float(ref.max()))
 
 
 def test_thousands_of_equal_depths_keep_index_order(built_lib, c_oracle):

@@ -154,7 +154,7 @@ def test_fused_scene_vs_oracle(built_lib, K, D, noise):
 
 @pytest.mark.gpu
 def test_fused_scene_accumulates_into_model_buffers(built_lib):
-    """MODEL_GRAD_BUFFERS: two views added on the device == sum of the two separately computed gradients; the fused
+    """SceneContext.model_grad_buffers: two views added on the device == sum of the two separately computed gradients; the fused
     autograd path equals the unfused one (torch activations + cat + GaussianRasterizer) on the same leaves."""
     from dreamscene_amd import scene, synth
     from dreamscene_amd.rasterizer import GaussianRasterizer
@@ -169,19 +169,16 @@ def test_fused_scene_accumulates_into_model_buffers(built_lib):
     gi, gda = torch.tensor(gi_np, device=dev), torch.tensor(gda_np, device=dev)
 
     def fused(cam, bufs):
-        scene.MODEL_GRAD_BUFFERS = bufs
-        try:
-            s = settings_for(cam, [1, 1, 1], D, dev)
-            m2d = torch.zeros((P, 3), device=dev, requires_grad=True)
-            img, radii, da, scales = scene.rasterize_models(s, models, m2d)
-            leaves = [t for m in models for t in m]
-            loss = (img * gi).sum() + (da * gda).sum() + 0.01 * scales.mean()
-            if bufs is None:
-                return torch.autograd.grad(loss, leaves)
-            loss.backward(inputs=[m2d])
-            return None
-        finally:
-            scene.MODEL_GRAD_BUFFERS = None
+        s = settings_for(cam, [1, 1, 1], D, dev)
+        m2d = torch.zeros((P, 3), device=dev, requires_grad=True)
+        img, radii, da, scales = scene.rasterize_models(s, models, m2d,
+                                                        context=scene.SceneContext(model_grad_buffers=bufs))
+        leaves = [t for m in models for t in m]
+        loss = (img * gi).sum() + (da * gda).sum() + 0.01 * scales.mean()
+        if bufs is None:
+            return torch.autograd.grad(loss, leaves)
+        loss.backward(inputs=[m2d])
+        return None
 
     g1, g2 = fused(cams[1], None), fused(cams[2], None)
     bufs = [tuple(torch.zeros_like(t) for t in m) for m in models]

@@ -46,18 +46,15 @@ def test_batched_views_match_sequential(built_lib, K, D, use_arena, noisy_scales
         return outs, tot, torch.stack(m2ds)
 
     ref_outs, ref_grads, ref_m2d = sequential()         # also leaves the capacity hint the batched path needs
-    rast = GaussianRasterizerViews(sets)
     arena = multiview.GradArena(P, K, dev) if use_arena else None
-    R.GRAD_ARENA = arena
-    try:
-        for rep in range(2):
-            m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
-            outs = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
-                        scales=view_scales() if noisy_scales else t["scales"], rotations=t["rotations"])
-            grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [m2d],
-                                        [y for k in range(V) for y in (gis[k], gdas[k])])
-    finally:
-        R.GRAD_ARENA = None
+    rast = GaussianRasterizerViews(sets, context=R.RasterContext(grad_arena=arena))
+    for rep in range(2):
+        m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+        outs = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
+                    scales=view_scales() if noisy_scales else t["scales"], rotations=t["rotations"])
+        # with an arena the parameter gradients are delivered THERE, not through autograd (allow_unused)
+        grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [m2d],
+                                    [y for k in range(V) for y in (gis[k], gdas[k])], allow_unused=use_arena)
     for (img, radii, da), (rimg, rradii, rda) in zip(outs, ref_outs):
         assert torch.equal(radii, rradii)
         assert torch.equal(img, rimg) and torch.equal(da, rda)      # same kernels, same order inside a view
@@ -142,3 +139,19 @@ def test_batched_views_with_precomputed_colours(built_lib):
                                     [y for k in range(V) for y in (gis[k], gdas[k])])
     for a, b in zip(grads, tot):
         assert tol_ok(a.cpu().numpy(), b.cpu().numpy(), atol=3e-6)
+
+
+def test_views_of_one_call_must_share_image_size():
+    """a mixed batch used to render and then fail in backward. Now it is refused up front (CPU: no GPU needed)."""
+    from dreamscene_amd.rasterizer import GaussianRasterizationSettings
+    from dreamscene_amd.views import GaussianRasterizerViews
+    mk = lambda h, w, sm=1.0: GaussianRasterizationSettings(
+        image_height=h, image_width=w, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3), scale_modifier=sm,
+        viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=0, campos=torch.zeros(3), prefiltered=False)
+    GaussianRasterizerViews([mk(32, 48), mk(32, 48)])
+    with pytest.raises(ValueError, match="same image_height"):
+        GaussianRasterizerViews([mk(32, 48), mk(48, 32)])
+    with pytest.raises(ValueError, match="scale_modifier"):
+        GaussianRasterizerViews([mk(32, 48), mk(32, 48, sm=2.0)])
+    with pytest.raises(ValueError):
+        GaussianRasterizerViews([])

@@ -11,8 +11,7 @@ t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)
 res = {}
 for flag in (False, True):
     for mode in (0, 1):
-        R.SCORE_MODE = mode
-        rs = [GaussianRasterizer(GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=t([1, 1, 1]),
+        rs = [GaussianRasterizer(context=R.RasterContext(score_mode=mode), raster_settings=GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=t([1, 1, 1]),
               scale_modifier=1.0, viewmatrix=t(c.world_view_transform), projmatrix=t(c.full_proj_transform), sh_degree=D,
               campos=t(c.camera_center), prefiltered=False, score_flag=flag)) for c in cams]
         m2d = torch.zeros_like(p["means3D"])

@@ -85,15 +85,17 @@ def main():
     lv_b, groups_b = make()
     opt_b = FusedAdam(groups_b, lr=0.0, eps=1e-15)
     stats = densify.DensifyStats(P, dev)
-    rast = GaussianRasterizerViews(sets)
+    from dreamscene_amd.rasterizer import RasterContext
+    rc_b = RasterContext()
+    rast = GaussianRasterizerViews(sets, context=rc_b)
 
     def step_b():
         scales, rots, opac, shs = activations(lv_b)
         vsp = torch.zeros((V, P, 3), device=dev, requires_grad=True)
         sc = torch.clamp(scales[None] + torch.randn((V, P, 3), device=dev) * ((0.2 ** 0.5) * scales[None] / 4), 0.0)
-        outs = rast(means3D=lv_b["_xyz"], means2D=vsp, shs=shs, opacities=opac, scales=sc, rotations=rots)
-        with stats.collect():          # (all views' statistics; the reference keeps the last view's only)
-            losses([o[0] for o in outs], [o[2] for o in outs], list(sc)).backward()
+        with stats.collect(rc_b):      # the LAST view's statistics count, like the reference's trainers
+            outs = rast(means3D=lv_b["_xyz"], means2D=vsp, shs=shs, opacities=opac, scales=sc, rotations=rots)
+        losses([o[0] for o in outs], [o[2] for o in outs], list(sc)).backward()
         opt_b.step(set_to_none=True)
 
     # ---------------- C: raw leaves straight into the views kernels (activations + noise fused)
@@ -103,11 +105,14 @@ def main():
     stats_c = densify.DensifyStats(P, dev)
     model_c = tuple(lv_c[k] for k in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"))
 
+    rc_c = scene.SceneContext()
+
     def step_c():
         vsp = torch.zeros((V, P, 3), device=dev, requires_grad=True)
-        outs = scene.rasterize_models_views(sets, [model_c], vsp, scale_noise=torch.randn((V, P, 3), device=dev))
-        with stats_c.collect():
-            losses([o[0] for o in outs], [o[2] for o in outs], [o[3] for o in outs]).backward()
+        with stats_c.collect(rc_c):
+            outs = scene.rasterize_models_views(sets, [model_c], vsp, scale_noise=torch.randn((V, P, 3), device=dev),
+                                                context=rc_c)
+        losses([o[0] for o in outs], [o[2] for o in outs], [o[3] for o in outs]).backward()
         opt_c.step(set_to_none=True)
 
     for name, fn in (("A_drop_in_only", step_a), ("B_views_fused_epilogue", step_b), ("C_raw_leaves_views", step_c)):

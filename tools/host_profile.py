@@ -28,9 +28,8 @@ sets = [GaussianRasterizationSettings(image_height=res, image_width=res, tanfovx
                                       bg=t([1.0, 1.0, 1.0]), scale_modifier=1.0, viewmatrix=t(c.world_view_transform),
                                       projmatrix=t(c.full_proj_transform), sh_degree=D, campos=t(c.camera_center),
                                       prefiltered=False, score_flag=False) for c in cams]
-rast = GaussianRasterizerViews(sets)
 arena = multiview.GradArena(P, K, dev)
-R.GRAD_ARENA = arena
+rast = GaussianRasterizerViews(sets, context=R.RasterContext(grad_arena=arena))
 leaves = [params[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
 
 
@@ -38,7 +37,7 @@ def step():
     means2D = torch.zeros((V,) + tuple(params["means3D"].shape), device=dev, requires_grad=True)
     outs = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
                 opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"], cov3D_precomp=None)
-    torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [means2D], [gi, gda] * V)
+    torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], [means2D], [gi, gda] * V)
 
 
 for _ in range(30):
