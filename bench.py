@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fwd-mode", type=int, default=None, help="force the forward compositing variant (0 / 1)")
+    ap.add_argument("--no-capture", action="store_true",
+                    help="batched call without graph capture: every step's ~45 launches are issued from Python "
+                         "(GaussianRasterizerViews) instead of replayed from captured hipGraphs (graph.CapturedViews)")
     ap.add_argument("--unbatched", action="store_true",
                     help="render the views of a step one call at a time (GaussianRasterizer) instead of through "
                          "GaussianRasterizerViews (same kernels; the depth sorts of all views share their launches)")
@@ -98,8 +101,10 @@ def main():
     H = W = args.res
     V = max(1, args.views_per_step)
     batched = V > 1 and not args.unbatched
-    how = (f"{V} views/step through ONE batched call (GaussianRasterizerViews)" if batched else
-           f"{V} views/step, one GaussianRasterizer call per view (drop-in interface)")
+    captured = batched and not args.no_capture
+    how = (f"{V} views/step through ONE batched call ("
+           f"{'graph.CapturedViews: launches replayed from captured hipGraphs' if captured else 'GaussianRasterizerViews'})"
+           if batched else f"{V} views/step, one GaussianRasterizer call per view (drop-in interface)")
     if args.scene == "object":
         K, D = 16, args.sh_degree
         g = synth.g_object(args.gaussians, seed=0, K=K, init_opacity=args.init_opacity)
@@ -138,9 +143,11 @@ def main():
     plain_rast0 = GaussianRasterizer(raster_settings=settings)        # no arena: autograd returns view 0's own gradients
     leaves = [params[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
 
+    from dreamscene_amd.graph import CapturedViews
     from dreamscene_amd.views import GaussianRasterizerViews
     views_ctx = ctx(False)
     rast_views = GaussianRasterizerViews(settings_list, context=views_ctx)
+    rast_captured = CapturedViews(context=views_ctx)
 
     def set_profile(p):
         prof_holder[0] = p
@@ -155,9 +162,13 @@ def main():
 
     def step_batched():
         means2D = torch.zeros((V,) + tuple(params["means3D"].shape), device=dev, requires_grad=True)
-        outs = rast_views(means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
-                          opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"],
-                          cov3D_precomp=None)
+        if captured and prof_holder[0] is None:      # (the stage timers record events: the profiled passes run eagerly)
+            outs = rast_captured(settings_list, means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
+                                 shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
+        else:
+            outs = rast_views(means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
+                              opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"],
+                              cov3D_precomp=None)
         (g2d,) = torch.autograd.grad([t_ for (img, _, da) in outs for t_ in (img, da)], [means2D], [gi, gda] * V)
         reduce_grads()
         return outs[0], g2d[0]
@@ -215,8 +226,9 @@ def main():
         single = {k: v for k, v in stage_ms.items() if k not in ("sort", "scan")}
         dominant = max(single, key=single.get)
         prof.reset()
-        prof.set_stages([dominant])      # timed region records only the dominant kernel's events ...
-        prof.set_sampling(3)             # ... of every 3rd launch (two event records per launch are not free)
+        set_profile(None)
+        for _ in range(3):               # (back to the timed configuration: no event records, captured graphs replay)
+            step()
 
     sync()
     R.HOST_WAIT_S[0] = 0.0
@@ -245,11 +257,19 @@ def main():
             step_dropin()
         sync()
         dropin = {"views_per_s": world * n_drop * V / (time.perf_counter() - td), "steps": n_drop}
-        set_profile(prof)
 
     N_pairs = None
     roofline = None
     if prof is not None:
+        # launch duration of the dominant kernel: HIP events around its launches on the launch stream. The timed region
+        # replays captured graphs, which cannot carry event records, so the same launches are issued eagerly here (same
+        # kernels, same arguments) right after it, only that stage's timer on.
+        prof.set_stages([dominant])
+        set_profile(prof)
+        n_roof = max(10, min(50, args.steps // 4))
+        for _ in range(n_roof):
+            step()
+        sync()
         res = prof.collect()
         ms, cnt = res[dominant]
         set_profile(None)
@@ -299,6 +319,9 @@ def main():
             roofline = {"bound": bound, "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,
                         "avg_launch_us": round(avg_s * 1e6, 2), "views_per_launch": per_launch,
+                        "launches_timed": int(cnt),
+                        "timed_how": "HIP events around the kernel's launches on the launch stream, eager pass right after "
+                                     "the timed region" + (" (the timed region replays captured graphs)" if captured else ""),
                         "whole_path": {"algorithmic_bytes_per_view": int(e2e_bytes),
                                        "achieved_GBps": round(e2e_bytes * world * args.steps * V / elapsed / 1e9 / world, 1),
                                        "frac_of_hbm_peak": round(e2e_bytes * args.steps * V / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
@@ -332,7 +355,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "gaussians": P, "resolution": [H, W], "tile_pairs_N": N_pairs,
-                       "views_per_step_per_gpu": V, "batched_call": batched,
+                       "views_per_step_per_gpu": V, "batched_call": batched, "captured_graphs": captured,
+                       "capture_stats": dict(rast_captured.stats) if captured else None,
                        "dropin": ("`dropin_views_per_s`: the same views through one GaussianRasterizer call per view (the "
                                   f"reference's interface), {dropin['steps']} steps after the timed region") if dropin else
                                  "`value` IS the drop-in figure (one GaussianRasterizer call per view)",

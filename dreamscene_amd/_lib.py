@@ -18,10 +18,11 @@ class GsrView(C.Structure):
                 ("image_height", C.c_int32), ("image_width", C.c_int32),
                 ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
                 ("prefiltered", C.c_int32), ("score_mode", C.c_int32),
-                ("bg", _f), ("viewmatrix", _f), ("projmatrix", _f), ("campos", _f)]
+                ("bg", _f), ("viewmatrix", _f), ("projmatrix", _f), ("campos", _f), ("dynamic", _f)]
 
 
 GSR_MAX_MODELS = 16
+GSR_PACKED_VIEW_FLOATS = 44
 
 
 class GsrModel(C.Structure):
@@ -106,6 +107,7 @@ SYMBOLS = [
                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gsr_forward_project_batch", C.c_int, [C.c_int32, C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom),
                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("gsr_pack_views", C.c_int, [C.c_int32, C.POINTER(GsrView), C.c_void_p, C.c_void_p]),
     ("gsr_forward_render", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGeom), C.c_uint64, C.POINTER(GsrBinning),
                                      C.POINTER(GsrImages), C.c_void_p, C.c_void_p]),
     ("gsr_backward_views", C.c_int, [C.c_int32, C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom),

@@ -152,6 +152,45 @@ int gsr_profile_collect(GsrProfile* p, double* ms, int64_t* counts) {
   return GSR_OK;
 }
 
+namespace {
+struct PackViews {
+  const float* bg[GSR_MAX_BATCH_VIEWS];
+  const float* viewmatrix[GSR_MAX_BATCH_VIEWS];
+  const float* projmatrix[GSR_MAX_BATCH_VIEWS];
+  const float* campos[GSR_MAX_BATCH_VIEWS];
+  float tanfovx[GSR_MAX_BATCH_VIEWS], tanfovy[GSR_MAX_BATCH_VIEWS], sh_degree[GSR_MAX_BATCH_VIEWS];
+};
+// one workgroup per view, one thread per float of the packed row
+__global__ void __launch_bounds__(64) k_pack_views(const PackViews pv, float* __restrict__ packed) {
+  const int k = blockIdx.x, t = threadIdx.x;
+  float x = 0.f;
+  if (t < 3) x = pv.bg[k][t];
+  else if (t >= 4 && t < 20) x = pv.viewmatrix[k][t - 4];
+  else if (t >= 20 && t < 36) x = pv.projmatrix[k][t - 20];
+  else if (t >= 36 && t < 39) x = pv.campos[k][t - 36];
+  else if (t == 40) x = pv.tanfovx[k];
+  else if (t == 41) x = pv.tanfovy[k];
+  else if (t == 42) x = pv.sh_degree[k];
+  if (t < GSR_PACKED_VIEW_FLOATS) packed[k * GSR_PACKED_VIEW_FLOATS + t] = x;
+}
+}  // namespace
+
+int gsr_pack_views(int32_t n_views, const GsrView* views, float* packed, void* stream_) {
+  if (n_views < 1 || n_views > GSR_MAX_BATCH_VIEWS || !views || !packed || !aligned16(packed)) return GSR_EINVAL;
+  PackViews pv = PackViews{};
+  for (int k = 0; k < n_views; ++k) {
+    const int rc = check_view(&views[k]);
+    if (rc) return rc;
+    pv.bg[k] = views[k].bg; pv.viewmatrix[k] = views[k].viewmatrix; pv.projmatrix[k] = views[k].projmatrix;
+    pv.campos[k] = views[k].campos;
+    pv.tanfovx[k] = views[k].tanfovx; pv.tanfovy[k] = views[k].tanfovy; pv.sh_degree[k] = (float)views[k].sh_degree;
+  }
+  GsrDeviceGuard dev(packed);
+  hipLaunchKernelGGL(k_pack_views, dim3((uint32_t)n_views), dim3(64), 0, (hipStream_t)stream_, pv, packed);
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
+
 static uint64_t* n_pairs_device(const GsrGeom* geom, int32_t P) { return gsr_pair_counts(*geom, P); }
 
 static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geom, uint64_t* n_pairs_host,

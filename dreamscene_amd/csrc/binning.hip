@@ -518,7 +518,7 @@ static uint32_t col_runs(int32_t P) { return (uint32_t)(((P > 0 ? P : 1) + kColR
 // packed tile rectangles and the per-run column histogram of the column path.
 extern "C" size_t gsr_project_scratch_bytes(int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
-  return 5 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4) + align256(kRadix * 4) +
+  return 5 * align256(m * 4) + align256((size_t)kMaxBins * sort_blocks(m, kItemsSmall) * 4) + align256(kMaxBins * 4) +
          align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + align256(264 * 4) + 256 + 1024;
 }
 
@@ -532,7 +532,7 @@ extern "C" size_t gsr_sort_scratch_bytes(uint64_t n, uint32_t n_tiles) {
 
 struct ProjectScratch {
   uint32_t *k0, *k1, *v0, *v1, *hist, *totals, *rects, *hist1, *totals1, *colstart;
-  uint64_t* counts;   // [0] = N (pairs), [1] = visible Gaussians
+  uint64_t* counts;   // [0] = N (pairs), [1] = visible Gaussians, then two u32: (~min, max) of the visible depth keys
 };
 static ProjectScratch carve_project(void* scratch, int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
@@ -542,8 +542,8 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
   s.k1 = (uint32_t*)b; b += align256(m * 4);
   s.v0 = (uint32_t*)b; b += align256(m * 4);
   s.v1 = (uint32_t*)b; b += align256(m * 4);
-  s.hist = (uint32_t*)b; b += align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4);
-  s.totals = (uint32_t*)b; b += align256(kRadix * 4);
+  s.hist = (uint32_t*)b; b += align256((size_t)kMaxBins * sort_blocks(m, kItemsSmall) * 4);
+  s.totals = (uint32_t*)b; b += align256(kMaxBins * 4);
   s.rects = (uint32_t*)b; b += align256(m * 4);
   s.hist1 = (uint32_t*)b; b += align256((size_t)256 * col_runs((int32_t)m) * 4);
   s.totals1 = (uint32_t*)b; b += align256(256 * 4);
@@ -570,12 +570,15 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
   uint64_t* n_vis_dev = s.counts + 1;
   const bool columns = use_columns(v.image_height, v.image_width, v.P);
   if (batch > 1 && !columns) return GSR_EINVAL;
-  int where;
+  const int where = 1;      // three ranged passes: the result is in (k1, v1) whatever the input
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
-                                        s.totals, stream, batch, bstride);
-    geom.sorted_idx = where ? s.v1 : s.v0;
+    uint32_t* range = reinterpret_cast<uint32_t*>(s.counts + 2);
+    if (batch > 1) GSR_HIP(hipMemset2DAsync(range, bstride, 0, 2 * sizeof(uint32_t), (size_t)batch, stream));
+    else GSR_HIP(hipMemsetAsync(range, 0, 2 * sizeof(uint32_t), stream));
+    ranged_sort_iota_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, (uint64_t)P, n_vis_dev, range, s.hist, s.totals, stream, batch,
+                                      bstride);
+    geom.sorted_idx = s.v1;
     GSR_HIP(hipGetLastError());
   }
   {

@@ -420,6 +420,20 @@ __device__ __forceinline__ float splat_tau(float opac) {
   return (opac * 255.0f > 1.0f) ? 2.0f * logf(opac * 255.0f) * 1.0001f + 0.001f : -1.f;
 }
 
+// tanfov and the active SH degree travel by value in GsrView -- unless GsrView.dynamic names a device f32[4]
+// (tanfovx, tanfovy, sh_degree, reserved): then the kernels take them from there WHEN THEY RUN, which is what lets a
+// captured graph (hipGraph) of a step be replayed with the next step's cameras (dreamscene_amd/graph.py).
+struct ViewDyn {
+  float tanfovx, tanfovy;
+  int sh_degree;
+};
+__device__ __forceinline__ ViewDyn view_dyn(const float* __restrict__ dyn, float tfx, float tfy, int D) {
+  ViewDyn d;
+  d.tanfovx = tfx; d.tanfovy = tfy; d.sh_degree = D;
+  if (dyn) { d.tanfovx = dyn[0]; d.tanfovy = dyn[1]; d.sh_degree = (int)dyn[2]; }
+  return d;
+}
+
 // --------------------------------------------------------------------------------------------------------- K1
 template <int KT, bool SCENE = false, typename TAB = NoScene>
 __global__ void __launch_bounds__(256)
@@ -437,8 +451,9 @@ k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restr
     p_xyz = sc.xyz[rw.m]; p_scale = sc.scaling[rw.m]; p_rot = sc.rotation[rw.m]; p_opac = sc.opacity[rw.m];
   }
   const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
-  const float fx = (float)W / (2.0f * v.tanfovx), fy = (float)H / (2.0f * v.tanfovy);
-  const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
+  const ViewDyn vd = view_dyn(v.dynamic, v.tanfovx, v.tanfovy, v.sh_degree);
+  const float fx = (float)W / (2.0f * vd.tanfovx), fy = (float)H / (2.0f * vd.tanfovy);
+  const float limx = 1.3f * vd.tanfovx, limy = 1.3f * vd.tanfovy;
 
   ViewConst vc;
   load_view(v, vc);
@@ -522,9 +537,9 @@ k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restr
       const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float b[16];
-      sh_basis(v.sh_degree, dx, dy, dz, b);
+      sh_basis(vd.sh_degree, dx, dy, dz, b);
       float acc[3];
-      sh_colour_n<KT>(v.sh_degree, shr, b, acc);
+      sh_colour_n<KT>(vd.sh_degree, shr, b, acc);
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
     }
@@ -548,9 +563,9 @@ k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restr
       const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float b[16];
-      sh_basis(v.sh_degree, dx, dy, dz, b);
+      sh_basis(vd.sh_degree, dx, dy, dz, b);
       float acc[3];
-      sh_colour_n<(KT > 0 ? KT : 1)>(v.sh_degree, shr, b, acc);
+      sh_colour_n<(KT > 0 ? KT : 1)>(vd.sh_degree, shr, b, acc);
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
     }
@@ -578,10 +593,10 @@ k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restr
       const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float b[16];
-      sh_basis(v.sh_degree, dx, dy, dz, b);
+      sh_basis(vd.sh_degree, dx, dy, dz, b);
       const float* sh = lw + lane * sh_lds_stride(K);
       float acc[3];
-      sh_colour(v.sh_degree, sh, b, acc);
+      sh_colour(vd.sh_degree, sh, b, acc);
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
     }
@@ -616,6 +631,7 @@ struct K1Views {
   float tanfovx[GSR_MAX_BATCH_VIEWS];
   float tanfovy[GSR_MAX_BATCH_VIEWS];
   int32_t sh_degree[GSR_MAX_BATCH_VIEWS];
+  const float* dyn[GSR_MAX_BATCH_VIEWS];    // GsrView.dynamic of every view (NULL: the by-value entries above)
   int32_t per_view_scales;
   const float* scales[GSR_MAX_BATCH_VIEWS];
   // scene input (raw leaves): per-view noise samples and the per-view activated scales handed back to the caller
@@ -648,7 +664,8 @@ k_preprocess_views(const GsrView v, const GsrGaussians g, const K1Views vb) {
     for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
-    const float tfx = vb.tanfovx[vv], tfy = vb.tanfovy[vv];
+    const ViewDyn vd = view_dyn(vb.dyn[vv], vb.tanfovx[vv], vb.tanfovy[vv], vb.sh_degree[vv]);
+    const float tfx = vd.tanfovx, tfy = vd.tanfovy;
     const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
     Proj pr;
     pr.vis = false; pr.radius = 0; pr.ntiles = 0; pr.rect = 0;
@@ -678,9 +695,9 @@ k_preprocess_views(const GsrView v, const GsrGaussians g, const K1Views vb) {
       const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float b[16];
-      sh_basis(vb.sh_degree[vv], dx, dy, dz, b);
+      sh_basis(vd.sh_degree, dx, dy, dz, b);
       float acc[3];
-      sh_colour_n<KT>(vb.sh_degree[vv], shr, b, acc);
+      sh_colour_n<KT>(vd.sh_degree, shr, b, acc);
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
     }
@@ -733,7 +750,8 @@ k_preprocess_views_scene(const GsrView v, const SceneTab sc, const K1Views vb) {
     for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
-    const float tfx = vb.tanfovx[vv], tfy = vb.tanfovy[vv];
+    const ViewDyn vd = view_dyn(vb.dyn[vv], vb.tanfovx[vv], vb.tanfovy[vv], vb.sh_degree[vv]);
+    const float tfx = vd.tanfovx, tfy = vd.tanfovy;
     const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
     Proj pr;
     pr.vis = false; pr.radius = 0; pr.ntiles = 0; pr.rect = 0;
@@ -766,16 +784,16 @@ k_preprocess_views_scene(const GsrView v, const SceneTab sc, const K1Views vb) {
       const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float b[16];
-      sh_basis(vb.sh_degree[vv], dx, dy, dz, b);
+      sh_basis(vd.sh_degree, dx, dy, dz, b);
       float acc[3];
       if (vb.sh_noise[vv]) {
         float shv[F];
         const float* nz = vb.sh_noise[vv] + (size_t)i * F;
 #pragma unroll
         for (int k = 0; k < F; ++k) shv[k] = shr[k] + nz[k] * (kSqrtPoint2 * shr[k]);
-        sh_colour_n<KT>(vb.sh_degree[vv], shv, b, acc);
+        sh_colour_n<KT>(vd.sh_degree, shv, b, acc);
       } else {
-        sh_colour_n<KT>(vb.sh_degree[vv], shr, b, acc);
+        sh_colour_n<KT>(vd.sh_degree, shr, b, acc);
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb[c] = fmaxf(acc[c] + 0.5f, 0.0f);
@@ -935,15 +953,16 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
                  const int32_t* __restrict__ radii, const float* __restrict__ partials, const GsrGrads out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float cam_red[4][32];
-  const int P = v.P, W = v.image_width, H = v.image_height, K = KT > 0 ? KT : v.sh_stride, D = v.sh_degree;
+  const ViewDyn vd = view_dyn(v.dynamic, v.tanfovx, v.tanfovy, v.sh_degree);
+  const int P = v.P, W = v.image_width, H = v.image_height, K = KT > 0 ? KT : v.sh_stride, D = vd.sh_degree;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const Rows rw = resolve_rows<SCENE>(sc, P);
   const int64_t i = rw.i, row = rw.row, wave_first = rw.wave_row;
   const int n_valid = rw.n_valid;
   const float *p_xyz = g.means3D, *p_scale = g.scales, *p_rot = g.rotations;
   if constexpr (SCENE) { p_xyz = sc.xyz[rw.m]; p_scale = sc.scaling[rw.m]; p_rot = sc.rotation[rw.m]; }
-  const float fx = (float)W / (2.0f * v.tanfovx), fy = (float)H / (2.0f * v.tanfovy);
-  const float limx = 1.3f * v.tanfovx, limy = 1.3f * v.tanfovy;
+  const float fx = (float)W / (2.0f * vd.tanfovx), fy = (float)H / (2.0f * vd.tanfovy);
+  const float limx = 1.3f * vd.tanfovx, limy = 1.3f * vd.tanfovy;
   const float mod = v.scale_modifier;
   const bool want_cam = (out.dL_dview != nullptr) || (out.dL_dproj != nullptr) || (out.dL_dcampos != nullptr);
 
@@ -1261,6 +1280,7 @@ struct K8Views {
   float tanfovx[GSR_MAX_BATCH_VIEWS];
   float tanfovy[GSR_MAX_BATCH_VIEWS];
   int32_t sh_degree[GSR_MAX_BATCH_VIEWS];   // the active degree may differ per view (scene_render's sh_deg_aug)
+  const float* dyn[GSR_MAX_BATCH_VIEWS];    // GsrView.dynamic of every view (NULL: the by-value entries above)
   const int32_t* radii[GSR_MAX_BATCH_VIEWS];
   const float* partials[GSR_MAX_BATCH_VIEWS];
   float* dL_dmeans2D[GSR_MAX_BATCH_VIEWS];
@@ -1329,8 +1349,9 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
 #pragma unroll
       for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
-      const float tfx = vb.tanfovx[vv], tfy = vb.tanfovy[vv];
-      const int D = vb.sh_degree[vv];
+      const ViewDyn vd = view_dyn(vb.dyn[vv], vb.tanfovx[vv], vb.tanfovy[vv], vb.sh_degree[vv]);
+      const float tfx = vd.tanfovx, tfy = vd.tanfovy;
+      const int D = vd.sh_degree;
       const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
       const float limx = 1.3f * tfx, limy = 1.3f * tfy;
       const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
@@ -1523,8 +1544,9 @@ k_preprocess_bwd_views_scene(const GsrView v, const SceneTab sc, const SceneGrad
       for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
 #pragma unroll
       for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
-      const float tfx = vb.tanfovx[vv], tfy = vb.tanfovy[vv];
-      const int D = vb.sh_degree[vv];
+      const ViewDyn vd = view_dyn(vb.dyn[vv], vb.tanfovx[vv], vb.tanfovy[vv], vb.sh_degree[vv]);
+      const float tfx = vd.tanfovx, tfy = vd.tanfovy;
+      const int D = vd.sh_degree;
       const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
       const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
       const float4 pa = pp[0], pb = pp[1], pc = pp[2];
@@ -1779,6 +1801,7 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
     if (gs[k].scales != g.scales) vb.per_view_scales = 1;
     vb.viewmatrix[k] = views[k].viewmatrix; vb.projmatrix[k] = views[k].projmatrix; vb.campos[k] = views[k].campos;
     vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy; vb.sh_degree[k] = views[k].sh_degree;
+    vb.dyn[k] = views[k].dynamic;
     vb.radii[k] = geoms[k].radii; vb.partials[k] = outs[k].partials; vb.dL_dmeans2D[k] = outs[k].dL_dmeans2D;
   }
   // densification statistics: the views whose GsrGrads entry names the statistics tensors (all the same ones)
@@ -1851,6 +1874,7 @@ int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaus
     if (gs[k].scales != g.scales) vb.per_view_scales = 1;
     vb.viewmatrix[k] = views[k].viewmatrix; vb.projmatrix[k] = views[k].projmatrix; vb.campos[k] = views[k].campos;
     vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy; vb.sh_degree[k] = views[k].sh_degree;
+    vb.dyn[k] = views[k].dynamic;
     vb.splat[k] = geoms[k].splat; vb.radii[k] = geoms[k].radii; vb.tiles_touched[k] = geoms[k].tiles_touched;
     vb.depth_keys[k] = gsr_depth_keys(geoms[k], views[k].P); vb.rects[k] = gsr_tile_rects(geoms[k], views[k].P);
   }

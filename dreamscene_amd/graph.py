@@ -1,0 +1,289 @@
+"""The V views of an optimizer step with their launches replayed from captured graphs (hipGraph through
+torch.cuda.CUDAGraph) -- same kernels, same results as `GaussianRasterizerViews`, a fraction of the host work.
+
+Why: a 4-view step is ~45 kernel launches issued from Python through ctypes; the host needs 0.93 ms to enqueue what the
+GPU executes in 0.93 ms at 500 k Gaussians @1024^2, and smaller workloads are outright host-bound (100 k @512^2: 7 100
+views/s where the kernels alone allow 11 400 -- round-1 measurements). In capacity mode every launch parameter of the
+path depends only on (P, K, H, W, V, capacity): the kernels take the data-dependent pair count N from device memory. So
+the launches of a step are three fixed sequences:
+    graph A   K1 of all views, depth sorts, column counts            -> N of every view lands in pinned host words
+    graph B   pair emission, tile sort, ranges, work lists, K6       (binning + compositing)
+    graph C   work lists, K7 of all views, K8                        (backward)
+A and B are two graphs so that the host can check N against the capacity while B runs (the same protocol as the eager
+path: one wait per step, the GPU stays busy); if a view outgrew the capacity the step is redone eagerly with exact sizes
+and the graphs are re-captured with more room.
+
+What changes from step to step lives in device memory the graphs only point to:
+  * the parameters: the caller's own tensors (persistent leaves updated in place by the optimizer); a new tensor
+    (densification changes P) means a new capture;
+  * the cameras: bg / viewmatrix / projmatrix / campos AND tanfov / active SH degree of every view sit in one packed
+    block (`gsr_pack_views`, GsrView.dynamic) rewritten by one small launch per step from the step's settings;
+  * per-view scales [V,P,3] (the trainers' scale noise) and the upstream gradients are copied into static buffers.
+The outputs are static tensors too: they are overwritten by the next step's replay (consume them within the step, as
+with any captured graph).
+
+    rast = CapturedViews(context=RasterContext(grad_arena=arena))
+    outs = rast(settings_list, means3D=..., means2D=m2d, opacities=..., shs=..., scales=..., rotations=...)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from . import rasterizer as R
+from . import views as VW
+
+WARM_CALLS = 2          # eager calls (they learn the pair counts) before the first capture
+
+
+class _Captured:
+    """Static buffers + the three graphs of one (inputs, geometry, capacity) signature."""
+    pass
+
+
+def _sig(settings_list, tensors, rc, per_view):
+    s0 = settings_list[0]
+    return (len(settings_list), int(s0.image_height), int(s0.image_width), float(s0.scale_modifier), per_view,
+            tuple((t.data_ptr(), tuple(t.shape)) if t is not None else None for t in tensors),
+            id(rc.grad_arena), bool(rc.accumulate), rc.score_mode,
+            tuple(t.data_ptr() for t in rc.densify_stats) if rc.densify_stats is not None else None,
+            tuple(rc.stats_views) if isinstance(rc.stats_views, (list, tuple)) else rc.stats_views)
+
+
+class _CapturedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, owner, settings_list, rc):
+        outs, cap_state, eager_states = owner._forward(settings_list, means3D, opacities, shs, scales, rotations, rc)
+        ctx.owner, ctx.rc, ctx.cap_state, ctx.eager_states = owner, rc, cap_state, eager_states
+        ctx.opac_shape = opacities.shape
+        ctx.per_view_scales = scales.dim() == 3
+        ctx.set_materialize_grads(False)
+        flat = []
+        for (img, radii, da) in outs:
+            ctx.mark_non_differentiable(radii)
+            flat += [img, radii, da]
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        o = ctx.owner._backward(ctx.cap_state, ctx.eager_states, grads, ctx.rc, ctx.per_view_scales)
+        if ctx.rc.grad_arena is not None:
+            return (None, o["dL_dmeans2D"], None, None, o["dL_dscales"] if ctx.per_view_scales else None, None,
+                    None, None, None)
+        return (o["dL_dmeans3D"], o["dL_dmeans2D"], o["dL_dshs"], o["dL_dopacities"].reshape(ctx.opac_shape),
+                o["dL_dscales"], o["dL_drotations"], None, None, None)
+
+
+class CapturedViews(torch.nn.Module):
+    """Like views.GaussianRasterizerViews, with the settings of the step passed to forward() (cameras change every step;
+    image size and scale_modifier must stay the same) and shs + scales + rotations as inputs (the trainers' case)."""
+
+    def __init__(self, context: Optional[R.RasterContext] = None, headroom: float = 1.5):
+        super().__init__()
+        self.context = context
+        self.headroom = float(headroom)
+        self._cap: Optional[_Captured] = None
+        self._warm = 0
+        self._peak_n = 0
+        self.stats = dict(captures=0, replays=0, eager_steps=0, overflows=0)
+
+    # ------------------------------------------------------------------------------------------------ public
+    def forward(self, raster_settings_list: Sequence, means3D, means2D, opacities, shs, scales, rotations) -> List[tuple]:
+        settings_list = tuple(raster_settings_list)
+        V = len(settings_list)
+        if V < 1 or V > VW.MAX_VIEWS:
+            raise ValueError(f"1..{VW.MAX_VIEWS} views per call")
+        if not VW._uniform(settings_list):
+            raise ValueError("all views of a call must have the same image_height, image_width and scale_modifier")
+        if any(s.score_flag for s in settings_list):
+            raise ValueError("score_flag views return a 4-tuple: render them with GaussianRasterizer")
+        if means2D.shape[0] != V:
+            raise ValueError(f"means2D must be [V,P,3] with V = {V} views")
+        rc = (self.context or R.DEFAULT_CONTEXT).snapshot()
+        flat = _CapturedFn.apply(means3D, means2D, shs, opacities, scales, rotations, self, settings_list, rc)
+        return [tuple(flat[3 * k:3 * k + 3]) for k in range(V)]
+
+    # ------------------------------------------------------------------------------------------------ internals
+    def _eager_forward(self, settings_list, means3D, opacities, shs, scales, rotations, rc):
+        res = VW.rasterize_views_forward_raw(settings_list, means3D, opacities, shs, None, scales, rotations, None, rc=rc)
+        self._peak_n = max([self._peak_n] + [int(o["N"]) for o, _ in res])
+        self.stats["eager_steps"] += 1
+        return [(o["color"], o["radii"], o["depth_alpha"]) for o, _ in res], None, [st for _, st in res]
+
+    def _forward(self, settings_list, means3D, opacities, shs, scales, rotations, rc):
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise L.GsrError("the HIP rasterizer needs tensors on a cuda (ROCm) device; there is no CPU fallback")
+        per_view = scales.dim() == 3
+        persistent = (means3D, opacities, shs, rotations) + (() if per_view else (scales,))
+        for t in persistent + ((scales,) if per_view else ()):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("CapturedViews inputs must be contiguous fp32 tensors")
+        sig = _sig(settings_list, persistent, rc, per_view) + (tuple(scales.shape),)
+        cap = self._cap
+        if cap is None or cap.sig != sig:
+            self._cap = cap = None
+            if self._warm < WARM_CALLS or int(means3D.shape[0]) == 0:
+                self._warm += 1
+                return self._eager_forward(settings_list, means3D, opacities, shs, scales, rotations, rc)
+            cap = self._capture(sig, settings_list, means3D, opacities, shs, scales, rotations, rc, per_view)
+        lib = L.load()
+        V = len(settings_list)
+        stream = torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev):
+            # this step's cameras -> the packed block the captured views point into (one small launch)
+            structs = (L.GsrView * V)(*[self._user_view(s, cap.P, cap.K, rc) for s in settings_list])
+            L.check(lib.gsr_pack_views(V, structs, cap.packed.data_ptr(), stream.cuda_stream), "gsr_pack_views")
+            if per_view:
+                cap.scales.copy_(scales)
+            cap.pinned.fill_(-1)
+            cap.gA.replay()
+            cap.evA.record(stream)
+            cap.gB.replay()
+            t_wait = time.perf_counter()
+            cap.evA.synchronize()                 # (graph B is already enqueued behind A: the GPU stays busy)
+            R.HOST_WAIT_S[0] += time.perf_counter() - t_wait
+        ns = [int(x) for x in cap.pinned[:V].tolist()]
+        self._peak_n = max([self._peak_n] + ns)
+        self.stats["replays"] += 1
+        if max(ns) > cap.cap or min(ns) < 0:
+            # a view outgrew the capacity (its lists were clamped): redo this step exactly, capture again next step
+            self.stats["overflows"] += 1
+            self._cap = None
+            return self._eager_forward(settings_list, means3D, opacities, shs, scales, rotations, rc)
+        return cap.outs, cap, None
+
+    def _user_view(self, s, P, K, rc):
+        dev = s.viewmatrix.device
+        f = lambda t, n: R._prep(t.reshape(-1), n, dev, align=4)
+        bg, vm, pm, cp = f(s.bg, "bg"), f(s.viewmatrix, "viewmatrix"), f(s.projmatrix, "projmatrix"), f(s.campos, "campos")
+        v = R._view_struct(s, P, K, bg, vm, pm, cp, rc.score_mode)
+        v._keep = (bg, vm, pm, cp)          # until gsr_pack_views has been enqueued (stream order covers the rest)
+        return v
+
+    def _capture(self, sig, settings_list, means3D, opacities, shs, scales, rotations, rc, per_view) -> _Captured:
+        lib = L.load()
+        dev = means3D.device
+        V = len(settings_list)
+        s0 = settings_list[0]
+        P, K, H, W = int(means3D.shape[0]), int(shs.shape[1]), int(s0.image_height), int(s0.image_width)
+        cap = _Captured()
+        cap.sig, cap.P, cap.K, cap.V = sig, P, K, V
+        want = int(self._peak_n * self.headroom) + 65536
+        q = max(65536, 1 << max(0, want.bit_length() - 4))
+        cap.cap = (want + q - 1) // q * q
+        f32 = torch.float32
+        with torch.cuda.device(dev):
+            cap.packed = torch.zeros((V, L.GSR_PACKED_VIEW_FLOATS), dtype=f32, device=dev)
+            cap.pinned = torch.zeros(VW.MAX_VIEWS, dtype=torch.int64).pin_memory()
+            cap.scales = torch.empty_like(scales) if per_view else scales
+            # the captured views: their camera tensors are slices of the packed block, tanfov / SH degree come from it too
+            views = []
+            for k, s in enumerate(settings_list):
+                row = cap.packed[k]
+                views.append(s._replace(bg=row[0:3], viewmatrix=row[4:20].view(4, 4), projmatrix=row[20:36].view(4, 4),
+                                        campos=row[36:39]))
+            stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
+            cap.proj_scratch = torch.empty(stride * V + 4096, dtype=torch.uint8, device=dev)
+            sort_bytes = R._align(int(lib.gsr_sort_scratch_bytes(cap.cap, lib.gsr_num_tiles(H, W))), 256)
+            cap.sort_scratch = torch.empty(sort_bytes * V + 4096, dtype=torch.uint8, device=dev)
+            gens = [R._forward_steps(
+                views[k], means3D, opacities, shs, None, cap.scales[k] if per_view else scales, rotations, None, False,
+                False, "auto", None,
+                dict(scratch=cap.proj_scratch[k * stride:(k + 1) * stride], pinned=cap.pinned, index=k, event=None,
+                     sort=(lambda nbytes, k=k: cap.sort_scratch[k * sort_bytes:(k + 1) * sort_bytes]),
+                     capture=dict(cap=cap.cap, fwd_mode=int(rc.fwd_variant or 0)),
+                     dynamic=cap.packed[k].data_ptr() + 40 * 4), rc) for k in range(V)]
+            heads = [next(g) for g in gens]
+            cap.views = (L.GsrView * V)(*[h[0] for h in heads])
+            cap.geoms = (L.GsrGeom * V)(*[h[1] for h in heads])
+            cap.gauss = (L.GsrGaussians * V)(*[h[2] for h in heads])
+            cap.bins = (L.GsrBinning * V)(*[h[3] for h in heads])
+            cap.imgs = (L.GsrImages * V)(*[h[4] for h in heads])
+            # a first, un-captured run fills the packed block and proves the arguments before anything is recorded
+            structs = (L.GsrView * V)(*[self._user_view(s, P, K, rc) for s in settings_list])
+            cur = torch.cuda.current_stream(dev)
+            L.check(lib.gsr_pack_views(V, structs, cap.packed.data_ptr(), cur.cuda_stream), "gsr_pack_views")
+            if per_view:
+                cap.scales.copy_(scales)
+            torch.cuda.synchronize(dev)
+            cap.gA, cap.gB, cap.gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cap.gA, capture_error_mode="thread_local"):
+                st = torch.cuda.current_stream(dev).cuda_stream
+                L.check(lib.gsr_forward_project_batch(V, cap.views, cap.gauss, cap.geoms, cap.pinned.data_ptr(), st, None),
+                        "gsr_forward_project_batch (capture)")
+            for k in range(V):
+                heads[k][1].sorted_idx = cap.geoms[k].sorted_idx
+            with torch.cuda.graph(cap.gB, pool=cap.gA.pool(), capture_error_mode="thread_local"):
+                st = torch.cuda.current_stream(dev).cuda_stream
+                L.check(lib.gsr_forward_render_batch(V, cap.views, cap.geoms, cap.cap, cap.bins, cap.imgs, st, None),
+                        "gsr_forward_render_batch (capture)")
+            res = []
+            for g in gens:
+                try:
+                    next(g)
+                    raise RuntimeError("forward generator did not finish")
+                except StopIteration as e:
+                    res.append(e.value)
+            cap.states = [st_ for _, st_ in res]
+            cap.outs = [(o["color"], o["radii"], o["depth_alpha"]) for o, _ in res]
+            # ---- backward: static upstream-gradient buffers, static results
+            cap.g_color = torch.zeros((V, 3, H, W), dtype=f32, device=dev)
+            cap.g_da = torch.zeros((V, 2, H, W), dtype=f32, device=dev)
+            cap.bwd = None
+            cap.evA = torch.cuda.Event()
+            cap.rc = rc
+            cap.per_view = per_view
+        self.stats["captures"] += 1
+        return cap
+
+    def _capture_backward(self, cap: _Captured, rc, per_view):
+        dev = cap.g_color.device
+        V = cap.V
+        with torch.cuda.device(dev):
+            # run it once eagerly: allocates the result tensors (kept as the static ones) and validates the arguments
+            o = R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
+                                               accumulate=rc.accumulate, stats=None, per_view_scales=per_view)
+            torch.cuda.synchronize(dev)
+            cap.bwd_args = None
+
+            def launch(stream_ptr):
+                return R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
+                                                      accumulate=rc.accumulate, stats=rc.densify_stats,
+                                                      stats_views=rc.stats_views, per_view_scales=per_view,
+                                                      reuse=o)
+            with torch.cuda.graph(cap.gC, pool=cap.gA.pool(), capture_error_mode="thread_local"):
+                launch(None)
+            cap.bwd = o
+
+    def _backward(self, cap: Optional[_Captured], eager_states, grads, rc, per_view):
+        V = len(grads) // 3
+        if cap is None:            # a warm-up / overflow step: the eager backward on the eager states
+            st0 = eager_states[0]
+            H, W, dev = st0.view.image_height, st0.view.image_width, st0.dev
+            z = lambda c: torch.zeros((c, H, W), dtype=torch.float32, device=dev)
+            gcs = [grads[3 * k] if grads[3 * k] is not None else z(3) for k in range(V)]
+            gdas = [grads[3 * k + 2] if grads[3 * k + 2] is not None else z(2) for k in range(V)]
+            return R.rasterize_backward_views_raw(eager_states, gcs, gdas, arena=rc.grad_arena, accumulate=rc.accumulate,
+                                                  stats=rc.densify_stats, stats_views=rc.stats_views,
+                                                  per_view_scales=per_view, profile=rc.profile)
+        dev = cap.g_color.device
+        with torch.cuda.device(dev):
+            if cap.bwd is None:
+                self._capture_backward(cap, rc, per_view)
+            dst, src = [], []
+            for k in range(V):
+                for buf, g in ((cap.g_color[k], grads[3 * k]), (cap.g_da[k], grads[3 * k + 2])):
+                    if g is None:
+                        buf.zero_()
+                    elif g.data_ptr() != buf.data_ptr():
+                        dst.append(buf)
+                        src.append(g)
+            if dst:
+                torch._foreach_copy_(dst, src)
+            cap.gC.replay()
+        return cap.bwd

@@ -41,10 +41,177 @@ class GradArena:
 
 
 def allreduce_grads(arena: GradArena, group=None, async_op: bool = False):
-    """Sum the packed per-view gradients over all ranks, in place. No-op without an initialised process group."""
+    """Sum the packed per-view gradients over all ranks, in place: the plain dense exchange (236 B / Gaussian at K = 16).
+    No-op without an initialised process group. GradExchange below sends less."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return None
     return dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class GradExchange:
+    """Sum of the arena over the ranks of a step, moving only what can be non-zero.
+
+    What a rank's arena holds after its views' backward (K8 writes zeros everywhere else):
+      * SH columns beyond the ACTIVE degree D are identically zero (K8 writes dL/dSH for (D+1)^2 coefficients only;
+        D starts at 0 and grows by one every 500 steps, gs_renderer.py:185, 578-580): 11 + 3 (D+1)^2 floats per Gaussian
+        can differ from zero, not 11 + 3 K  (14 of 59 at D = 0, 23 at D = 1, 38 at D = 2);
+      * rows of Gaussians no pixel composited are identically zero: culled ones (indoor scenes: 94 % of 2 M per view) and
+        everything behind the opaque front layers of an object (early termination T < 1e-4).
+    Wire formats (`mode`, "auto" picks per step from the non-zero row fraction, one small host read):
+      * "dense": all-reduce of [geometry 11 P | active SH columns 3 (D+1)^2 P] -- the arena itself when D is the stored
+        degree (zero-copy), else a packed staging buffer (one strided copy each way);
+      * "rows":  every rank contributes only its non-zero rows: all-gather of the row counts, then of (row index, row
+        values) padded to the largest count; each rank adds the contributions in RANK ORDER, so all replicas end up
+        with bit-identical sums (as they do with the ring all-reduce) and keep taking identical optimizer steps.
+        Received bytes per rank: sum_r nnz_r (4 + 4 F) with F = 11 + 3 (D+1)^2, against 2 (W-1)/W 4 F P for the dense
+        ring -- a win below ~ 2 (W-1) / W^2 of the rows per rank (22 % at W = 8).
+    `reduce_scatter_adam` is the sharded-optimizer form of the dense exchange (flat parameter arena required)."""
+
+    GEOM = ("means3D", "scales", "rotations", "opacities")
+
+    def __init__(self, arena: GradArena, sh_degree: Optional[int] = None, group=None, mode: str = "auto",
+                 rows_below: Optional[float] = None):
+        if mode not in ("auto", "dense", "rows"):
+            raise ValueError("mode is 'auto', 'dense' or 'rows'")
+        self.arena, self.group, self.mode = arena, group, mode
+        self.rows_below = rows_below
+        self.sh_degree = None
+        self.set_sh_degree(sh_degree)
+        self.last = {}          # what the last reduce() did (format, bytes): for logs / bench lines
+
+    # ---- layout
+    def set_sh_degree(self, sh_degree: Optional[int]) -> None:
+        """Active SH degree of the coming steps (None = all stored coefficients)."""
+        K = self.arena.K
+        nb = K if sh_degree is None else min(K, (int(sh_degree) + 1) ** 2)
+        self.sh_degree, self.nb = sh_degree, nb
+        P = self.arena.P
+        self.row_floats = 11 + 3 * nb
+        self._staging = None
+        if nb < K:      # [geometry regions as laid out in the arena (incl. their alignment padding) | packed active SH]
+            self._staging = torch.zeros(self._offset_of_shs() + P * nb * 3, dtype=self.arena.flat.dtype,
+                                        device=self.arena.flat.device)
+
+    def _offset_of_shs(self) -> int:
+        es = self.arena.flat.element_size()
+        return (self.arena.views["shs"].data_ptr() - self.arena.flat.data_ptr()) // es
+
+    def wire_buffer(self) -> torch.Tensor:
+        """[geometry | active SH columns] as one contiguous tensor: the arena itself at full degree, else the staging
+        buffer filled from the arena (pack)."""
+        if self._staging is None:
+            return self.arena.flat
+        P, nb, o = self.arena.P, self.nb, self._offset_of_shs()
+        self._staging[:o].copy_(self.arena.flat[:o])
+        self._staging[o:o + P * nb * 3].view(P, nb, 3).copy_(self.arena.views["shs"][:, :nb, :])
+        return self._staging[:o + P * nb * 3]
+
+    def _unpack(self, wire: torch.Tensor) -> None:
+        if self._staging is None:
+            return
+        P, nb, o = self.arena.P, self.nb, self._offset_of_shs()
+        self.arena.flat[:o].copy_(wire[:o])
+        self.arena.views["shs"][:, :nb, :].copy_(wire[o:o + P * nb * 3].view(P, nb, 3))
+
+    # ---- non-zero rows
+    def nonzero_rows(self) -> torch.Tensor:
+        """Indices (ascending) of the Gaussians whose gradient row has any non-zero entry on this rank."""
+        v = self.arena.views
+        P, nb = self.arena.P, self.nb
+        m = (v["means3D"] != 0).any(1) | (v["scales"] != 0).any(1) | (v["rotations"] != 0).any(1) | \
+            (v["opacities"].reshape(P) != 0) | (v["shs"][:, :nb, :].reshape(P, nb * 3) != 0).any(1)
+        return torch.nonzero(m).reshape(-1)
+
+    def _rows_of(self, idx: torch.Tensor) -> torch.Tensor:
+        v = self.arena.views
+        n, nb = idx.numel(), self.nb
+        return torch.cat([v["means3D"][idx], v["scales"][idx], v["rotations"][idx], v["opacities"][idx].reshape(n, 1),
+                          v["shs"][idx, :nb, :].reshape(n, nb * 3)], dim=1)
+
+    def _add_rows(self, idx: torch.Tensor, rows: torch.Tensor) -> None:
+        v = self.arena.views
+        n, nb = idx.numel(), self.nb
+        v["means3D"].index_add_(0, idx, rows[:, 0:3])
+        v["scales"].index_add_(0, idx, rows[:, 3:6])
+        v["rotations"].index_add_(0, idx, rows[:, 6:10])
+        v["opacities"].index_add_(0, idx, rows[:, 10:11].reshape((n,) + tuple(v["opacities"].shape[1:])))
+        v["shs"][:, :nb, :].index_add_(0, idx, rows[:, 11:].reshape(n, nb, 3))
+
+    # ---- the exchange
+    def reduce(self):
+        """Leaves the sum over all ranks in the arena, on every rank, bit-identical across ranks."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            self.last = dict(format="none", bytes_sent=0)
+            return
+        W = dist.get_world_size(self.group)
+        P, F = self.arena.P, self.row_floats
+        mode = self.mode
+        idx = counts = None
+        if mode in ("auto", "rows"):
+            idx = self.nonzero_rows()
+            counts = [torch.zeros(1, dtype=torch.int64, device=idx.device) for _ in range(W)]
+            dist.all_gather(counts, torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device), group=self.group)
+            counts = [int(c.item()) for c in counts]          # (the one host read of the exchange)
+            if mode == "auto":
+                # received bytes: rows format sum_r n_r (4 + 4F) vs dense ring 2 (W-1)/W 4 F P  (same decision on every rank)
+                limit = self.rows_below if self.rows_below is not None else None
+                rows_bytes = sum(counts) * (4 + 4 * F)
+                dense_bytes = 2 * (W - 1) / W * 4 * F * P
+                use_rows = (sum(counts) / W <= limit * P) if limit is not None else (rows_bytes < dense_bytes)
+                mode = "rows" if use_rows else "dense"
+        if mode == "dense":
+            wire = self.wire_buffer()
+            dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
+            self._unpack(wire)
+            self.last = dict(format="dense", row_floats=F, bytes_per_rank=int(2 * (W - 1) / W * 4 * wire.numel()))
+            return
+        nmax = max(counts)
+        dev, dt = self.arena.flat.device, self.arena.flat.dtype
+        my_idx = torch.zeros(max(nmax, 1), dtype=torch.int64, device=dev)
+        my_rows = torch.zeros((max(nmax, 1), F), dtype=dt, device=dev)
+        n = idx.numel()
+        my_idx[:n] = idx
+        if n:
+            my_rows[:n] = self._rows_of(idx)
+        all_idx = [torch.empty_like(my_idx) for _ in range(W)]
+        all_rows = [torch.empty_like(my_rows) for _ in range(W)]
+        dist.all_gather(all_idx, my_idx, group=self.group)
+        dist.all_gather(all_rows, my_rows, group=self.group)
+        self.arena.flat.zero_()
+        for r in range(W):                                    # rank order: the same association on every rank
+            if counts[r]:
+                self._add_rows(all_idx[r][:counts[r]], all_rows[r][:counts[r]])
+        self.last = dict(format="rows", row_floats=F, rows=counts, bytes_per_rank=int(sum(counts) * (4 + 4 * F)))
+
+    def reduce_scatter_adam(self, param_flat: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
+                            lr_of, betas=(0.9, 0.999), eps: float = 1e-15, adam=None):
+        """The dense exchange in its sharded-optimizer form (full stored degree only): reduce-scatter of the arena, every
+        rank updates ITS 1/W of the flat parameter arena (`param_flat`, laid out like the gradient arena: the trainer's
+        leaves are views of it) with `adam(param_shard, grad_shard, m_shard, v_shard, step, lr tensor-or-callable)`, then
+        all-gather of the updated parameters. Same wire bytes as the all-reduce, 1/W of the optimizer's HBM traffic per
+        rank, and the second half of the exchange carries PARAMETERS, which the next forward needs anyway.
+        lr_of(lo, hi) -> per-element learning rates of flat elements [lo, hi) (the reference uses one lr per group)."""
+        if self._staging is not None:
+            raise ValueError("reduce_scatter_adam needs the full stored SH degree (the arena is the wire buffer)")
+        W = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        r = dist.get_rank(self.group) if dist.is_initialized() else 0
+        n = self.arena.flat.numel()
+        per = (n + W - 1) // W
+        if per * W != n:
+            raise ValueError(f"arena size {n} must be a multiple of the world size {W} (pad P)")
+        lo, hi = r * per, (r + 1) * per
+        gshard = torch.empty(per, dtype=self.arena.flat.dtype, device=self.arena.flat.device)
+        if W > 1 and dist.get_backend(self.group) != "gloo":
+            dist.reduce_scatter_tensor(gshard, self.arena.flat, op=dist.ReduceOp.SUM, group=self.group)
+        elif W > 1:       # gloo (the CPU tests) has no reduce-scatter: same result through an all-reduce
+            dist.all_reduce(self.arena.flat, op=dist.ReduceOp.SUM, group=self.group)
+            gshard.copy_(self.arena.flat[lo:hi])
+        else:
+            gshard.copy_(self.arena.flat)
+        adam(param_flat[lo:hi], gshard, exp_avg[lo:hi], exp_avg_sq[lo:hi], step, lr_of(lo, hi), betas, eps)
+        if W > 1:
+            dist.all_gather_into_tensor(param_flat, param_flat[lo:hi].clone(), group=self.group)
+        self.last = dict(format="reduce_scatter+adam+all_gather", bytes_per_rank=int(2 * (W - 1) / W * 4 * n))
 
 
 def reduce_view_stats(means2D_grad: torch.Tensor, radii: torch.Tensor, group=None):
@@ -67,25 +234,25 @@ def shard_views(n_views: int, rank: int, world: int):
 
 
 def render_views_data_parallel(rasterize_view, params: Dict[str, torch.Tensor], cameras, upstream, arena: GradArena,
-                               group=None):
+                               group=None, exchange: Optional[GradExchange] = None):
     """Render this rank's share of `cameras` (fwd+bwd) and leave the SUM over all views of every parameter
     gradient in `arena` on every rank.
 
-    rasterize_view(params, camera, grad_out) must run one view forward+backward and write that view's parameter
-    gradients into the tensors of grad_out (a dict of arena-shaped tensors), overwriting them.
+    rasterize_view(params, camera, grad_out, upstream, accumulate) runs one view forward+backward and writes that view's
+    parameter gradients into the tensors of grad_out (the arena's views): overwriting them when accumulate is False,
+    ADDING to them when it is True -- K8's accumulate mode (RasterContext.accumulate): the sum over a rank's views is
+    formed on the device by the kernel that produces the gradients, no extra pass over the arena.
     Equivalent, to fp32 summation order, to the sequential accumulation the reference performs."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     mine = shard_views(len(cameras), rank, world)
-    acc: Optional[torch.Tensor] = None
     outs = []
     for j, vi in enumerate(mine):
-        outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi]))
-        if len(mine) > 1:
-            acc = arena.flat.clone() if acc is None else acc.add_(arena.flat)
-    if acc is not None:
-        arena.flat.copy_(acc)
+        outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi], j > 0))
     if not mine:
         arena.flat.zero_()
-    allreduce_grads(arena, group)
+    if exchange is not None:
+        exchange.reduce()
+    else:
+        allreduce_grads(arena, group)
     return outs

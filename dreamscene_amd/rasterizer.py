@@ -232,10 +232,10 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     shs, colors_precomp = _prep(shs, "shs", dev), _prep(colors_precomp, "colors_precomp", dev)
     scales, rotations = _prep(scales, "scales", dev, align=4), _prep(rotations, "rotations", dev)
     cov3D_precomp = _prep(cov3D_precomp, "cov3D_precomp", dev)
-    bg = _prep(s.bg.reshape(-1), "bg", dev)
-    vm = _prep(s.viewmatrix.reshape(-1), "viewmatrix", dev)
-    pm = _prep(s.projmatrix.reshape(-1), "projmatrix", dev)
-    cp = _prep(s.campos.reshape(-1), "campos", dev)
+    bg = _prep(s.bg.reshape(-1), "bg", dev, align=4)
+    vm = _prep(s.viewmatrix.reshape(-1), "viewmatrix", dev, align=4)
+    pm = _prep(s.projmatrix.reshape(-1), "projmatrix", dev, align=4)
+    cp = _prep(s.campos.reshape(-1), "campos", dev, align=4)
     K = int(shs.shape[1]) if shs is not None else (K_scene if scene is not None else 0)
     if shs is not None and (shs.dim() != 3 or shs.shape[0] != P or shs.shape[2] != 3):
         raise ValueError(f"shs must be [P,K,3], got {tuple(shs.shape)}")
@@ -243,6 +243,8 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     st = _State()
     st.P, st.K, st.dev = P, K, dev
     st.view = _view_struct(s, P, K, bg, vm, pm, cp, rc.score_mode)
+    if batch is not None and batch.get("dynamic") is not None:
+        st.view.dynamic = int(batch["dynamic"])     # device f32[4]: tanfov / SH degree read when the kernels run
     g = L.GsrGaussians()
     g.means3D, g.opacities, g.shs, g.colors_precomp = _ptr(means3D), _ptr(opacities), _ptr(shs), _ptr(colors_precomp)
     g.scales, g.rotations, g.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3D_precomp)
@@ -260,6 +262,9 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     tiles = lib.gsr_num_tiles(H, W)
     mode = mode or rc.forward_mode
     hint = ws.hint.get((P, H, W)) if mode == "auto" else None
+    capture = batch is not None and batch.get("capture") is not None
+    if capture:           # graph capture (graph.py): fixed capacity, no host reads at all, nothing learned from this call
+        hint = int(batch["capture"]["cap"])
     if batch is not None and hint is None:
         raise RuntimeError("batched forward needs a capacity hint (render the views once unbatched first)")
 
@@ -306,10 +311,13 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
             b.scratch, b.scratch_bytes, b.count_on_device = sort_scratch.data_ptr(), sort_scratch.numel(), int(on_device)
             # forward variant from the PREVIOUS view's statistics (complete by now; a wrong guess only costs speed):
             # whole-tile items when thousands of shallow tiles saturate the machine, quarter items otherwise
-            last_active, last_n = ws.last_stats.get((P, H, W), (0, 0))
-            act = int(ws.stats_pinned[0]) if last_active is None else last_active
-            b.fwd_mode = int(rc.fwd_variant if rc.fwd_variant is not None else
-                             (act >= 2048 and last_n > 0 and last_n / max(act, 1) < 1024))
+            if capture:
+                b.fwd_mode = int(batch["capture"].get("fwd_mode", rc.fwd_variant or 0))
+            else:
+                last_active, last_n = ws.last_stats.get((P, H, W), (0, 0))
+                act = int(ws.stats_pinned[0]) if last_active is None else last_active
+                b.fwd_mode = int(rc.fwd_variant if rc.fwd_variant is not None else
+                                 (act >= 2048 and last_n > 0 and last_n / max(act, 1) < 1024))
             b.stats_host = ws.stats_pinned.data_ptr()
             im.final_T, im.n_contrib, im.tile_depth = ptrs["final_T"], ptrs["n_contrib"], ptrs["tile_depth"]
             im.ckpt = ptrs["ckpt"]
@@ -341,6 +349,8 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
             want = int(hint * 1.5) + 65536
             q = max(65536, 1 << max(0, want.bit_length() - 4))
             cap = (want + q - 1) // q * q
+            if capture:
+                cap = hint                       # the caller chose the capacity
             buf, ptrs, offs = alloc_state(cap)
             bind(ptrs, cap, True)
             if batch is not None:
@@ -355,6 +365,17 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                 event.record(torch.cuda.current_stream(dev))
                 L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), cap, C.byref(b), C.byref(im), stream,
                                                prof), "gsr_forward_render")
+            if capture:
+                # nothing may touch the host while the stream is being captured: the pair counts land in the pinned words
+                # when the graph RUNS; the owner of the graph compares them with `cap` after every replay (graph.py)
+                st.N = None
+                st.geom, st.binning, st.images = geom, b, im
+                color_alias, da_alias = color.detach(), depth_alpha.detach()
+                st.keep = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, bg, vm, pm, cp, radii,
+                           (buf,), color_alias, da_alias, sc_keep, sc_out)
+                st.versions = []
+                return dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, N=None, cap=cap,
+                            **{"act_" + k: v for k, v in sc_out.items()}), st
             if batch is None or not batch.get("synced", [False])[0]:
                 t_wait = time.perf_counter()
                 event.synchronize()          # (the render is already enqueued behind the projection: the GPU stays busy)
@@ -616,11 +637,12 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
 
 def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=None, accumulate: bool = False,
                                  stats=None, stats_views=None, per_view_scales: Optional[bool] = None,
-                                 profile=None) -> dict:
+                                 profile=None, reuse: Optional[dict] = None) -> dict:
     """Backward of several views of the same Gaussians through gsr_backward_views: K7 per view, one K8 pass over all
     views. Returns the SUMMED parameter gradients (written to / added to the arena's views when given) and the per-view
     means2D gradients [V,P,3]. per_view_scales (default: whether the views' scales are different tensors): every view has
-    its own scales tensor, `dL_dscales` is then [V,P,3]."""
+    its own scales tensor, `dL_dscales` is then [V,P,3]. reuse: the dict a previous call with the same arguments returned --
+    its tensors receive the results again and nothing is allocated (graph capture, graph.py)."""
     lib = L.load()
     V = len(states)
     st0 = states[0]
@@ -638,17 +660,22 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
     def new(*shape, name=None):
         t = av.get(name)
         return t if t is not None else torch.empty(shape, dtype=f32, device=dev)
-    o = dict(dL_dmeans3D=new(P, 3, name="means3D"), dL_dopacities=new(P, 1, name="opacities"),
-             dL_dshs=new(P, K, 3, name="shs") if g.shs else None, dL_dcolors=new(P, 3) if g.colors_precomp else None,
-             dL_dscales=new(P, 3, name="scales") if g.scales else None,
-             dL_drotations=new(P, 4, name="rotations") if g.rotations else None,
-             dL_dcov3D=new(P, 6) if g.cov3D_precomp else None)
+    names = ("dL_dmeans3D", "dL_dopacities", "dL_dshs", "dL_dcolors", "dL_dscales", "dL_drotations", "dL_dcov3D")
     if per_view_scales is None:
         per_view_scales = any(st.gauss.scales != g.scales for st in states)
-    if per_view_scales:        # every view has its own scales tensor -> its own scale gradient
-        o["dL_dscales"] = torch.empty((V, P, 3), dtype=f32, device=dev)
-    m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
-    partials = torch.empty((V, max(P, 1), 12), dtype=f32, device=dev)
+    if reuse is not None:
+        o = {k: reuse[k] for k in names}
+        m2d, partials = reuse["_m2d"], reuse["_partials"]
+    else:
+        o = dict(dL_dmeans3D=new(P, 3, name="means3D"), dL_dopacities=new(P, 1, name="opacities"),
+                 dL_dshs=new(P, K, 3, name="shs") if g.shs else None, dL_dcolors=new(P, 3) if g.colors_precomp else None,
+                 dL_dscales=new(P, 3, name="scales") if g.scales else None,
+                 dL_drotations=new(P, 4, name="rotations") if g.rotations else None,
+                 dL_dcov3D=new(P, 6) if g.cov3D_precomp else None)
+        if per_view_scales:        # every view has its own scales tensor -> its own scale gradient
+            o["dL_dscales"] = torch.empty((V, P, 3), dtype=f32, device=dev)
+        m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
+        partials = torch.empty((V, max(P, 1), 12), dtype=f32, device=dev)
     views = (L.GsrView * V)(*[st.view for st in states])
     gauss = (L.GsrGaussians * V)(*[st.gauss for st in states])
     geoms = (L.GsrGeom * V)(*[st.geom for st in states])
@@ -663,6 +690,8 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         keep += [gc, gda]
         igs[k].dL_dcolor, igs[k].dL_ddepth_alpha = gc.data_ptr(), gda.data_ptr()
         for name, t in o.items():
+            if name.startswith("_"):
+                continue
             setattr(grs[k], name, _ptr(t))
         if per_view_scales:
             grs[k].dL_dscales = o["dL_dscales"][k].data_ptr()
@@ -677,6 +706,7 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof),
                 "gsr_backward_views")
     o["dL_dmeans2D"] = m2d[:, :P]
+    o["_m2d"], o["_partials"] = m2d, partials
     return o
 
 

@@ -58,6 +58,12 @@ typedef struct GsrView {
   const float* viewmatrix; /* device f32[16] */
   const float* projmatrix; /* device f32[16] */
   const float* campos;     /* device f32[3]  */
+  const float* dynamic;    /* NULL, or device f32[4] = (tanfovx, tanfovy, sh_degree, reserved): when set, the kernels take
+                              these three from HERE at the time they run instead of the by-value fields above -- with bg /
+                              viewmatrix / projmatrix / campos already being device tensors, every per-camera quantity then
+                              lives in device memory and a captured graph of a step (hipGraph) can be replayed with new
+                              cameras by rewriting that memory (gsr_pack_views). The by-value fields must still be valid
+                              (they are what the host-side checks see) */
 } GsrView;
 
 /* ---- gather-free multi-model input with the activations fused into K1 / K8 -------
@@ -256,6 +262,15 @@ int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uin
 #define GSR_MAX_BATCH_VIEWS 16
 int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGaussians* gaussians /* [n_views] */,
                               GsrGeom* geoms, uint64_t* n_pairs_pinned, void* stream, GsrProfile* prof);
+
+/* Camera block of n_views views in one launch: packed[k] = (bg[3], 0, viewmatrix[16], projmatrix[16], campos[3], 0,
+ * tanfovx, tanfovy, sh_degree, 0) = GSR_PACKED_VIEW_FLOATS floats (every tensor 16-byte aligned), gathered from the
+ * views' device tensors and by-value fields. A caller that replays a captured step points the GsrView tensors of the
+ * CAPTURED views into such a block (bg = row, viewmatrix = row + 4, projmatrix = row + 20, campos = row + 36,
+ * dynamic = row + 40) and refreshes it with this call from the settings of the step at hand. packed must be 16-byte
+ * aligned; no host synchronisation. */
+#define GSR_PACKED_VIEW_FLOATS 44
+int gsr_pack_views(int32_t n_views, const GsrView* views, float* packed, void* stream);
 
 /* K3 pair emission in depth order, K4 stable tile sort, K5 tile ranges, K6 front-to-back compositing. */
 int gsr_forward_render(const GsrView*, const GsrGeom*, uint64_t n_pairs, GsrBinning*, GsrImages*, void* stream,

@@ -1,0 +1,138 @@
+"""-m gpu: the captured (hipGraph) step -- dreamscene_amd/graph.py -- replays exactly what the eager batched path runs:
+per-view outputs bit-identical, gradients equal to fp32-atomic order, new cameras / FoV / SH degree / backgrounds picked
+up from the packed camera block at replay time, capacity overflow handled by an exact eager step + re-capture."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import settings_for, small_scene, tol_ok
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(P=3000, H=112, W=144, K=16, seed=17, scale_mul=6.0):
+    g, _ = small_scene(P=P, H=H, W=W, K=K, seed=seed, scale_mul=scale_mul)
+    t = {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in g.items()}
+    return g, t
+
+
+def _eager(sets, t, gis, gdas, scales=None):
+    from dreamscene_amd.views import GaussianRasterizerViews
+    V, P = len(sets), t["means3D"].shape[0]
+    leaves = [t[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    rast = GaussianRasterizerViews(sets)
+    for _ in range(2):      # second call: batched
+        m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+        outs = rast(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
+                    scales=t["scales"] if scales is None else scales, rotations=t["rotations"])
+        grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [m2d],
+                                    [y for k in range(V) for y in (gis[k], gdas[k])])
+    return [(a.clone(), b.clone(), c.clone()) for a, b, c in outs], [x.clone() for x in grads]
+
+
+@pytest.mark.parametrize("V,K,D", [(4, 16, 3), (1, 4, 1), (3, 9, 2)])
+def test_captured_step_equals_eager_and_follows_the_cameras(built_lib, V, K, D):
+    from dreamscene_amd import synth
+    from dreamscene_amd.graph import CapturedViews
+    P, H, W = 3000, 112, 144
+    g, t = _setup(P, H, W, K)
+    leaves = [t[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    cams = synth.object_cameras(8, H, W, radius=3.0)
+    gis = [torch.tensor(synth.upstream_grads(H, W, seed=k)[0], device=DEV) for k in range(V)]
+    gdas = [torch.tensor(synth.upstream_grads(H, W, seed=k)[1], device=DEV) for k in range(V)]
+    rast = CapturedViews()
+    # five steps with DIFFERENT cameras, backgrounds, FoV and active SH degree: steps 0-1 run eagerly (they learn the pair
+    # counts), step 2 captures, steps 3-4 replay with new cameras
+    for step in range(5):
+        sets = []
+        for k in range(V):
+            c = cams[(step + 2 * k) % 8]
+            s = settings_for(c, [0.1 * step, 0.4, 1.0 - 0.2 * k], D if (step + k) % 3 else 0, DEV)
+            if step == 4:                        # a different field of view at replay time (GsrView.dynamic)
+                s = s._replace(tanfovx=s.tanfovx * 1.25, tanfovy=s.tanfovy * 1.25)
+            sets.append(s)
+        ref_outs, ref_grads = _eager(sets, t, gis, gdas)
+        m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+        outs = rast(sets, means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                    rotations=t["rotations"])
+        grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [m2d],
+                                    [y for k in range(V) for y in (gis[k], gdas[k])])
+        for (img, radii, da), (rimg, rradii, rda) in zip(outs, ref_outs):
+            assert torch.equal(radii, rradii), step
+            assert torch.equal(img, rimg) and torch.equal(da, rda), step      # same kernels, same order inside a view
+        for a, b in zip(grads, ref_grads):
+            assert tol_ok(a.reshape(b.shape).cpu().numpy(), b.cpu().numpy(), atol=2e-6), step   # (fp32 atomics order)
+    assert rast.stats["captures"] == 1 and rast.stats["replays"] == 3 and rast.stats["eager_steps"] == 2, rast.stats
+
+
+def test_captured_step_with_arena_per_view_scales_and_stats(built_lib):
+    """The trainers' configuration: gradients delivered in a GradArena, fresh per-view scale noise ([V,P,3] scales, their
+    own gradient per view), densification statistics of the last view -- all through the replayed graphs."""
+    from dreamscene_amd import densify, multiview, synth
+    from dreamscene_amd.graph import CapturedViews
+    from dreamscene_amd.rasterizer import RasterContext
+    from dreamscene_amd.views import GaussianRasterizerViews
+    V, P, H, W, K, D = 4, 2500, 96, 128, 16, 3
+    g, t = _setup(P, H, W, K, seed=23)
+    cams = synth.object_cameras(8, H, W, radius=3.0)
+    gis = [torch.tensor(synth.upstream_grads(H, W, seed=k)[0], device=DEV) for k in range(V)]
+    gdas = [torch.tensor(synth.upstream_grads(H, W, seed=k)[1], device=DEV) for k in range(V)]
+    gen = torch.Generator().manual_seed(5)
+    arena_c, arena_e = multiview.GradArena(P, K, torch.device(DEV)), multiview.GradArena(P, K, torch.device(DEV))
+    stats_c, stats_e = densify.DensifyStats(P, torch.device(DEV)), densify.DensifyStats(P, torch.device(DEV))
+    rc_c = RasterContext(grad_arena=arena_c, densify_stats=stats_c.tensors())
+    rc_e = RasterContext(grad_arena=arena_e, densify_stats=stats_e.tensors())
+    rast_c = CapturedViews(context=rc_c)
+    for step in range(5):
+        sets = [settings_for(cams[(step + k) % 8], [1, 1, 1], D, DEV) for k in range(V)]
+        noise = torch.randn((V, P, 3), generator=gen).to(DEV)
+        sc = torch.clamp(t["scales"][None] + noise * ((0.2 ** 0.5) * t["scales"][None] / 4), 0.0).detach().requires_grad_(True)
+        res = {}
+        for name, rast, arena in (("e", GaussianRasterizerViews(sets, context=rc_e), arena_e), ("c", rast_c, arena_c)):
+            m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+            kw = dict(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], shs=t["shs"], scales=sc,
+                      rotations=t["rotations"])
+            outs = rast(sets, **kw) if name == "c" else rast(**kw)
+            g2d, gsc = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], [m2d, sc],
+                                           [y for k in range(V) for y in (gis[k], gdas[k])])
+            res[name] = ([tuple(x.clone() for x in o) for o in outs], g2d.clone(), gsc.clone(), arena.flat.clone())
+        for (a, b) in zip(res["c"][0], res["e"][0]):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), step
+        assert tol_ok(res["c"][1].cpu().numpy(), res["e"][1].cpu().numpy(), atol=2e-6)
+        assert tol_ok(res["c"][2].cpu().numpy(), res["e"][2].cpu().numpy(), atol=2e-6)
+        assert tol_ok(res["c"][3].cpu().numpy(), res["e"][3].cpu().numpy(), atol=2e-6)
+    assert torch.equal(stats_c.denom, stats_e.denom) and torch.equal(stats_c.max_radii2D, stats_e.max_radii2D)
+    np.testing.assert_allclose(stats_c.xyz_gradient_accum.cpu().numpy(), stats_e.xyz_gradient_accum.cpu().numpy(),
+                               rtol=1e-5, atol=1e-9)
+    assert int(stats_c.denom.max()) == 5 and rast_c.stats["captures"] == 1
+
+
+def test_captured_step_overflow_falls_back_and_recaptures(built_lib):
+    """The splats grow until a view's pair count exceeds the captured capacity: that step is redone eagerly (exact), the
+    next one captures again with more room; results stay equal to the eager path throughout."""
+    from dreamscene_amd import synth
+    from dreamscene_amd.graph import CapturedViews
+    V, P, H, W, K, D = 2, 2000, 192, 256, 4, 1          # 192 tiles: 2000 screen-filling splats exceed the 131072-pair capacity
+    g, t = _setup(P, H, W, K, seed=41, scale_mul=1.0)
+    cams = synth.object_cameras(4, H, W, radius=3.0)
+    gis = [torch.tensor(synth.upstream_grads(H, W, seed=k)[0], device=DEV) for k in range(V)]
+    gdas = [torch.tensor(synth.upstream_grads(H, W, seed=k)[1], device=DEV) for k in range(V)]
+    sets = [settings_for(cams[k + 1], [0, 0, 0], D, DEV) for k in range(V)]
+    rast = CapturedViews(headroom=1.0)
+    rast_cap_before = None
+    for step, mul in enumerate([1.0, 1.0, 1.0, 1.0, 12.0, 12.0, 12.0, 12.0]):
+        with torch.no_grad():
+            t["scales"].copy_(torch.tensor(g["scales"], device=DEV) * mul)
+        ref_outs, _ = _eager(sets, t, gis, gdas)
+        m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+        outs = rast(sets, means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                    rotations=t["rotations"])
+        torch.autograd.backward([x for (img, _, da) in outs for x in (img, da)],
+                                [y for k in range(V) for y in (gis[k], gdas[k])])
+        for (img, radii, da), (rimg, rradii, rda) in zip(outs, ref_outs):
+            assert torch.equal(radii, rradii) and torch.equal(img, rimg) and torch.equal(da, rda), step
+        if step == 3:
+            rast_cap_before = rast._cap.cap
+    assert rast.stats["overflows"] == 1 and rast.stats["captures"] == 2, rast.stats
+    assert rast._cap.cap > rast_cap_before
