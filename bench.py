@@ -398,43 +398,73 @@ def _torch_cpu_leg(P, res, n_views, budget_s):
             "config": f"{P} Gaussians @{res}x{res}, K=16, SH degree 3"}
 
 
-def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), init_opacity=False):
-    """The CPU path timed beside the GPU numbers, on a bounded sample (~20-30 s of CPU work), host core count stated.
+def _cpu_legs_child(P, K, D, H, W, init_opacity, budget_s):
+    """Runs in a SUBPROCESS (python bench.py --cpu-legs ...) under a hard timeout: the all-core CPU figures. A CPU leg
+    must never be able to stall the bench line (256-thread OpenMP / torch thread pools on an unknown host)."""
+    from dreamscene_amd import synth
+    from oracle import c_oracle as CO
+    out = {}
+    g = synth.g_object(P, seed=0, K=K, init_opacity=init_opacity)
+    cams = synth.object_cameras(8, H, W)
+    gi_np, gda_np = synth.upstream_grads(H, W, seed=0)
+
+    def one(c, omp):
+        v = CO.make_view(P, K, D, H, W, c.tanfovx, c.tanfovy, [1.0, 1.0, 1.0], c.world_view_transform,
+                         c.full_proj_transform, c.camera_center)
+        t0 = time.perf_counter()
+        f = CO.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"], omp=omp)
+        CO.backward(v, f, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"], omp=omp)
+        return time.perf_counter() - t0
+    one(cams[0], True)                                  # warm-up (thread pool, page faults)
+    n_omp, dt_omp = 0, 0.0
+    for c2 in cams:
+        dt_omp += one(c2, True)
+        n_omp += 1
+        if dt_omp > budget_s:
+            break
+    out["omp"] = {"value": round(n_omp / dt_omp, 5), "threads": CO.threads(True), "views": n_omp, "seconds": round(dt_omp, 1)}
+    print("CPU_LEG " + json.dumps(out), flush=True)     # (printed as soon as it exists: the torch legs may be cut off)
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    for name, (p_, r_, n_, b_) in (("C1", (10_000, 256, 3, 6.0)), ("C2", (100_000, 512, 1, 20.0))):
+        try:
+            out.setdefault("torch", {})[name] = _torch_cpu_leg(p_, r_, n_, b_)
+        except Exception as e:      # (a baseline, not a gate)
+            out.setdefault("torch", {})[name] = {"error": repr(e)}
+        print("CPU_LEG " + json.dumps(out), flush=True)
+
+
+def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), init_opacity=False, timeout_s=120):
+    """The CPU path timed beside the GPU numbers, on a bounded sample, host core count stated.
     The reference has NO CPU path for the rasterizer, so the baselines are this repo's CPU restatements:
       * `value`: the C port of the same algorithm (oracle/gsr_oracle.c, OpenMP build) on ALL host cores, on views of the
         SAME workload as `value` of the bench line -- kind "port";
       * `single_thread`: the scalar build of the same file (the parity checker), one thread; its first view also yields the
         HIP path's max gradient error at the full benchmark size;
-      * `torch_all_cores`: the PyTorch-CPU oracle, torch.set_num_threads(all cores), at C1 (10 k @256^2) and C2 (100 k @512^2)."""
+      * `torch_all_cores`: the PyTorch-CPU oracle, torch.set_num_threads(all cores), at C1 (10 k @256^2) and C2 (100 k @512^2).
+    The all-core legs run in a subprocess under a hard timeout (a baseline must not be able to stall the bench line)."""
+    import subprocess
     from oracle import c_oracle as CO
     CO.build()
     P = g["means3D"].shape[0]
-    mk = lambda c: CO.make_view(P, K, D, H, W, c.tanfovx, c.tanfovy, [1.0, 1.0, 1.0], c.world_view_transform,
-                                c.full_proj_transform, c.camera_center)
-
-    def one(c, omp):
-        v = mk(c)
-        t0 = time.perf_counter()
-        f = CO.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"], omp=omp)
-        b = CO.backward(v, f, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
-                        omp=omp)
-        return f, b, time.perf_counter() - t0
-    f, b, dt1 = one(cam, False)                     # scalar, one thread: the checker (and the single-thread figure)
-    one(cam, True)                                  # all cores: warm-up (thread pool, page faults)
-    n_omp, dt_omp = 0, 0.0
-    for c2 in [cam] + list(extra_cams):
-        dt_omp += one(c2, True)[2]
-        n_omp += 1
-        if dt_omp > 8.0:
-            break
+    v = CO.make_view(P, K, D, H, W, cam.tanfovx, cam.tanfovy, [1.0, 1.0, 1.0], cam.world_view_transform,
+                     cam.full_proj_transform, cam.camera_center)
+    t0 = time.perf_counter()
+    f = CO.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    b = CO.backward(v, f, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    dt1 = time.perf_counter() - t0                  # scalar, one thread: the checker (and the single-thread figure)
     cores = os.cpu_count()
-    torch.set_num_threads(cores)
-    torch_legs = {}
+    legs, note = {}, ""
     try:
-        torch_legs["C1"] = _torch_cpu_leg(10_000, 256, 3, 6.0)
-        torch_legs["C2"] = _torch_cpu_leg(100_000, 512, 1, 20.0)
-    except Exception as e:      # (a baseline, not a gate)
-        torch_legs["error"] = repr(e)
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-legs", json.dumps([P, K, D, H, W, bool(init_opacity), 8.0])]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        txt = r.stdout
+    except subprocess.TimeoutExpired as e:
+        txt = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        note = f"; the all-core legs were cut off after {timeout_s} s (what had finished is reported)"
+    for line in txt.splitlines():
+        if line.startswith("CPU_LEG "):
+            legs = json.loads(line[len("CPU_LEG "):])
     img, da, radii, grads = hip_out
     names = ["dL_dmeans3D", "dL_dshs", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]
     worst, worst_frac, per = 0.0, 0.0, {}
@@ -447,13 +477,18 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), 
         worst_frac = max(worst_frac, per[n]["frac_over_1e-5"])
     d_img = np.abs(img.detach().cpu().numpy() - f["image"]).max(axis=0)
     what = f"{P} Gaussians @{W}x{H}, orbit cameras{', all opacities 0.1' if init_opacity else ''}"
-    base = {"value": round(n_omp / dt_omp, 5), "unit": "views/s", "cores": CO.threads(True), "kind": "port",
-            "sample": f"{n_omp} fwd+bwd views of the same workload ({what}) through oracle/gsr_oracle.c built with OpenMP "
-                      f"({CO.threads(True)} threads), {dt_omp:.1f} s; host has {cores} cores",
-            "single_thread": {"value": round(1.0 / dt1, 5), "unit": "views/s", "cores": 1,
-                              "sample": f"1 fwd+bwd view of the same workload, scalar build, {dt1:.1f} s"},
-            "torch_all_cores": dict(torch_legs, cores=cores,
-                                    note="PyTorch-CPU oracle (oracle/torch_oracle.py), fp32, torch.set_num_threads(all cores)")}
+    single = {"value": round(1.0 / dt1, 5), "unit": "views/s", "cores": 1,
+              "sample": f"1 fwd+bwd view of the same workload, scalar build of oracle/gsr_oracle.c, {dt1:.1f} s"}
+    if "omp" in legs:
+        o = legs["omp"]
+        base = {"value": o["value"], "unit": "views/s", "cores": o["threads"], "kind": "port",
+                "sample": f"{o['views']} fwd+bwd views of the same workload ({what}) through oracle/gsr_oracle.c built with "
+                          f"OpenMP ({o['threads']} threads), {o['seconds']} s; host has {cores} cores{note}"}
+    else:
+        base = dict(single, kind="port", sample=single["sample"] + f"; host has {cores} cores{note}")
+    base["single_thread"] = single
+    base["torch_all_cores"] = dict(legs.get("torch", {}), cores=cores,
+                                   note="PyTorch-CPU oracle (oracle/torch_oracle.py), fp32, torch.set_num_threads(all cores)")
     return base, {"bit_exact_radii": bool(np.array_equal(radii.cpu().numpy(), f["radii"])),
                   "image_max_abs": float(d_img.max()), "image_frac_pixels_over_1e-5": float((d_img > 1e-5).mean()),
                   "grads_max_err_over_max1": worst, "grads_max_frac_entries_over_1e-5": worst_frac,
@@ -461,4 +496,7 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), 
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-legs":
+        _cpu_legs_child(*json.loads(sys.argv[2]))
+    else:
+        main()
