@@ -258,6 +258,15 @@ def main():
         sync()
         dropin = {"views_per_s": world * n_drop * V / (time.perf_counter() - td), "steps": n_drop}
 
+    # what the exchange would have to move for this rank's step (the arena holds the sum over the step's V views)
+    exch = None
+    if exchange is not None:
+        step()
+        torch.cuda.synchronize(dev)
+        nz = int(exchange.nonzero_rows().numel())
+        exch = {"row_floats": exchange.row_floats, "dense_bytes": int(4 * exchange.row_floats * P),
+                "nonzero_row_frac": round(nz / max(P, 1), 4), "last": exchange.last or None}
+
     N_pairs = None
     roofline = None
     if prof is not None:
@@ -364,6 +373,7 @@ def main():
                                       f"all-reduce of {arena.nbytes()} B per step" if world > 1 else
                                       f"single GPU, {V} view(s) per step, gradients summed on the device"},
             "roofline": roofline,
+            "exchange": exch,
             "cpu_baseline": cpu_baseline,
             "max_grad_err_vs_oracle": grad_err,
         }
@@ -398,43 +408,57 @@ def _torch_cpu_leg(P, res, n_views, budget_s):
             "config": f"{P} Gaussians @{res}x{res}, K=16, SH degree 3"}
 
 
-def _cpu_legs_child(P, K, D, H, W, init_opacity, budget_s):
-    """Runs in a SUBPROCESS (python bench.py --cpu-legs ...) under a hard timeout: the all-core CPU figures. A CPU leg
-    must never be able to stall the bench line (256-thread OpenMP / torch thread pools on an unknown host)."""
+def _cpu_legs_child(leg, P, K, D, H, W, init_opacity, budget_s, threads):
+    """Runs in a SUBPROCESS (python bench.py --cpu-legs ...) under a hard timeout: one all-core CPU figure per process.
+    A CPU leg must never be able to stall the bench line (256-thread OpenMP / torch thread pools on an unknown host)."""
     from dreamscene_amd import synth
-    from oracle import c_oracle as CO
-    out = {}
-    g = synth.g_object(P, seed=0, K=K, init_opacity=init_opacity)
-    cams = synth.object_cameras(8, H, W)
-    gi_np, gda_np = synth.upstream_grads(H, W, seed=0)
+    if leg == "omp":
+        from oracle import c_oracle as CO
+        g = synth.g_object(P, seed=0, K=K, init_opacity=init_opacity)
+        cams = synth.object_cameras(8, H, W)
+        gi_np, gda_np = synth.upstream_grads(H, W, seed=0)
 
-    def one(c, omp):
-        v = CO.make_view(P, K, D, H, W, c.tanfovx, c.tanfovy, [1.0, 1.0, 1.0], c.world_view_transform,
-                         c.full_proj_transform, c.camera_center)
-        t0 = time.perf_counter()
-        f = CO.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"], omp=omp)
-        CO.backward(v, f, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"], omp=omp)
-        return time.perf_counter() - t0
-    one(cams[0], True)                                  # warm-up (thread pool, page faults)
-    n_omp, dt_omp = 0, 0.0
-    for c2 in cams:
-        dt_omp += one(c2, True)
-        n_omp += 1
-        if dt_omp > budget_s:
-            break
-    out["omp"] = {"value": round(n_omp / dt_omp, 5), "threads": CO.threads(True), "views": n_omp, "seconds": round(dt_omp, 1)}
-    print("CPU_LEG " + json.dumps(out), flush=True)     # (printed as soon as it exists: the torch legs may be cut off)
-    cores = os.cpu_count()
-    torch.set_num_threads(cores)
+        def one(c):
+            v = CO.make_view(P, K, D, H, W, c.tanfovx, c.tanfovy, [1.0, 1.0, 1.0], c.world_view_transform,
+                             c.full_proj_transform, c.camera_center)
+            t0 = time.perf_counter()
+            f = CO.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"], omp=True)
+            CO.backward(v, f, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"], omp=True)
+            return time.perf_counter() - t0
+        one(cams[0])                                        # warm-up (thread pool, page faults)
+        n_omp, dt_omp = 0, 0.0
+        for c2 in cams:
+            dt_omp += one(c2)
+            n_omp += 1
+            if dt_omp > budget_s:
+                break
+        print("CPU_LEG " + json.dumps({"value": round(n_omp / dt_omp, 5), "threads": CO.threads(True), "views": n_omp,
+                                       "seconds": round(dt_omp, 1)}), flush=True)
+        return
+    torch.set_num_threads(int(threads))
+    out = {"threads": int(threads)}
     for name, (p_, r_, n_, b_) in (("C1", (10_000, 256, 3, 6.0)), ("C2", (100_000, 512, 1, 20.0))):
-        try:
-            out.setdefault("torch", {})[name] = _torch_cpu_leg(p_, r_, n_, b_)
-        except Exception as e:      # (a baseline, not a gate)
-            out.setdefault("torch", {})[name] = {"error": repr(e)}
-        print("CPU_LEG " + json.dumps(out), flush=True)
+        out[name] = _torch_cpu_leg(p_, r_, n_, b_)
+        print("CPU_LEG " + json.dumps(out), flush=True)     # (printed as it grows: a slow C2 may be cut off)
 
 
-def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), init_opacity=False, timeout_s=120):
+def _run_cpu_leg(args, timeout_s):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-legs", json.dumps(args)]
+    note = None
+    try:
+        txt = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT).stdout
+    except subprocess.TimeoutExpired as e:
+        txt = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        note = f"cut off after {timeout_s} s"
+    res = None
+    for line in txt.splitlines():
+        if line.startswith("CPU_LEG "):
+            res = json.loads(line[len("CPU_LEG "):])
+    return res, note
+
+
+def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), init_opacity=False):
     """The CPU path timed beside the GPU numbers, on a bounded sample, host core count stated.
     The reference has NO CPU path for the rasterizer, so the baselines are this repo's CPU restatements:
       * `value`: the C port of the same algorithm (oracle/gsr_oracle.c, OpenMP build) on ALL host cores, on views of the
@@ -443,7 +467,6 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), 
         HIP path's max gradient error at the full benchmark size;
       * `torch_all_cores`: the PyTorch-CPU oracle, torch.set_num_threads(all cores), at C1 (10 k @256^2) and C2 (100 k @512^2).
     The all-core legs run in a subprocess under a hard timeout (a baseline must not be able to stall the bench line)."""
-    import subprocess
     from oracle import c_oracle as CO
     CO.build()
     P = g["means3D"].shape[0]
@@ -454,17 +477,16 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), 
     b = CO.backward(v, f, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
     dt1 = time.perf_counter() - t0                  # scalar, one thread: the checker (and the single-thread figure)
     cores = os.cpu_count()
-    legs, note = {}, ""
-    try:
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-legs", json.dumps([P, K, D, H, W, bool(init_opacity), 8.0])]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
-        txt = r.stdout
-    except subprocess.TimeoutExpired as e:
-        txt = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
-        note = f"; the all-core legs were cut off after {timeout_s} s (what had finished is reported)"
-    for line in txt.splitlines():
-        if line.startswith("CPU_LEG "):
-            legs = json.loads(line[len("CPU_LEG "):])
+    omp, omp_note = _run_cpu_leg(["omp", P, K, D, H, W, bool(init_opacity), 8.0, 0], 75)
+    # the PyTorch-CPU oracle with every host core -- thread pools of hundreds of threads can make
+    # its many small ops crawl, so the same is also run with 32 threads; each under its own hard timeout
+    t_all, t_all_note = _run_cpu_leg(["torch", 0, 0, 0, 0, 0, False, 0.0, cores], 50)
+    t_32, t_32_note = (None, None) if cores <= 32 else _run_cpu_leg(["torch", 0, 0, 0, 0, 0, False, 0.0, 32], 60)
+    note = f"; all-core C leg {omp_note}" if omp_note else ""
+    legs = {"omp": omp} if omp else {}
+    torch_legs = {"all_cores": dict(t_all or {}, threads=cores, **({"note": t_all_note} if t_all_note else {}))}
+    if cores > 32:
+        torch_legs["threads_32"] = dict(t_32 or {}, threads=32, **({"note": t_32_note} if t_32_note else {}))
     img, da, radii, grads = hip_out
     names = ["dL_dmeans3D", "dL_dshs", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]
     worst, worst_frac, per = 0.0, 0.0, {}
@@ -487,8 +509,9 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), 
     else:
         base = dict(single, kind="port", sample=single["sample"] + f"; host has {cores} cores{note}")
     base["single_thread"] = single
-    base["torch_all_cores"] = dict(legs.get("torch", {}), cores=cores,
-                                   note="PyTorch-CPU oracle (oracle/torch_oracle.py), fp32, torch.set_num_threads(all cores)")
+    base["torch_all_cores"] = dict(torch_legs, cores=cores,
+                                   note="PyTorch-CPU oracle (oracle/torch_oracle.py), fp32, fwd+bwd views/s at C1 = 10 k @256^2 and "
+                                        "C2 = 100 k @512^2; torch.set_num_threads(all cores) and, on big hosts, 32 threads")
     return base, {"bit_exact_radii": bool(np.array_equal(radii.cpu().numpy(), f["radii"])),
                   "image_max_abs": float(d_img.max()), "image_frac_pixels_over_1e-5": float((d_img > 1e-5).mean()),
                   "grads_max_err_over_max1": worst, "grads_max_frac_entries_over_1e-5": worst_frac,

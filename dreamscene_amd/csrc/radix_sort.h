@@ -242,7 +242,23 @@ __device__ __forceinline__ DigitCfg ranged_cfg(const uint32_t* __restrict__ rang
 __device__ __forceinline__ uint32_t ranged_digit(const DigitCfg& c, uint32_t key) {
   return ((key - c.base) >> c.shift) & ((1u << c.w) - 1u);
 }
+template <int NB>
+__device__ __forceinline__ unsigned long long match_bits_n(uint32_t d, bool valid) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+// lanes of the wave holding the same nbits-bit digit (among `valid` lanes); nbits is wave-uniform: the usual widths get
+// their unrolled ballot chains, anything else a loop
 __device__ __forceinline__ unsigned long long match_bits(uint32_t d, bool valid, int nbits) {
+  if (nbits == 8) return match_bits_n<8>(d, valid);
+  if (nbits == 9) return match_bits_n<9>(d, valid);
+  if (nbits == 7) return match_bits_n<7>(d, valid);
   unsigned long long m = __ballot(valid);
   for (int b = 0; b < nbits; ++b) {
     const bool bit = (d >> b) & 1u;
@@ -319,11 +335,12 @@ k_rsort_scan(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ 
              const uint32_t* __restrict__ range, size_t bstride) {
   hist = batch_ptr(hist, bstride); totals = batch_ptr(totals, bstride); range = batch_ptr(range, bstride);
   const DigitCfg cfg = ranged_cfg(range, 0);
-  if ((int)blockIdx.x >= (1 << cfg.w)) return;
   __shared__ uint32_t wave_tot[4];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t* row = hist + (uint64_t)blockIdx.x * nblk;
+  for (int r = (int)blockIdx.x; r < (1 << cfg.w); r += (int)gridDim.x) {
+  uint32_t* row = hist + (uint64_t)r * nblk;
+  __syncthreads();
   if (tid == 0) carry_s = 0;
   __syncthreads();
   constexpr uint32_t kPer = 4;
@@ -357,7 +374,8 @@ k_rsort_scan(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ 
     if (tid == 255) carry_s = carry + woff + inc;
     __syncthreads();
   }
-  if (tid == 0) totals[blockIdx.x] = carry_s;
+  if (tid == 0) totals[r] = carry_s;
+  }
 }
 
 // IOTA: values are the element indices (first pass); DROP: the sentinel keys are not written and *n_out = survivors.
@@ -523,7 +541,7 @@ template <int ITEMS>
 void ranged_sort_iota_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint64_t cap, uint64_t* n_compact,
                           uint32_t* range, uint32_t* hist, uint32_t* totals, hipStream_t stream, int batch, size_t bstride) {
   const uint32_t nblk = sort_blocks(cap, ITEMS);
-  const dim3 grid(nblk, (uint32_t)batch), grid_scan(kMaxBins, (uint32_t)batch);
+  const dim3 grid(nblk, (uint32_t)batch), grid_scan(256, (uint32_t)batch);   // (a row-workgroup takes rows r, r + 256, ...)
   hipLaunchKernelGGL(k_key_range, dim3(kRangeGroups, (uint32_t)batch), dim3(256), 0, stream, k0, cap, range, bstride);
   // pass 0: k0 -> k1 (drops the sentinels, values = indices); pass 1: k1 -> k0; pass 2: k0 -> k1
   hipLaunchKernelGGL((k_rsort_hist<ITEMS, true>), grid, dim3(kSortThreads), 0, stream, k0, (const uint64_t*)nullptr, cap,

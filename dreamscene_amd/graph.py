@@ -130,7 +130,7 @@ class CapturedViews(torch.nn.Module):
             if self._warm < WARM_CALLS or int(means3D.shape[0]) == 0:
                 self._warm += 1
                 return self._eager_forward(settings_list, means3D, opacities, shs, scales, rotations, rc)
-            cap = self._capture(sig, settings_list, means3D, opacities, shs, scales, rotations, rc, per_view)
+            self._cap = cap = self._capture(sig, settings_list, means3D, opacities, shs, scales, rotations, rc, per_view)
         lib = L.load()
         V = len(settings_list)
         stream = torch.cuda.current_stream(dev)

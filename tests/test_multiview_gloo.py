@@ -139,7 +139,8 @@ def _exchange_worker(rank, world, port, P, K, D, row_frac, mode, out_dir):
 
 @pytest.mark.parametrize("D,row_frac,mode,expect", [(3, 1.0, "auto", "dense"), (0, 1.0, "auto", "dense"),
                                                     (1, 0.9, "dense", "dense"), (3, 0.05, "auto", "rows"),
-                                                    (0, 0.05, "rows", "rows"), (2, 0.0, "auto", "rows")])
+                                                    (0, 0.05, "rows", "rows"), (2, 0.0, "auto", "rows"),
+                                                    (3, 1.0, "direct", "direct"), (1, 0.5, "direct", "direct")])
 def test_grad_exchange_formats_equal_plain_sum(tmp_path, D, row_frac, mode, expect):
     """Active-degree columns only / non-zero rows only on the wire: the arena ends up with exactly the sum a plain dense
     all-reduce of everything would give, identical on both ranks."""
@@ -153,7 +154,7 @@ def test_grad_exchange_formats_equal_plain_sum(tmp_path, D, row_frac, mode, expe
     assert np.array_equal(r0["flat"], ref), np.abs(r0["flat"] - ref).max()      # two addends: the sum is exact either way
     F = 11 + 3 * (D + 1) ** 2
     dense_full = 2 * (world - 1) / world * 4 * (11 + 3 * K) * P
-    if expect == "dense":
+    if expect in ("dense", "direct"):
         assert int(r0["nbytes"]) <= 2 * (world - 1) / world * 4 * (F * P + 16)       # active columns only (+ alignment pad)
     else:
         assert int(r0["nbytes"]) < 0.25 * dense_full or row_frac == 0.0
