@@ -394,7 +394,7 @@ static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom
 static int backward_render(const GsrView* v, const GsrGeom* geom, const GsrBinning* b, const GsrImages* img,
                            const GsrImageGrads* ig, GsrGrads* out, hipStream_t stream, GsrProfile* prof,
                            bool clear_partials = true) {
-  if (clear_partials) GSR_HIP(hipMemsetAsync(out->partials, 0, (size_t)v->P * 12 * sizeof(float), stream));
+  if (clear_partials) GSR_HIP(gsr_zero_async(out->partials, (size_t)v->P * 12 * sizeof(float), stream));
   return gsr_launch_render_bwd(*v, *geom, *b, *img, *ig, *out, stream, prof);
 }
 
@@ -448,7 +448,7 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   bool contiguous = true;
   for (int k = 1; k < n_views; ++k)
     contiguous = contiguous && ((char*)outs[k].partials == (char*)outs[0].partials + (size_t)k * pbytes);
-  if (contiguous) GSR_HIP(hipMemsetAsync(outs[0].partials, 0, pbytes * (size_t)n_views, stream));
+  if (contiguous) GSR_HIP(gsr_zero_async(outs[0].partials, pbytes * (size_t)n_views, stream));
   {
     const int rc = gsr_launch_work_order_bwd(n_views, views, bs, imgs, stream);   // all views' work lists in one launch
     if (rc) return rc;
@@ -456,7 +456,7 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   if (fused) {
     // K7 of all views in one launch
     if (!contiguous)
-      for (int k = 0; k < n_views; ++k) GSR_HIP(hipMemsetAsync(outs[k].partials, 0, pbytes, stream));
+      for (int k = 0; k < n_views; ++k) GSR_HIP(gsr_zero_async(outs[k].partials, pbytes, stream));
     const int rc = gsr_launch_render_bwd_views(n_views, views, geoms, bs, imgs, igs, outs, stream, prof);
     if (rc) return rc;
   } else {

@@ -26,6 +26,9 @@
 // "Capacity mode": the pair count N is data dependent. Every N-sized kernel takes the true count from device
 // memory and clamps it to the capacity of the caller's buffers, so the whole forward can be enqueued without a
 // host round trip; the host checks N against the capacity afterwards (gsrast.h, gsr_forward_render).
+#include <cstdlib>
+#include <cstring>
+
 #include "gsr_common.h"
 #include "radix_sort.h"
 
@@ -570,15 +573,21 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
   uint64_t* n_vis_dev = s.counts + 1;
   const bool columns = use_columns(v.image_height, v.image_width, v.P);
   if (batch > 1 && !columns) return GSR_EINVAL;
-  const int where = 1;      // three ranged passes: the result is in (k1, v1) whatever the input
+  // GSR_DEPTH_SORT=lsd4 (environment, read once): the four fixed 8-bit passes instead of the three ranged ones (A/B)
+  static const bool lsd4 = [] { const char* e = getenv("GSR_DEPTH_SORT"); return e && !strcmp(e, "lsd4"); }();
+  int where = 1;            // three ranged passes: the result is in (k1, v1) whatever the input
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    uint32_t* range = reinterpret_cast<uint32_t*>(s.counts + 2);
-    if (batch > 1) GSR_HIP(hipMemset2DAsync(range, bstride, 0, 2 * sizeof(uint32_t), (size_t)batch, stream));
-    else GSR_HIP(hipMemsetAsync(range, 0, 2 * sizeof(uint32_t), stream));
-    ranged_sort_iota_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, (uint64_t)P, n_vis_dev, range, s.hist, s.totals, stream, batch,
-                                      bstride);
-    geom.sorted_idx = s.v1;
+    if (lsd4) {
+      where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
+                                          s.totals, stream, batch, bstride);
+    } else {
+      uint32_t* range = reinterpret_cast<uint32_t*>(s.counts + 2);
+      GSR_HIP(gsr_zero_async(range, 2 * sizeof(uint32_t), stream, bstride, (uint32_t)batch));   // (one word pair per view)
+      ranged_sort_iota_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, (uint64_t)P, n_vis_dev, range, s.hist, s.totals, stream,
+                                        batch, bstride);
+    }
+    geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }
   {
@@ -680,7 +689,7 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
                        const uint64_t* n_dev_vis, GsrBinning& b, hipStream_t stream, GsrProfile* prof) {
   const uint32_t tiles = gsr_num_tiles(v.image_height, v.image_width);
   if (cap == 0 || v.P == 0) {
-    GSR_HIP(hipMemsetAsync(b.ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), stream));
+    GSR_HIP(gsr_zero_async(b.ranges, (size_t)tiles * 2 * sizeof(uint32_t), stream));
     return GSR_OK;
   }
   if (b.scratch_bytes < gsr_sort_scratch_bytes(cap, tiles) || !b.scratch) return GSR_ESCRATCH;

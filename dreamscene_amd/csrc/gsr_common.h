@@ -80,6 +80,35 @@ struct GsrStageTimer {
   ~GsrStageTimer() { stop(); }
 };
 
+// ---- clearing device memory with a KERNEL, never hipMemsetAsync: a captured step (hipGraph) whose first node is a memset
+// node was observed to start before the work enqueued ahead of the graph launch had finished (ROCm 7.2: the backward
+// graph ran into the tail of the forward's compositing kernel; tests/test_graph.py). Plain kernel nodes keep stream order.
+namespace {
+__global__ void __launch_bounds__(256) k_gsr_zero16(uint4* __restrict__ p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+// `rows` blocks of `words` 32-bit words, `pitch` bytes apart (any 4-byte alignment)
+__global__ void __launch_bounds__(256) k_gsr_zero_words(uint32_t* __restrict__ p, size_t pitch, uint32_t words) {
+  uint32_t* row = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(p) + (size_t)blockIdx.y * pitch);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) row[i] = 0u;
+}
+}  // namespace
+// bytes: a multiple of 4. 16-byte aligned regions of a multiple of 16 bytes go through 16-byte stores.
+static inline hipError_t gsr_zero_async(void* p, size_t bytes, hipStream_t stream, size_t pitch = 0, uint32_t rows = 1) {
+  if (bytes == 0 || rows == 0) return hipSuccess;
+  if (rows == 1 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (bytes & 15u) == 0) {
+    const size_t n16 = bytes / 16;
+    const uint32_t grid = (uint32_t)((n16 + 255) / 256 < 8192 ? (n16 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_gsr_zero16, dim3(grid), dim3(256), 0, stream, reinterpret_cast<uint4*>(p), n16);
+  } else {
+    const uint32_t words = (uint32_t)(bytes / 4);
+    const uint32_t gx = (words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024;
+    hipLaunchKernelGGL(k_gsr_zero_words, dim3(gx, rows), dim3(256), 0, stream, reinterpret_cast<uint32_t*>(p), pitch, words);
+  }
+  return hipGetLastError();
+}
+
 // float -> int32: truncating, saturating, NaN -> 0 (SEMANTICS.md; identical to the C oracle's f2i_sat).
 __device__ __forceinline__ int32_t gsr_f2i_sat(float x) {
   if (!(x == x)) return 0;

@@ -194,7 +194,7 @@ extern "C" int gsr_knn_mean_dist2(const float* points, int32_t n, float* out, vo
   // the device recomputes R the same way from n (cbrtf): keep one cell of slack per axis for rounding
   const size_t cells = (size_t)std::min<uint64_t>((uint64_t)(R + 1) * (R + 1) * (R + 1), (uint64_t)kMaxR * kMaxR * kMaxR);
   hipLaunchKernelGGL(k_knn_init, dim3(1), dim3(64), 0, stream, bbox);   // (min, max) sentinels: no host->device copy
-  GSR_HIP(hipMemsetAsync(ranges, 0, cells * 8, stream));
+  GSR_HIP(gsr_zero_async(ranges, cells * 8, stream));
   const int nb = (n + 255) / 256;
   hipLaunchKernelGGL(k_knn_bbox, dim3(std::min(nb, 1024)), dim3(256), 0, stream, points, n, bbox);
   hipLaunchKernelGGL(k_knn_cells, dim3(nb), dim3(256), 0, stream, points, n, bbox, k0);

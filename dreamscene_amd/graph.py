@@ -38,6 +38,7 @@ from . import rasterizer as R
 from . import views as VW
 
 WARM_CALLS = 2          # eager calls (they learn the pair counts) before the first capture
+MAX_DIRECT_GRAPHS = 4   # backward graphs captured over callers' gradient addresses (beyond that: copy + the static one)
 
 
 class _Captured:
@@ -242,23 +243,37 @@ class CapturedViews(torch.nn.Module):
         return cap
 
     def _capture_backward(self, cap: _Captured, rc, per_view):
+        """Graph C over the static upstream-gradient buffers (the fallback every call can use after one copy)."""
         dev = cap.g_color.device
-        V = cap.V
         with torch.cuda.device(dev):
             # run it once eagerly: allocates the result tensors (kept as the static ones) and validates the arguments
             o = R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
                                                accumulate=rc.accumulate, stats=None, per_view_scales=per_view)
             torch.cuda.synchronize(dev)
-            cap.bwd_args = None
-
-            def launch(stream_ptr):
-                return R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
-                                                      accumulate=rc.accumulate, stats=rc.densify_stats,
-                                                      stats_views=rc.stats_views, per_view_scales=per_view,
-                                                      reuse=o)
             with torch.cuda.graph(cap.gC, pool=cap.gA.pool(), capture_error_mode="thread_local"):
-                launch(None)
+                R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
+                                               accumulate=rc.accumulate, stats=rc.densify_stats, stats_views=rc.stats_views,
+                                               per_view_scales=per_view, reuse=o)
             cap.bwd = o
+            cap.direct = {}          # upstream-gradient addresses -> graph C reading the caller's tensors directly
+
+    def _direct_graph(self, cap: _Captured, gcs, gdas, rc, per_view):
+        """A loss written in torch produces its gradients at the same addresses step after step (the caching allocator
+        returns the blocks it was just given back), so graph C is also captured over the CALLER'S gradient tensors: when
+        the addresses repeat nothing is copied (80 MB per 4-view step at 1024^2). The tensors are only read while the
+        backward that received them runs (stream order), exactly like the eager path reads them."""
+        key = tuple(t.data_ptr() for t in gcs + gdas)
+        g = cap.direct.get(key)
+        if g is None and len(cap.direct) < MAX_DIRECT_GRAPHS:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(cap.g_color.device)
+            with torch.cuda.graph(g, pool=cap.gA.pool(), capture_error_mode="thread_local"):
+                R.rasterize_backward_views_raw(cap.states, gcs, gdas, arena=rc.grad_arena, accumulate=rc.accumulate,
+                                               stats=rc.densify_stats, stats_views=rc.stats_views,
+                                               per_view_scales=per_view, reuse=cap.bwd)
+            cap.direct[key] = g
+            self.stats["captures_bwd_direct"] = self.stats.get("captures_bwd_direct", 0) + 1
+        return g
 
     def _backward(self, cap: Optional[_Captured], eager_states, grads, rc, per_view):
         V = len(grads) // 3
@@ -275,9 +290,17 @@ class CapturedViews(torch.nn.Module):
         with torch.cuda.device(dev):
             if cap.bwd is None:
                 self._capture_backward(cap, rc, per_view)
+            gcs = [grads[3 * k] for k in range(V)]
+            gdas = [grads[3 * k + 2] for k in range(V)]
+            usable = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() % 4 == 0
+                         for g in gcs + gdas)
+            g_direct = self._direct_graph(cap, gcs, gdas, rc, per_view) if usable else None
+            if g_direct is not None:
+                g_direct.replay()
+                return cap.bwd
             dst, src = [], []
             for k in range(V):
-                for buf, g in ((cap.g_color[k], grads[3 * k]), (cap.g_da[k], grads[3 * k + 2])):
+                for buf, g in ((cap.g_color[k], gcs[k]), (cap.g_da[k], gdas[k])):
                     if g is None:
                         buf.zero_()
                     elif g.data_ptr() != buf.data_ptr():

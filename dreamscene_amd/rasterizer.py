@@ -543,8 +543,8 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
     lib = L.load()
     dev, P, K = st.dev, st.P, st.K
     _check_versions(st)
-    dL_dcolor = _prep(dL_dcolor, "dL_dcolor", dev)
-    dL_ddepth_alpha = _prep(dL_ddepth_alpha, "dL_ddepth_alpha", dev)
+    dL_dcolor = _prep(dL_dcolor, "dL_dcolor", dev, align=4)           # (read pixel by pixel: no 16-byte requirement)
+    dL_ddepth_alpha = _prep(dL_ddepth_alpha, "dL_ddepth_alpha", dev, align=4)
     if st.scene is not None:
         return _backward_scene(st, dL_dcolor, dL_ddepth_alpha, cam_grads, model_grads, accumulate, dL_dscales_out,
                                stats, profile)
@@ -613,7 +613,7 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
     keep = []
     counted = _stat_views(V, stats, stats_views)
     for k in range(V):
-        gc, gda = _prep(dL_dcolors[k], "dL_dcolor", dev), _prep(dL_ddepth_alphas[k], "dL_ddepth_alpha", dev)
+        gc, gda = _prep(dL_dcolors[k], "dL_dcolor", dev, align=4), _prep(dL_ddepth_alphas[k], "dL_ddepth_alpha", dev, align=4)
         gso = _prep(dL_dscales_outs[k], "dL_dscales_out", dev) if dL_dscales_outs is not None else None
         keep += [gc, gda, gso]
         igs[k].dL_dcolor, igs[k].dL_ddepth_alpha = gc.data_ptr(), gda.data_ptr()
@@ -686,7 +686,7 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
     keep = []
     counted = _stat_views(V, stats, stats_views)
     for k in range(V):
-        gc, gda = _prep(dL_dcolors[k], "dL_dcolor", dev), _prep(dL_ddepth_alphas[k], "dL_ddepth_alpha", dev)
+        gc, gda = _prep(dL_dcolors[k], "dL_dcolor", dev, align=4), _prep(dL_ddepth_alphas[k], "dL_ddepth_alpha", dev, align=4)
         keep += [gc, gda]
         igs[k].dL_dcolor, igs[k].dL_ddepth_alpha = gc.data_ptr(), gda.data_ptr()
         for name, t in o.items():

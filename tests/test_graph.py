@@ -31,10 +31,14 @@ def _eager(sets, t, gis, gdas, scales=None):
     return [(a.clone(), b.clone(), c.clone()) for a, b, c in outs], [x.clone() for x in grads]
 
 
-@pytest.mark.parametrize("V,K,D", [(4, 16, 3), (1, 4, 1), (3, 9, 2)])
-def test_captured_step_equals_eager_and_follows_the_cameras(built_lib, V, K, D):
-    from dreamscene_amd import synth
+@pytest.mark.parametrize("V,K,D,direct", [(4, 16, 3, True), (1, 4, 1, True), (3, 9, 2, False), (4, 16, 3, False)])
+def test_captured_step_equals_eager_and_follows_the_cameras(built_lib, monkeypatch, V, K, D, direct):
+    """direct: the backward graph reads the caller's gradient tensors (their addresses repeat); not direct: the gradients
+    are copied into the module's static buffers first (what happens when the addresses keep changing)."""
+    from dreamscene_amd import graph, synth
     from dreamscene_amd.graph import CapturedViews
+    if not direct:
+        monkeypatch.setattr(graph, "MAX_DIRECT_GRAPHS", 0)
     P, H, W = 3000, 112, 144
     g, t = _setup(P, H, W, K)
     leaves = [t[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
