@@ -77,9 +77,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fwd-mode", type=int, default=None, help="force the forward compositing variant (0 / 1)")
-    ap.add_argument("--no-capture", action="store_true",
-                    help="batched call without graph capture: every step's ~45 launches are issued from Python "
-                         "(GaussianRasterizerViews) instead of replayed from captured hipGraphs (graph.CapturedViews)")
+    ap.add_argument("--capture", choices=["auto", "on", "off"], default="auto",
+                    help="batched call: replay the step's launches from captured hipGraphs (graph.CapturedViews: 2 graph "
+                         "launches per step) or issue its ~45 launches from Python (GaussianRasterizerViews). auto = time "
+                         "both for a few steps after the warm-up and keep the faster one (big workloads are GPU-bound either "
+                         "way and lose ~1 %% to graph boundaries; small ones are host-bound without graphs)")
+    ap.add_argument("--no-capture", action="store_true", help="same as --capture off")
     ap.add_argument("--unbatched", action="store_true",
                     help="render the views of a step one call at a time (GaussianRasterizer) instead of through "
                          "GaussianRasterizerViews (same kernels; the depth sorts of all views share their launches)")
@@ -101,10 +104,10 @@ def main():
     H = W = args.res
     V = max(1, args.views_per_step)
     batched = V > 1 and not args.unbatched
-    captured = batched and not args.no_capture
-    how = (f"{V} views/step through ONE batched call ("
-           f"{'graph.CapturedViews: launches replayed from captured hipGraphs' if captured else 'GaussianRasterizerViews'})"
-           if batched else f"{V} views/step, one GaussianRasterizer call per view (drop-in interface)")
+    cap_mode = "off" if (args.no_capture or not batched) else args.capture
+    use_capture = [cap_mode in ("on", "auto")]       # (a cell: "auto" decides after the warm-up)
+    how = (f"{V} views/step through ONE batched call" if batched else
+           f"{V} views/step, one GaussianRasterizer call per view (drop-in interface)")
     if args.scene == "object":
         K, D = 16, args.sh_degree
         g = synth.g_object(args.gaussians, seed=0, K=K, init_opacity=args.init_opacity)
@@ -162,7 +165,7 @@ def main():
 
     def step_batched():
         means2D = torch.zeros((V,) + tuple(params["means3D"].shape), device=dev, requires_grad=True)
-        if captured and prof_holder[0] is None:      # (the stage timers record events: the profiled passes run eagerly)
+        if use_capture[0] and prof_holder[0] is None:      # (the stage timers record events: the profiled passes run eagerly)
             outs = rast_captured(settings_list, means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
                                  shs=params["shs"], scales=params["scales"], rotations=params["rotations"])
         else:
@@ -209,6 +212,26 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    capture_probe = None
+    if cap_mode == "auto":
+        rates = {}
+        for flag in (False, True):
+            use_capture[0] = flag
+            for _ in range(4):
+                step()
+            sync()
+            tp = time.perf_counter()
+            for _ in range(15):
+                step()
+            sync()
+            rates[flag] = 15 * V / (time.perf_counter() - tp)
+        if world > 1:      # every rank must take the same decision
+            tt = torch.tensor([rates[False], rates[True]], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            rates = {False: float(tt[0]), True: float(tt[1])}
+        use_capture[0] = rates[True] > rates[False]
+        capture_probe = {"eager_views_per_s": round(rates[False], 1), "captured_views_per_s": round(rates[True], 1)}
+    captured = bool(use_capture[0])
     stage_ms = {}
     dominant = None
     if prof is not None:
@@ -365,6 +388,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "gaussians": P, "resolution": [H, W], "tile_pairs_N": N_pairs,
                        "views_per_step_per_gpu": V, "batched_call": batched, "captured_graphs": captured,
+                       "batched_through": ("graph.CapturedViews (launches replayed from captured hipGraphs)" if captured else
+                                           "views.GaussianRasterizerViews (launches issued from Python)") if batched else None,
+                       "capture_mode": cap_mode, "capture_probe": capture_probe,
                        "capture_stats": dict(rast_captured.stats) if captured else None,
                        "dropin": ("`dropin_views_per_s`: the same views through one GaussianRasterizer call per view (the "
                                   f"reference's interface), {dropin['steps']} steps after the timed region") if dropin else

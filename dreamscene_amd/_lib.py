@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsrast.so")
+# GSR_LIB: an experimental build of the same library (dreamscene_amd/build.py, A/B measurements); default: the product
+LIB_PATH = os.environ.get("GSR_LIB") or os.path.join(_HERE, "libgsrast.so")
 
 STAGES = ["preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd"]
 

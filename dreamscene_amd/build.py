@@ -41,9 +41,12 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = OUT, objdir: str = None) -> str:
+    """out / objdir: an experimental variant (other flags) next to the product library, e.g.
+    build(extra_flags=["-DGSR_XCD_MAP=0"], out=".../libgsrast_noxcd.so", objdir=".../_obj_noxcd"); GSR_LIB=<path> makes
+    dreamscene_amd._lib load it instead (A/B measurements only)."""
     cc = hipcc()
-    objdir = os.path.join(HERE, "_obj")
+    objdir = objdir or os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "gsr_common.h"), os.path.join(CSRC, "radix_sort.h"),
                os.path.join(ROOT, "include", "gsrast.h"), os.path.abspath(__file__)]
@@ -67,9 +70,9 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         with ThreadPoolExecutor(max_workers=4) as ex:
             list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(OUT, objs):
-        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs)
-    return OUT
+    if force or jobs or _stale(out, objs):
+        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs)
+    return out
 
 
 if __name__ == "__main__":

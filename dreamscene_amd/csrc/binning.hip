@@ -26,9 +26,6 @@
 // "Capacity mode": the pair count N is data dependent. Every N-sized kernel takes the true count from device
 // memory and clamps it to the capacity of the caller's buffers, so the whole forward can be enqueued without a
 // host round trip; the host checks N against the capacity afterwards (gsrast.h, gsr_forward_render).
-#include <cstdlib>
-#include <cstring>
-
 #include "gsr_common.h"
 #include "radix_sort.h"
 
@@ -280,11 +277,12 @@ k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x,
   __shared__ uint32_t col_run[256];
   __shared__ uint32_t pbase[65];
   __shared__ uint32_t rs[64], ids[64], mg[64];
-  const int64_t s0 = (int64_t)blockIdx.x * kColRun;
+  const uint32_t run_id = blockIdx.x;
+  const int64_t s0 = (int64_t)run_id * kColRun;
   const int64_t nv = (int64_t)*n_vis;
   if (s0 >= nv) return;
   const int lane = threadIdx.x;
-  for (int tx = lane; tx < gx; tx += 64) col_run[tx] = colstart[tx] + hist1[(uint64_t)tx * nrun + blockIdx.x];
+  for (int tx = lane; tx < gx; tx += 64) col_run[tx] = colstart[tx] + hist1[(uint64_t)tx * nrun + run_id];
   const bool in = s0 + lane < nv;
   const uint32_t r = in ? rect_sorted[s0 + lane] : 0u;
   const uint32_t w = rect_w(r);
@@ -381,8 +379,9 @@ k_row_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ colst
   __shared__ uint32_t sh_fb[257];
   __shared__ uint32_t sh_tmp[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t blk = blockIdx.x;
   h[tid] = 0;
-  const ColBlocks cb = col_blocks(colstart, gx, cap, blockIdx.x, sh_fb, sh_tmp);
+  const ColBlocks cb = col_blocks(colstart, gx, cap, blk, sh_fb, sh_tmp);
   if (cb.base < cb.end) {
     uint32_t kv[kPass2Items];
 #pragma unroll
@@ -399,7 +398,7 @@ k_row_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ colst
     }
   }
   __syncthreads();
-  hist[(uint64_t)tid * nblk + blockIdx.x] = h[tid];
+  hist[(uint64_t)tid * nblk + blk] = h[tid];
 }
 
 // per-view outputs of the ty pass (they live in separately allocated per-view state buffers)
@@ -423,7 +422,8 @@ k_row_scatter(const uint32_t* __restrict__ vals_in, const RowOut ro, const uint3
   __shared__ uint32_t sh_fb[257];
   __shared__ uint32_t sh_tmp[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const ColBlocks cb = col_blocks(colstart, gx, cap, blockIdx.x, sh_fb, sh_tmp);
+  const uint32_t blk = blockIdx.x;
+  const ColBlocks cb = col_blocks(colstart, gx, cap, blk, sh_fb, sh_tmp);
   if (cb.col == 0xFFFFFFFFu) return;
 #pragma unroll
   for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
@@ -442,8 +442,8 @@ k_row_scatter(const uint32_t* __restrict__ vals_in, const RowOut ro, const uint3
     dbase[tid] = woff + inc - x;
   }
   __syncthreads();
-  const uint32_t my_hist = hist[(uint64_t)tid * nblk + blockIdx.x];
-  if (blockIdx.x == sh_fb[cb.col] && tid < gy) {   // tile (ty = tid, tx = col): [first pair, first pair of tx + 1)
+  const uint32_t my_hist = hist[(uint64_t)tid * nblk + blk];
+  if (blk == sh_fb[cb.col] && tid < gy) {   // tile (ty = tid, tx = col): [first pair, first pair of tx + 1)
     const uint32_t a = dbase[tid] + my_hist;
     const uint32_t b = dbase[tid] + hist[(uint64_t)tid * nblk + sh_fb[cb.col + 1]];
     uint2 rg = make_uint2(a, b);
@@ -521,7 +521,7 @@ static uint32_t col_runs(int32_t P) { return (uint32_t)(((P > 0 ? P : 1) + kColR
 // packed tile rectangles and the per-run column histogram of the column path.
 extern "C" size_t gsr_project_scratch_bytes(int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
-  return 5 * align256(m * 4) + align256((size_t)kMaxBins * sort_blocks(m, kItemsSmall) * 4) + align256(kMaxBins * 4) +
+  return 5 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4) + align256(kRadix * 4) +
          align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + align256(264 * 4) + 256 + 1024;
 }
 
@@ -535,7 +535,7 @@ extern "C" size_t gsr_sort_scratch_bytes(uint64_t n, uint32_t n_tiles) {
 
 struct ProjectScratch {
   uint32_t *k0, *k1, *v0, *v1, *hist, *totals, *rects, *hist1, *totals1, *colstart;
-  uint64_t* counts;   // [0] = N (pairs), [1] = visible Gaussians, then two u32: (~min, max) of the visible depth keys
+  uint64_t* counts;   // [0] = N (pairs), [1] = visible Gaussians
 };
 static ProjectScratch carve_project(void* scratch, int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
@@ -545,8 +545,8 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
   s.k1 = (uint32_t*)b; b += align256(m * 4);
   s.v0 = (uint32_t*)b; b += align256(m * 4);
   s.v1 = (uint32_t*)b; b += align256(m * 4);
-  s.hist = (uint32_t*)b; b += align256((size_t)kMaxBins * sort_blocks(m, kItemsSmall) * 4);
-  s.totals = (uint32_t*)b; b += align256(kMaxBins * 4);
+  s.hist = (uint32_t*)b; b += align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4);
+  s.totals = (uint32_t*)b; b += align256(kRadix * 4);
   s.rects = (uint32_t*)b; b += align256(m * 4);
   s.hist1 = (uint32_t*)b; b += align256((size_t)256 * col_runs((int32_t)m) * 4);
   s.totals1 = (uint32_t*)b; b += align256(256 * 4);
@@ -573,20 +573,11 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
   uint64_t* n_vis_dev = s.counts + 1;
   const bool columns = use_columns(v.image_height, v.image_width, v.P);
   if (batch > 1 && !columns) return GSR_EINVAL;
-  // GSR_DEPTH_SORT=lsd4 (environment, read once): the four fixed 8-bit passes instead of the three ranged ones (A/B)
-  static const bool lsd4 = [] { const char* e = getenv("GSR_DEPTH_SORT"); return e && !strcmp(e, "lsd4"); }();
-  int where = 1;            // three ranged passes: the result is in (k1, v1) whatever the input
+  int where;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    if (lsd4) {
-      where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
-                                          s.totals, stream, batch, bstride);
-    } else {
-      uint32_t* range = reinterpret_cast<uint32_t*>(s.counts + 2);
-      GSR_HIP(gsr_zero_async(range, 2 * sizeof(uint32_t), stream, bstride, (uint32_t)batch));   // (one word pair per view)
-      ranged_sort_iota_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, (uint64_t)P, n_vis_dev, range, s.hist, s.totals, stream,
-                                        batch, bstride);
-    }
+    where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
+                                        s.totals, stream, batch, bstride);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }

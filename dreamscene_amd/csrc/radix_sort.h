@@ -211,282 +211,6 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
   }
 }
 
-// ------------------------------------------------------------------------------- ranged sort (the depth sort)
-// The depth keys of a view span a narrow range of float bit patterns (an object at distance 5: 22 bits; a room: 26), so
-// the P-sized depth sort runs on key - min(key) with THREE passes whose digit width follows the range on the device:
-// w = ceil(bits(max - min) / 3) <= 11 bits. Three passes for every input (static launch sequence: capturable in a graph,
-// result always in the same buffer), one pass less than 4 x 8 bits, bit-identical order (it is still a stable LSD sort
-// of the full keys: equal keys keep their index order). The LDS tables hold 512 bins; wider digits (w = 10, 11: depth
-// ranges beyond 65536 : 1) are processed in chunks of 512 bins over the keys a workgroup holds in registers.
-constexpr int kMaxDigitBits = 11;
-constexpr int kMaxBins = 1 << kMaxDigitBits;
-constexpr int kChunkBits = 9;
-constexpr int kChunkBins = 1 << kChunkBits;
-constexpr int kRangeGroups = 128;          // workgroups of k_key_range per view
-
-struct DigitCfg {
-  uint32_t base;
-  int shift, w;
-};
-// range[0] = ~min(key), range[1] = max(key) over the keys that are not the sentinel; both 0 when there is none
-__device__ __forceinline__ DigitCfg ranged_cfg(const uint32_t* __restrict__ range, int pass) {
-  const uint32_t kmin = ~range[0], kmax = range[1];
-  const uint32_t span = kmax >= kmin ? kmax - kmin : 0u;
-  const int bits = span ? 32 - __clz((int)span) : 0;
-  DigitCfg c;
-  c.w = max(1, (bits + 2) / 3);
-  c.base = kmin;
-  c.shift = pass * c.w;
-  return c;
-}
-__device__ __forceinline__ uint32_t ranged_digit(const DigitCfg& c, uint32_t key) {
-  return ((key - c.base) >> c.shift) & ((1u << c.w) - 1u);
-}
-template <int NB>
-__device__ __forceinline__ unsigned long long match_bits_n(uint32_t d, bool valid) {
-  unsigned long long m = __ballot(valid);
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const bool bit = (d >> b) & 1u;
-    const unsigned long long bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
-  }
-  return m;
-}
-// lanes of the wave holding the same nbits-bit digit (among `valid` lanes); nbits is wave-uniform: the usual widths get
-// their unrolled ballot chains, anything else a loop
-__device__ __forceinline__ unsigned long long match_bits(uint32_t d, bool valid, int nbits) {
-  if (nbits == 8) return match_bits_n<8>(d, valid);
-  if (nbits == 9) return match_bits_n<9>(d, valid);
-  if (nbits == 7) return match_bits_n<7>(d, valid);
-  unsigned long long m = __ballot(valid);
-  for (int b = 0; b < nbits; ++b) {
-    const bool bit = (d >> b) & 1u;
-    const unsigned long long bal = __ballot(bit);
-    m &= bit ? bal : ~bal;
-  }
-  return m;
-}
-
-// (~min, max) of the non-sentinel keys of each view. range[] must be zero on entry (K1's first thread clears it).
-__global__ void __launch_bounds__(256)
-k_key_range(const uint32_t* __restrict__ keys, const uint64_t n, uint32_t* __restrict__ range, size_t bstride) {
-  keys = batch_ptr(keys, bstride); range = batch_ptr(range, bstride);
-  __shared__ uint32_t s_nmin[4], s_max[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t nmin = 0u, mx = 0u;       // running max of ~key and of key
-  for (uint64_t e = (uint64_t)blockIdx.x * 256 + tid; e < n; e += (uint64_t)gridDim.x * 256) {
-    const uint32_t k = keys[e];
-    if (k != 0xFFFFFFFFu) { nmin = max(nmin, ~k); mx = max(mx, k); }
-  }
-  nmin = gsr_wave_max_u32(nmin);
-  mx = gsr_wave_max_u32(mx);
-  if (lane == 0) { s_nmin[wave] = nmin; s_max[wave] = mx; }
-  __syncthreads();
-  if (tid == 0) {
-    nmin = max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
-    mx = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    if (nmin) atomicMax(range, nmin);
-    if (mx) atomicMax(range + 1, mx);
-  }
-}
-
-template <int ITEMS, bool DROP>
-__global__ void __launch_bounds__(kSortThreads)
-k_rsort_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev, uint64_t cap,
-             const uint32_t* __restrict__ range, int pass, uint32_t nblk, uint32_t* __restrict__ hist, size_t bstride) {
-  keys = batch_ptr(keys, bstride); n_dev = batch_ptr(n_dev, bstride); hist = batch_ptr(hist, bstride);
-  range = batch_ptr(range, bstride);
-  __shared__ uint32_t h[kChunkBins];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t n = eff_count(n_dev, cap);
-  const DigitCfg cfg = ranged_cfg(range, pass);
-  const bool mine = (uint64_t)blockIdx.x * (kSortThreads * ITEMS) < n;
-  uint32_t key[ITEMS];
-  bool ok[ITEMS];
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-    ok[it] = mine && e < n;
-    key[it] = ok[it] ? keys[e] : 0xFFFFFFFFu;
-    if (DROP) ok[it] = ok[it] && key[it] != 0xFFFFFFFFu;
-  }
-  const int cw = min(cfg.w, kChunkBits), nchunk = 1 << (cfg.w - cw), cbins = 1 << cw;
-  for (int c = 0; c < nchunk; ++c) {
-    h[tid] = 0; h[tid + 256] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const uint32_t d = ranged_digit(cfg, key[it]);
-      const bool valid = ok[it] && (int)(d >> kChunkBits) == c;
-      const uint32_t dl = d & (kChunkBins - 1);
-      const unsigned long long m = match_bits(dl, valid, cw);
-      if (valid && lane == __ffsll((long long)m) - 1) atomicAdd(&h[dl], (uint32_t)__popcll(m));
-    }
-    __syncthreads();
-    for (int b = tid; b < cbins; b += 256) hist[(uint64_t)(c * kChunkBins + b) * nblk + blockIdx.x] = h[b];
-    __syncthreads();
-  }
-}
-
-// Workgroup d < 2^w scans row d of hist[][nblk_stride] in place (exclusive), row total to totals[d].
-__global__ void __launch_bounds__(256)
-k_rsort_scan(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ totals,
-             const uint32_t* __restrict__ range, size_t bstride) {
-  hist = batch_ptr(hist, bstride); totals = batch_ptr(totals, bstride); range = batch_ptr(range, bstride);
-  const DigitCfg cfg = ranged_cfg(range, 0);
-  __shared__ uint32_t wave_tot[4];
-  __shared__ uint32_t carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int r = (int)blockIdx.x; r < (1 << cfg.w); r += (int)gridDim.x) {
-  uint32_t* row = hist + (uint64_t)r * nblk;
-  __syncthreads();
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  constexpr uint32_t kPer = 4;
-  for (uint32_t base = 0; base < nblk; base += 256 * kPer) {
-    uint32_t x[kPer];
-    uint32_t s = 0;
-    const uint32_t first = base + tid * kPer;
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {
-      x[k] = (first + k < nblk) ? row[first + k] : 0u;
-      s += x[k];
-    }
-    uint32_t inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wave_tot[w];
-    const uint32_t carry = carry_s;
-    uint32_t run = carry + woff + inc - s;
-#pragma unroll
-    for (uint32_t k = 0; k < kPer; ++k) {
-      if (first + k < nblk) row[first + k] = run;
-      run += x[k];
-    }
-    __syncthreads();
-    if (tid == 255) carry_s = carry + woff + inc;
-    __syncthreads();
-  }
-  if (tid == 0) totals[r] = carry_s;
-  }
-}
-
-// IOTA: values are the element indices (first pass); DROP: the sentinel keys are not written and *n_out = survivors.
-template <bool IOTA, int ITEMS, bool DROP>
-__global__ void __launch_bounds__(kSortThreads)
-k_rsort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint64_t* __restrict__ n_dev,
-                uint64_t cap, const uint32_t* __restrict__ range, int pass, uint32_t nblk,
-                const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals, uint64_t* __restrict__ n_out,
-                size_t bstride) {
-  keys_in = batch_ptr(keys_in, bstride); vals_in = batch_ptr(vals_in, bstride);
-  keys_out = batch_ptr(keys_out, bstride); vals_out = batch_ptr(vals_out, bstride);
-  n_dev = batch_ptr(n_dev, bstride); hist = batch_ptr(hist, bstride); totals = batch_ptr(totals, bstride);
-  n_out = batch_ptr(n_out, bstride); range = batch_ptr(range, bstride);
-  __shared__ uint32_t wh[4][kChunkBins];   // running per-wave digit counters, then per-wave global bases
-  __shared__ uint32_t dbase[kMaxBins];     // exclusive scan of the digit totals
-  __shared__ uint32_t wtot[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t n = eff_count(n_dev, cap);
-  const DigitCfg cfg = ranged_cfg(range, pass);
-  const int nbins = 1 << cfg.w;
-  const bool mine = (uint64_t)blockIdx.x * (kSortThreads * ITEMS) < n;
-  if (!mine && !(DROP && n_out && blockIdx.x == 0)) return;
-  {
-    // exclusive scan of totals[0 .. nbins): thread t owns kMaxBins / 256 = 8 consecutive digits
-    constexpr int kOwn = kMaxBins / 256;
-    uint32_t x[kOwn];
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < kOwn; ++k) {
-      const int d = tid * kOwn + k;
-      x[k] = d < nbins ? totals[d] : 0u;
-      s += x[k];
-    }
-    uint32_t inc = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wtot[w];
-    uint32_t run = woff + inc - s;
-#pragma unroll
-    for (int k = 0; k < kOwn; ++k) {
-      dbase[tid * kOwn + k] = run;
-      run += x[k];
-    }
-    if (DROP && n_out && blockIdx.x == 0 && tid == kSortThreads - 1) *n_out = (uint64_t)(woff + inc);   // survivors
-  }
-  __syncthreads();
-  if (!mine) return;
-  volatile uint32_t* mywh = wh[wave];
-  uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
-  bool ok[ITEMS];
-  const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
-    ok[it] = e < n;
-    key[it] = ok[it] ? keys_in[e] : 0xFFFFFFFFu;
-    val[it] = IOTA ? (uint32_t)e : (ok[it] ? vals_in[e] : 0u);
-    if (DROP) ok[it] = ok[it] && key[it] != 0xFFFFFFFFu;
-  }
-  const int cw = min(cfg.w, kChunkBits), nchunk = 1 << (cfg.w - cw), cbins = 1 << cw;
-  for (int c = 0; c < nchunk; ++c) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { wh[w][tid] = 0; wh[w][tid + 256] = 0; }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const uint32_t d = ranged_digit(cfg, key[it]);
-      const bool valid = ok[it] && (int)(d >> kChunkBits) == c;
-      const uint32_t dl = d & (kChunkBins - 1);
-      const unsigned long long m = match_bits(dl, valid, cw);
-      const int leader = __ffsll((long long)m) - 1;
-      uint32_t old = 0;
-      if (valid && lane == leader) {
-        old = mywh[dl];
-        mywh[dl] = old + (uint32_t)__popcll(m);
-      }
-      old = (uint32_t)__shfl((int)old, valid ? leader : lane, 64);
-      if (valid) rank[it] = old + (uint32_t)__popcll(m & lt);
-    }
-    __syncthreads();
-    for (int b = tid; b < cbins; b += 256) {
-      const int d = c * kChunkBins + b;
-      uint32_t run = dbase[d] + hist[(uint64_t)d * nblk + blockIdx.x];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const uint32_t cnt = wh[w][b];
-        wh[w][b] = run;
-        run += cnt;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const uint32_t d = ranged_digit(cfg, key[it]);
-      if (ok[it] && (int)(d >> kChunkBits) == c) {
-        const uint32_t pos = wh[wave][d & (kChunkBins - 1)] + rank[it];
-        keys_out[pos] = key[it];
-        vals_out[pos] = val[it];
-      }
-    }
-    __syncthreads();
-  }
-}
-
 __host__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 uint32_t sort_blocks(uint64_t n, int items) {
@@ -532,33 +256,6 @@ int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const
     t = va; va = vb; vb = t;
   }
   return passes & 1;
-}
-
-// Stable sort of (u32 key, element index) by the full key in three ranged passes (see above). Keys in k0 (sentinel
-// 0xFFFFFFFF = drop). Result: keys in k1, indices in v1, the number of survivors in *n_compact. range: 2 words per view,
-// ZERO on entry. hist: kMaxBins x sort_blocks(cap, ITEMS) words, totals: kMaxBins words.
-template <int ITEMS>
-void ranged_sort_iota_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, uint64_t cap, uint64_t* n_compact,
-                          uint32_t* range, uint32_t* hist, uint32_t* totals, hipStream_t stream, int batch, size_t bstride) {
-  const uint32_t nblk = sort_blocks(cap, ITEMS);
-  const dim3 grid(nblk, (uint32_t)batch), grid_scan(256, (uint32_t)batch);   // (a row-workgroup takes rows r, r + 256, ...)
-  hipLaunchKernelGGL(k_key_range, dim3(kRangeGroups, (uint32_t)batch), dim3(256), 0, stream, k0, cap, range, bstride);
-  // pass 0: k0 -> k1 (drops the sentinels, values = indices); pass 1: k1 -> k0; pass 2: k0 -> k1
-  hipLaunchKernelGGL((k_rsort_hist<ITEMS, true>), grid, dim3(kSortThreads), 0, stream, k0, (const uint64_t*)nullptr, cap,
-                     range, 0, nblk, hist, bstride);
-  hipLaunchKernelGGL(k_rsort_scan, grid_scan, dim3(256), 0, stream, hist, nblk, totals, range, bstride);
-  hipLaunchKernelGGL((k_rsort_scatter<true, ITEMS, true>), grid, dim3(kSortThreads), 0, stream, k0, v0, k1, v1,
-                     (const uint64_t*)nullptr, cap, range, 0, nblk, hist, totals, n_compact, bstride);
-  uint32_t *ka = k1, *va = v1, *kb = k0, *vb = v0;
-  for (int p = 1; p < 3; ++p) {
-    hipLaunchKernelGGL((k_rsort_hist<ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, (const uint64_t*)n_compact,
-                       cap, range, p, nblk, hist, bstride);
-    hipLaunchKernelGGL(k_rsort_scan, grid_scan, dim3(256), 0, stream, hist, nblk, totals, range, bstride);
-    hipLaunchKernelGGL((k_rsort_scatter<false, ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb,
-                       (const uint64_t*)n_compact, cap, range, p, nblk, hist, totals, (uint64_t*)nullptr, bstride);
-    uint32_t* t = ka; ka = kb; kb = t;
-    t = va; va = vb; vb = t;
-  }
 }
 
 }  // namespace

@@ -6,12 +6,15 @@ GPU executes in 0.93 ms at 500 k Gaussians @1024^2, and smaller workloads are ou
 views/s where the kernels alone allow 11 400 -- round-1 measurements). In capacity mode every launch parameter of the
 path depends only on (P, K, H, W, V, capacity): the kernels take the data-dependent pair count N from device memory. So
 the launches of a step are three fixed sequences:
-    graph A   K1 of all views, depth sorts, column counts            -> N of every view lands in pinned host words
-    graph B   pair emission, tile sort, ranges, work lists, K6       (binning + compositing)
-    graph C   work lists, K7 of all views, K8                        (backward)
-A and B are two graphs so that the host can check N against the capacity while B runs (the same protocol as the eager
+    graph F   K1 of all views, depth sorts, column counts (-> N of every view lands in pinned host words), pair emission,
+              tile sort, ranges, work lists, K6
+    graph C   work lists, K7 of all views, K8                        (backward; also captured over the caller's gradient
+              addresses when those repeat, so that nothing is copied)
+The host polls the pinned words while F still runs and checks N against the capacity (the same protocol as the eager
 path: one wait per step, the GPU stays busy); if a view outgrew the capacity the step is redone eagerly with exact sizes
-and the graphs are re-captured with more room.
+and the graphs are re-captured with more room. (Measured on ROCm 7.2: every graph boundary costs ~10-15 us of GPU idle
+time, which is why the forward is ONE graph; and a graph whose ROOT node is a memset node started before the work
+enqueued ahead of it had finished -- libgsrast clears memory with kernels only.)
 
 What changes from step to step lives in device memory the graphs only point to:
   * the parameters: the caller's own tensors (persistent leaves updated in place by the optimizer); a new tensor
@@ -90,6 +93,7 @@ class CapturedViews(torch.nn.Module):
         self._cap: Optional[_Captured] = None
         self._warm = 0
         self._peak_n = 0
+        self._fwd_mode = 0
         self.stats = dict(captures=0, replays=0, eager_steps=0, overflows=0)
 
     # ------------------------------------------------------------------------------------------------ public
@@ -112,6 +116,7 @@ class CapturedViews(torch.nn.Module):
     def _eager_forward(self, settings_list, means3D, opacities, shs, scales, rotations, rc):
         res = VW.rasterize_views_forward_raw(settings_list, means3D, opacities, shs, None, scales, rotations, None, rc=rc)
         self._peak_n = max([self._peak_n] + [int(o["N"]) for o, _ in res])
+        self._fwd_mode = int(res[-1][1].binning.fwd_mode)      # the compositing variant the eager path settled on
         self.stats["eager_steps"] += 1
         return [(o["color"], o["radii"], o["depth_alpha"]) for o, _ in res], None, [st for _, st in res]
 
@@ -141,14 +146,24 @@ class CapturedViews(torch.nn.Module):
             L.check(lib.gsr_pack_views(V, structs, cap.packed.data_ptr(), stream.cuda_stream), "gsr_pack_views")
             if per_view:
                 cap.scales.copy_(scales)
-            cap.pinned.fill_(-1)
-            cap.gA.replay()
-            cap.evA.record(stream)
-            cap.gB.replay()
+            cap.pinned_np[:] = -1
+            cap.gF.replay()
+            cap.evF.record(stream)
+            # The pair counts land in the pinned words when the column-count kernel of the projection phase has run -- a
+            # third of the way into graph F. The host polls them (page-locked, device-visible memory: nothing else tells the
+            # host that a kernel INSIDE a graph has finished) so that the capacity check is over while the compositing
+            # still runs; if the words only become visible when the graph is done, the event ends the wait.
             t_wait = time.perf_counter()
-            cap.evA.synchronize()                 # (graph B is already enqueued behind A: the GPU stays busy)
+            spins = 0
+            while True:
+                ns = cap.pinned_np[:V]
+                if int(ns.min()) >= 0:
+                    break
+                spins += 1
+                if (spins & 63) == 0 and cap.evF.query():
+                    break
             R.HOST_WAIT_S[0] += time.perf_counter() - t_wait
-        ns = [int(x) for x in cap.pinned[:V].tolist()]
+        ns = [int(x) for x in cap.pinned_np[:V]]
         self._peak_n = max([self._peak_n] + ns)
         self.stats["replays"] += 1
         if max(ns) > cap.cap or min(ns) < 0:
@@ -197,7 +212,7 @@ class CapturedViews(torch.nn.Module):
                 False, "auto", None,
                 dict(scratch=cap.proj_scratch[k * stride:(k + 1) * stride], pinned=cap.pinned, index=k, event=None,
                      sort=(lambda nbytes, k=k: cap.sort_scratch[k * sort_bytes:(k + 1) * sort_bytes]),
-                     capture=dict(cap=cap.cap, fwd_mode=int(rc.fwd_variant or 0)),
+                     capture=dict(cap=cap.cap, fwd_mode=int(rc.fwd_variant if rc.fwd_variant is not None else self._fwd_mode)),
                      dynamic=cap.packed[k].data_ptr() + 40 * 4), rc) for k in range(V)]
             heads = [next(g) for g in gens]
             cap.views = (L.GsrView * V)(*[h[0] for h in heads])
@@ -212,15 +227,13 @@ class CapturedViews(torch.nn.Module):
             if per_view:
                 cap.scales.copy_(scales)
             torch.cuda.synchronize(dev)
-            cap.gA, cap.gB, cap.gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cap.gA, capture_error_mode="thread_local"):
+            cap.gF, cap.gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cap.gF, capture_error_mode="thread_local"):
                 st = torch.cuda.current_stream(dev).cuda_stream
                 L.check(lib.gsr_forward_project_batch(V, cap.views, cap.gauss, cap.geoms, cap.pinned.data_ptr(), st, None),
                         "gsr_forward_project_batch (capture)")
-            for k in range(V):
-                heads[k][1].sorted_idx = cap.geoms[k].sorted_idx
-            with torch.cuda.graph(cap.gB, pool=cap.gA.pool(), capture_error_mode="thread_local"):
-                st = torch.cuda.current_stream(dev).cuda_stream
+                for k in range(V):
+                    heads[k][1].sorted_idx = cap.geoms[k].sorted_idx
                 L.check(lib.gsr_forward_render_batch(V, cap.views, cap.geoms, cap.cap, cap.bins, cap.imgs, st, None),
                         "gsr_forward_render_batch (capture)")
             res = []
@@ -236,7 +249,8 @@ class CapturedViews(torch.nn.Module):
             cap.g_color = torch.zeros((V, 3, H, W), dtype=f32, device=dev)
             cap.g_da = torch.zeros((V, 2, H, W), dtype=f32, device=dev)
             cap.bwd = None
-            cap.evA = torch.cuda.Event()
+            cap.evF = torch.cuda.Event()
+            cap.pinned_np = cap.pinned.numpy()       # the same page-locked words, readable without a torch call
             cap.rc = rc
             cap.per_view = per_view
         self.stats["captures"] += 1
@@ -250,7 +264,7 @@ class CapturedViews(torch.nn.Module):
             o = R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
                                                accumulate=rc.accumulate, stats=None, per_view_scales=per_view)
             torch.cuda.synchronize(dev)
-            with torch.cuda.graph(cap.gC, pool=cap.gA.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(cap.gC, pool=cap.gF.pool(), capture_error_mode="thread_local"):
                 R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
                                                accumulate=rc.accumulate, stats=rc.densify_stats, stats_views=rc.stats_views,
                                                per_view_scales=per_view, reuse=o)
@@ -267,7 +281,7 @@ class CapturedViews(torch.nn.Module):
         if g is None and len(cap.direct) < MAX_DIRECT_GRAPHS:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(cap.g_color.device)
-            with torch.cuda.graph(g, pool=cap.gA.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=cap.gF.pool(), capture_error_mode="thread_local"):
                 R.rasterize_backward_views_raw(cap.states, gcs, gdas, arena=rc.grad_arena, accumulate=rc.accumulate,
                                                stats=rc.densify_stats, stats_views=rc.stats_views,
                                                per_view_scales=per_view, reuse=cap.bwd)
