@@ -69,7 +69,8 @@ class GradExchange:
         values) padded to the largest count; each rank adds the contributions in RANK ORDER, so all replicas end up
         with bit-identical sums (as they do with the ring all-reduce) and keep taking identical optimizer steps.
         Received bytes per rank: sum_r nnz_r (4 + 4 F) with F = 11 + 3 (D+1)^2, against 2 (W-1)/W 4 F P for the dense
-        ring -- a win below ~ 2 (W-1) / W^2 of the rows per rank (22 % at W = 8).
+        ring -- fewer bytes below ~ 2 (W-1) / W^2 of the rows per rank (22 % at W = 8); "auto" takes it below half of that
+        (the format also pays a gather, a scatter-add and two host reads).
     `reduce_scatter_adam` is the sharded-optimizer form of the dense exchange (flat parameter arena required)."""
 
     GEOM = ("means3D", "scales", "rotations", "opacities")
@@ -154,15 +155,18 @@ class GradExchange:
         idx = counts = None
         if mode in ("auto", "rows"):
             idx = self.nonzero_rows()
-            counts = [torch.zeros(1, dtype=torch.int64, device=idx.device) for _ in range(W)]
-            dist.all_gather(counts, torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device), group=self.group)
-            counts = [int(c.item()) for c in counts]          # (the one host read of the exchange)
+            cnt = torch.empty(W, dtype=torch.int64, device=idx.device)
+            dist.all_gather_into_tensor(cnt, torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device),
+                                        group=self.group)
+            counts = [int(c) for c in cnt.tolist()]           # (the one host read of the exchange)
             if mode == "auto":
-                # received bytes: rows format sum_r n_r (4 + 4F) vs dense ring 2 (W-1)/W 4 F P  (same decision on every rank)
-                limit = self.rows_below if self.rows_below is not None else None
+                # received bytes: rows format sum_r n_r (4 + 4F) vs dense ring 2 (W-1)/W 4 F P (the same decision on every
+                # rank). The rows format also pays a gather, a scatter-add and two host reads, so it must win clearly:
+                # by default it is taken below HALF the dense bytes.
                 rows_bytes = sum(counts) * (4 + 4 * F)
                 dense_bytes = 2 * (W - 1) / W * 4 * F * P
-                use_rows = (sum(counts) / W <= limit * P) if limit is not None else (rows_bytes < dense_bytes)
+                use_rows = (sum(counts) / W <= self.rows_below * P) if self.rows_below is not None else \
+                    (rows_bytes < 0.5 * dense_bytes)
                 mode = "rows" if use_rows else "dense"
         if mode == "dense":
             wire = self.wire_buffer()

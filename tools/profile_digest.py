@@ -58,7 +58,9 @@ def pmc_rows(db):
 
 def main(tag, scene_key=None):
     src = os.path.join(ROOT, "gpurun_out", tag)
-    out_dir = os.path.join(ROOT, "profiles")
+    # GSR_PROFILE_OUT: digest on the GPU box itself (the raw rocprofv3 databases exceed what gpurun copies back) into a
+    # small directory under gpurun_out/; its files are then copied into profiles/ here
+    out_dir = os.environ.get("GSR_PROFILE_OUT") or os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     bench = {}
     try:
@@ -125,7 +127,9 @@ def main(tag, scene_key=None):
     tj_path = os.path.join(out_dir, "traffic.json")
     tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
     cfg = bench.get("config", {})
-    key = scene_key or f"object_{cfg.get('gaussians', 500000)}_{(cfg.get('resolution') or [1024, 1024])[1]}"
+    wl = str(cfg.get("workload", ""))
+    scene = "indoor" if "indoor" in wl else ("object-init" if "init" in wl else "object")
+    key = scene_key or f"{scene}_{cfg.get('gaussians', 500000)}_{(cfg.get('resolution') or [1024, 1024])[1]}"
     tobytes = lambda d: int((2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024)
     tj = {k: v for k, v in tj.items() if not k.startswith(key)}
     tj[key] = {
