@@ -74,7 +74,13 @@ def main():
     ap.add_argument("--init-opacity", action="store_true",
                     help="object scene in the reference's initial state: every Gaussian at opacity 0.1 "
                          "(gs_renderer.py:598; ~87 layers blend before T < 1e-4 stops a pixel)")
+    ap.add_argument("--exchange", choices=["dense", "auto", "rows", "sparse_rs", "direct"], default="dense",
+                    help="wire format of the multi-GPU gradient exchange (multiview.GradExchange); dense = one in-place "
+                         "all-reduce of the active columns, the only format that needs no host read")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the drop-in measurement after the timed region (profiling runs: keeps the per-kernel "
+                         "statistics of the batched launches free of single-view launches)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fwd-mode", type=int, default=None, help="force the forward compositing variant (0 / 1)")
     ap.add_argument("--capture", choices=["auto", "on", "off"], default="auto",
@@ -128,7 +134,7 @@ def main():
     my_cams = [cams[(rank * V + j) % len(cams)] for j in range(V)]
     cam = my_cams[0]
     arena = multiview.GradArena(P, K, dev)
-    exchange = multiview.GradExchange(arena, sh_degree=D) if hasattr(multiview, "GradExchange") else None
+    exchange = multiview.GradExchange(arena, sh_degree=D, mode=args.exchange)
     prof_holder = [None]       # the contexts below share one profile slot (set for the stage pass / the timed region)
 
     def ctx(accumulate):
@@ -269,7 +275,7 @@ def main():
 
     # the drop-in figure: the same views through one GaussianRasterizer call per view (untimed w.r.t. `value`)
     dropin = None
-    if batched:
+    if batched and not args.no_dropin:
         set_profile(None)
         n_drop = max(10, args.steps // 4)
         for _ in range(3):
@@ -320,7 +326,7 @@ def main():
             # dispatch count); only used when they were collected for this configuration and call pattern
             traffic, valu = None, None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
-            key = f"{args.scene}{'-init' if args.init_opacity else ''}_{P}_{W}"
+            key = f"{args.scene}{'-init' if args.init_opacity else ''}_{P}_{W}" + ("" if batched else "_dropin")
             if os.path.exists(tf):
                 try:
                     ent = json.load(open(tf)).get(key, {})
@@ -378,7 +384,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "dropin_views_per_s": round(dropin["views_per_s"], 3) if dropin else round(views / elapsed, 3),
+            "dropin_views_per_s": round(dropin["views_per_s"], 3) if dropin else
+            (None if batched else round(views / elapsed, 3)),
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 4),
             "host_wait_ms_per_step": round(host_wait_s / args.steps * 1e3, 4),
             "higher_is_better": True,
@@ -394,9 +401,11 @@ def main():
                        "capture_stats": dict(rast_captured.stats) if captured else None,
                        "dropin": ("`dropin_views_per_s`: the same views through one GaussianRasterizer call per view (the "
                                   f"reference's interface), {dropin['steps']} steps after the timed region") if dropin else
-                                 "`value` IS the drop-in figure (one GaussianRasterizer call per view)",
+                                 ("not measured (--no-dropin)" if batched else
+                                  "`value` IS the drop-in figure (one GaussianRasterizer call per view)"),
                        "parallelism": f"{V} view(s)/GPU/step x {world} GPUs, gradients summed on the device, then 1 RCCL "
-                                      f"all-reduce of {arena.nbytes()} B per step" if world > 1 else
+                                      f"gradient exchange per step (multiview.GradExchange, format {args.exchange}: "
+                                      f"{exchange.last})" if world > 1 else
                                       f"single GPU, {V} view(s) per step, gradients summed on the device"},
             "roofline": roofline,
             "exchange": exch,

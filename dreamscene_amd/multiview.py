@@ -71,14 +71,19 @@ class GradExchange:
         Received bytes per rank: sum_r nnz_r (4 + 4 F) with F = 11 + 3 (D+1)^2, against 2 (W-1)/W 4 F P for the dense
         ring -- fewer bytes below ~ 2 (W-1) / W^2 of the rows per rank (22 % at W = 8); "auto" takes it below half of that
         (the format also pays a gather, a scatter-add and two host reads).
+      * "sparse_rs": the sparse form of reduce-scatter + all-gather. Rank o owns the rows [o P/W, (o+1) P/W). Every rank
+        sends each owner only ITS non-zero rows of that range (one all-to-all with uneven splits: (W-1)/W nnz_r (4 + 4F)
+        bytes out), the owner adds them in rank order, and the owners' reduced rows (the union over the ranks' views)
+        are all-gathered. Per rank at W = 8, C3 (15.7 % of the rows per rank, union ~30 %): 16.5 + 31.5 = 48 MB against
+        the dense ring's 206 MB. Three small host reads per step (row counts).
     `reduce_scatter_adam` is the sharded-optimizer form of the dense exchange (flat parameter arena required)."""
 
     GEOM = ("means3D", "scales", "rotations", "opacities")
 
     def __init__(self, arena: GradArena, sh_degree: Optional[int] = None, group=None, mode: str = "auto",
                  rows_below: Optional[float] = None):
-        if mode not in ("auto", "dense", "rows", "direct"):
-            raise ValueError("mode is 'auto', 'dense', 'rows' or 'direct'")
+        if mode not in ("auto", "dense", "rows", "direct", "sparse_rs"):
+            raise ValueError("mode is 'auto', 'dense', 'rows', 'sparse_rs' or 'direct'")
         self.arena, self.group, self.mode = arena, group, mode
         self.rows_below = rows_below
         self.sh_degree = None
@@ -153,7 +158,7 @@ class GradExchange:
         P, F = self.arena.P, self.row_floats
         mode = self.mode
         idx = counts = None
-        if mode in ("auto", "rows"):
+        if mode in ("auto", "rows"):      # ("sparse_rs" counts per owner itself)
             idx = self.nonzero_rows()
             cnt = torch.empty(W, dtype=torch.int64, device=idx.device)
             dist.all_gather_into_tensor(cnt, torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device),
@@ -190,6 +195,9 @@ class GradExchange:
             self._unpack(wire)
             self.last = dict(format="direct", row_floats=F, bytes_per_rank=int(2 * (W - 1) / W * 4 * n))
             return
+        if mode == "sparse_rs":
+            self._reduce_sparse_rs(W)
+            return
         nmax = max(counts)
         dev, dt = self.arena.flat.device, self.arena.flat.dtype
         my_idx = torch.zeros(max(nmax, 1), dtype=torch.int64, device=dev)
@@ -207,6 +215,65 @@ class GradExchange:
             if counts[r]:
                 self._add_rows(all_idx[r][:counts[r]], all_rows[r][:counts[r]])
         self.last = dict(format="rows", row_floats=F, rows=counts, bytes_per_rank=int(sum(counts) * (4 + 4 * F)))
+
+    def _set_rows(self, idx: torch.Tensor, rows: torch.Tensor) -> None:
+        v = self.arena.views
+        n, nb = idx.numel(), self.nb
+        v["means3D"][idx] = rows[:, 0:3]
+        v["scales"][idx] = rows[:, 3:6]
+        v["rotations"][idx] = rows[:, 6:10]
+        v["opacities"][idx] = rows[:, 10:11].reshape((n,) + tuple(v["opacities"].shape[1:]))
+        v["shs"][idx, :nb, :] = rows[:, 11:].reshape(n, nb, 3)
+
+    def _reduce_sparse_rs(self, W: int) -> None:
+        P, F = self.arena.P, self.row_floats
+        dev, dt = self.arena.flat.device, self.arena.flat.dtype
+        r = dist.get_rank(self.group)
+        per = (P + W - 1) // W
+        idx = self.nonzero_rows()                                         # ascending: contiguous per owner
+        bounds = torch.searchsorted(idx, torch.arange(0, W + 1, device=dev, dtype=idx.dtype) * per)
+        send_counts = (bounds[1:] - bounds[:-1]).to(torch.int64)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        sc, rc = [int(x) for x in send_counts.tolist()], [int(x) for x in recv_counts.tolist()]      # host read 1
+        rows = self._rows_of(idx) if idx.numel() else torch.zeros((0, F), dtype=dt, device=dev)
+        idx32 = idx.to(torch.int32)
+        got_idx = torch.empty(sum(rc), dtype=torch.int32, device=dev)
+        got_rows = torch.empty((sum(rc), F), dtype=dt, device=dev)
+        dist.all_to_all_single(got_idx, idx32, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        dist.all_to_all_single(got_rows, rows, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        # owner: add the contributions in rank order (got_* are ordered by source rank) into the owned slice
+        lo = r * per
+        n_own = max(0, min(per, P - lo))
+        mine = torch.zeros((max(n_own, 1), F), dtype=dt, device=dev)
+        touched = torch.zeros(max(n_own, 1), dtype=torch.bool, device=dev)
+        off = 0
+        for src in range(W):
+            if rc[src]:
+                li = got_idx[off:off + rc[src]].to(torch.int64) - lo
+                mine.index_add_(0, li, got_rows[off:off + rc[src]])
+                touched[li] = True
+            off += rc[src]
+        own_idx = torch.nonzero(touched[:n_own]).reshape(-1) if n_own else torch.zeros(0, dtype=torch.int64, device=dev)
+        cnt = torch.empty(W, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(cnt, torch.tensor([own_idx.numel()], dtype=torch.int64, device=dev), group=self.group)
+        counts = [int(c) for c in cnt.tolist()]                           # host read 2 (own_idx.numel() was the third)
+        nmax = max(max(counts), 1)
+        my_idx = torch.zeros(nmax, dtype=torch.int32, device=dev)
+        my_rows = torch.zeros((nmax, F), dtype=dt, device=dev)
+        my_idx[:own_idx.numel()] = (own_idx + lo).to(torch.int32)
+        if own_idx.numel():
+            my_rows[:own_idx.numel()] = mine[own_idx]
+        all_idx = torch.empty(W * nmax, dtype=torch.int32, device=dev)
+        all_rows = torch.empty((W * nmax, F), dtype=dt, device=dev)
+        dist.all_gather_into_tensor(all_idx, my_idx, group=self.group)
+        dist.all_gather_into_tensor(all_rows, my_rows, group=self.group)
+        self.arena.flat.zero_()
+        for o in range(W):                                                # disjoint row ranges: plain stores
+            if counts[o]:
+                self._set_rows(all_idx[o * nmax:o * nmax + counts[o]].to(torch.int64), all_rows[o * nmax:o * nmax + counts[o]])
+        self.last = dict(format="sparse_rs", row_floats=F, rows_sent=sum(sc) - sc[r], rows_reduced=counts,
+                         bytes_per_rank=int((sum(sc) - sc[r]) * (4 + 4 * F) + (sum(counts) - counts[r]) * (4 + 4 * F)))
 
     def reduce_scatter_adam(self, param_flat: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
                             lr_of, betas=(0.9, 0.999), eps: float = 1e-15, adam=None):

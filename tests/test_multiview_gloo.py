@@ -140,7 +140,9 @@ def _exchange_worker(rank, world, port, P, K, D, row_frac, mode, out_dir):
 @pytest.mark.parametrize("D,row_frac,mode,expect", [(3, 1.0, "auto", "dense"), (0, 1.0, "auto", "dense"),
                                                     (1, 0.9, "dense", "dense"), (3, 0.05, "auto", "rows"),
                                                     (0, 0.05, "rows", "rows"), (2, 0.0, "auto", "rows"),
-                                                    (3, 1.0, "direct", "direct"), (1, 0.5, "direct", "direct")])
+                                                    (3, 1.0, "direct", "direct"), (1, 0.5, "direct", "direct"),
+                                                    (3, 0.1, "sparse_rs", "sparse_rs"), (0, 0.6, "sparse_rs", "sparse_rs"),
+                                                    (2, 0.0, "sparse_rs", "sparse_rs")])
 def test_grad_exchange_formats_equal_plain_sum(tmp_path, D, row_frac, mode, expect):
     """Active-degree columns only / non-zero rows only on the wire: the arena ends up with exactly the sum a plain dense
     all-reduce of everything would give, identical on both ranks."""

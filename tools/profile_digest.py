@@ -6,8 +6,9 @@
                                     both counters are KiB).
 Every pass (trace, pmc_fetch, pmc_write, pmc_sq) is a separate run of bench.py, and rocprofv3 serialises kernels in the
 PMC passes, so the runs do not dispatch the same number of kernels: every pass is normalised by ITS OWN dispatch
-counts (per launch = mean over that pass's dispatches of the kernel; per step = the pass's sum over the stage's
-kernels / the pass's number of k_render_bwd launches, one per step)."""
+counts (per launch = median over that pass's dispatches of the kernel; per step = the pass's sum over the stage's
+kernels / the pass's number of k_render_bwd launches, one per step). Profile batched configurations with
+`bench.py --no-dropin` so that the per-kernel statistics are those of the batched launches."""
 import glob, json, os, sqlite3, sys
 from collections import defaultdict
 
@@ -75,7 +76,7 @@ def main(tag, scene_key=None):
     tot = sum(sum(v) for v in agg.values())
     lines = [f"# rocprofv3 --kernel-trace --stats of: bench.py (see bench line below); durations in us",
              f"# bench: {json.dumps(bench)[:1500]}",
-             f"{'kernel':86s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'total_ms':>9s} {'%':>6s}"]
+             f"{'kernel':86s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'total_ms':>9s} {'%':>6s}  median_us"]
     per_stage = defaultdict(float)
     vps = (bench.get("config", {}) or {}).get("views_per_step_per_gpu", 1) if bench else 1
     # steps of THIS pass, counted from the trace itself: one k_render_bwd launch per step in the batched path, one per
@@ -85,7 +86,7 @@ def main(tag, scene_key=None):
     n_views_trace = max(1, n_bwd_launches * (vps if batched else 1))
     for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         lines.append(f"{n[:86]:86s} {len(v):6d} {sum(v)/len(v)/1e3:9.2f} {min(v)/1e3:9.2f} {max(v)/1e3:9.2f} "
-                     f"{sum(v)/1e6:9.3f} {100*sum(v)/tot:6.2f}")
+                     f"{sum(v)/1e6:9.3f} {100*sum(v)/tot:6.2f}  med {sorted(v)[len(v)//2]/1e3:8.2f}")
         st = stage(n)
         if st:
             per_stage[st] += sum(v) / n_views_trace / 1e3
@@ -116,12 +117,15 @@ def main(tag, scene_key=None):
                 continue
             plines.append(kn[:120])
             for cn, v in sorted(d.items()):
-                plines.append(f"    {cn:24s} dispatches={len(v):5d} avg={sum(v)/len(v):16.1f}")
+                plines.append(f"    {cn:24s} dispatches={len(v):5d} avg={sum(v)/len(v):16.1f} median={sorted(v)[len(v)//2]:16.1f}")
+                # per launch: the MEDIAN over the pass's dispatches (the warm-up renders a few views one at a time before the
+                # batched launches start; the median is the batched launch's value, the mean would be diluted)
+                med = sorted(v)[len(v) // 2]
                 if cn in ("FETCH_SIZE", "WRITE_SIZE"):
-                    launch[short(kn)][cn] = sum(v) / len(v)
+                    launch[short(kn)][cn] = med
                     step[stage(kn)][cn] += sum(v) / steps_pass
                 elif sub == "pmc_sq":
-                    sq.setdefault(short(kn), {})[cn] = sum(v) / len(v)
+                    sq.setdefault(short(kn), {})[cn] = med
         plines.append("")
     open(os.path.join(out_dir, f"{tag}_pmc.txt"), "w").write("\n".join(plines) + "\n")
     tj_path = os.path.join(out_dir, "traffic.json")
@@ -129,9 +133,10 @@ def main(tag, scene_key=None):
     cfg = bench.get("config", {})
     wl = str(cfg.get("workload", ""))
     scene = "indoor" if "indoor" in wl else ("object-init" if "init" in wl else "object")
-    key = scene_key or f"{scene}_{cfg.get('gaussians', 500000)}_{(cfg.get('resolution') or [1024, 1024])[1]}"
+    key = scene_key or (f"{scene}_{cfg.get('gaussians', 500000)}_{(cfg.get('resolution') or [1024, 1024])[1]}" +
+                        ("" if batched else "_dropin"))
     tobytes = lambda d: int((2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024)
-    tj = {k: v for k, v in tj.items() if not k.startswith(key)}
+    tj = {k: v for k, v in tj.items() if k != key and not k.startswith(key + "_raw")}
     tj[key] = {
         "tag": tag, "views_per_step": vps, "batched_call": batched,
         "per_launch_bytes": {k: tobytes(d) for k, d in sorted(launch.items())},
