@@ -388,6 +388,7 @@ def main():
             (None if batched else round(views / elapsed, 3)),
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 4),
             "host_wait_ms_per_step": round(host_wait_s / args.steps * 1e3, 4),
+            "host_busy_ms_per_step": round((host_enqueue_s - host_wait_s) / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -7,11 +7,16 @@ Mirrors what the reference does around `GaussianRasterizer` (nothing here is imp
   * the zero `means2D` leaf that receives the screen-space gradient   scene_gaussian.py:919-933
   * post-processing depth_alpha -> (disp, alpha)            scene_gaussian.py:1023-1032
   * the returned dict                                       scene_gaussian.py:1036-1044
-Pinned by tests/golden/object_render.npz (the reference's own object_render executed over the CPU oracle).
+  * the training-time augmentations of object_render (test=False): active SH degree dropped to 0, background replaced
+    by noise or black, multiplicative noise on the SH coefficients and on the scales -- same random decisions in the
+    same order from the same generators                      scene_gaussian.py:938-947, 1001-1008
+Pinned by tests/golden/object_render.npz and object_render_train.npz (the reference's own object_render executed over the
+CPU oracle, test=True and, with seeded generators, test=False).
 """
 from __future__ import annotations
 
 import math
+import random
 from typing import Optional
 
 import torch
@@ -55,8 +60,13 @@ def _cam_tensors(cam, device, dtype=torch.float32):
 
 
 def object_render(params: GaussianParams, camera, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
-                  score_flag: bool = False, rasterizer_cls=None, settings_cls=None):
-    """test=True path of SceneGaussian.object_render / score_render (no random augmentation)."""
+                  score_flag: bool = False, rasterizer_cls=None, settings_cls=None, test: bool = True,
+                  black_video: bool = False, sh_deg_aug_ratio: float = 0.1, bg_aug_ratio: float = 0.3,
+                  shs_aug_ratio: float = 1.0, scale_aug_ratio: float = 1.0, rng=random, host_noise: bool = False):
+    """SceneGaussian.object_render / score_render. test=True (the default here): no random augmentation. test=False:
+    the reference's training-time augmentations, drawing from `rng` (Python's `random`) and torch's generator in the
+    reference's order. host_noise: draw the torch noise on the CPU generator and move it to the parameters' device (so
+    that a seeded run reproduces the CPU-captured fixture on a GPU)."""
     if rasterizer_cls is None or settings_cls is None:
         from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
         rasterizer_cls = rasterizer_cls or GaussianRasterizer
@@ -67,16 +77,30 @@ def object_render(params: GaussianParams, camera, bg_color: torch.Tensor, scalin
         screenspace_points.retain_grad()
     except Exception:
         pass
+
+    def rand_like(t, fn):
+        return fn(t.shape, dtype=t.dtype).to(t.device) if host_noise else (torch.rand_like(t) if fn is torch.rand
+                                                                           else torch.randn_like(t))
+    if black_video:
+        bg_color = torch.zeros_like(bg_color)
+    act_SH = 0 if (rng.random() < sh_deg_aug_ratio and not test) else params.active_sh_degree     # :938-941
+    if rng.random() < bg_aug_ratio and not test:                                                  # :943-947
+        bg_color = rand_like(bg_color, torch.rand) if rng.random() < 0.5 else torch.zeros_like(bg_color)
     tanfovx = math.tan(camera.FoVx * 0.5)
     tanfovy = math.tan(camera.FoVy * 0.5)
     vm, pm, cp = _cam_tensors(camera, xyz.device)
     settings = settings_cls(image_height=int(camera.image_height), image_width=int(camera.image_width),
                             tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
-                            viewmatrix=vm, projmatrix=pm, sh_degree=params.active_sh_degree, campos=cp,
+                            viewmatrix=vm, projmatrix=pm, sh_degree=act_SH, campos=cp,
                             prefiltered=False, score_flag=score_flag)
     rasterizer = rasterizer_cls(raster_settings=settings)
     scales = params.get_scaling
-    res = rasterizer(means3D=xyz, means2D=screenspace_points, shs=params.get_features, colors_precomp=None,
+    shs = params.get_features
+    if rng.random() < shs_aug_ratio and not test:                                                 # :1001-1003
+        shs = shs + (rand_like(shs, torch.randn) * ((0.2 ** 0.5) * shs))
+    if rng.random() < scale_aug_ratio and not test:                                               # :1005-1008
+        scales = torch.clamp(scales + (rand_like(scales, torch.randn) * ((0.2 ** 0.5) * scales / 4)), 0.0)
+    res = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=None,
                      opacities=params.get_opacity, scales=scales, rotations=params.get_rotation, cov3D_precomp=None)
     score: Optional[torch.Tensor] = None
     if score_flag:

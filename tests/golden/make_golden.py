@@ -192,6 +192,48 @@ def main():
              vsp_grad=out["viewspace_points"].grad.numpy(), g_xyz=gm._xyz.grad.numpy(), g_scaling=gm._scaling.grad.numpy(),
              g_rotation=gm._rotation.grad.numpy(), g_opacity=gm._opacity.grad.numpy(), g_f_dc=gm._features_dc.grad.numpy(),
              g_f_rest=gm._features_rest.grad.numpy())
+    # ---- the same object_render in TRAINING mode (test=False): the random augmentations of scene_gaussian.py:938-947 and
+    # :1001-1008 (active SH degree dropped to 0, background replaced by noise / black, SH noise, scale noise). Python's and
+    # torch's generators are seeded per case; a recording wrapper around the rasterizer captures what the reference handed
+    # over (settings.sh_degree, settings.bg, the noisy shs and scales). Seeds chosen for branch coverage: 31 = degree 0 +
+    # random background, 7 = black background, 43 = degree 0 + background kept, 1 = no degree / background change.
+    train = {}
+    orig_rast = SG.GaussianRasterizer
+    for seed in (31, 7, 43, 1):
+        random.seed(seed)
+        torch.manual_seed(seed)
+        rec = {}
+
+        def recording(raster_settings, rec=rec):
+            r = orig_rast(raster_settings)
+            rec["sh_degree"] = int(raster_settings.sh_degree)
+            rec["bg"] = raster_settings.bg.detach().clone()
+
+            def call(**kw):
+                rec["shs"] = kw["shs"].detach().clone()
+                rec["scales"] = kw["scales"].detach().clone()
+                return r(**kw)
+            return call
+        SG.GaussianRasterizer = recording
+        for prm in (gm._xyz, gm._scaling, gm._rotation, gm._opacity, gm._features_dc, gm._features_rest):
+            prm.grad = None
+        out = sg.object_render(gm, cam, bg.clone(), test=False)
+        loss = (out["image"] * gi).sum() + (out["depth"] * gd).sum() + (out["alpha"] * ga).sum()
+        loss.backward()
+        SG.GaussianRasterizer = orig_rast
+        t_ = f"s{seed}_"
+        train.update({t_ + "sh_degree": np.int64(rec["sh_degree"]), t_ + "bg_used": rec["bg"].numpy(),
+                      t_ + "shs_noisy": rec["shs"].numpy(), t_ + "scales_noisy": rec["scales"].numpy(),
+                      t_ + "image": out["image"].detach().numpy(), t_ + "depth": out["depth"].detach().numpy(),
+                      t_ + "alpha": out["alpha"].detach().numpy(), t_ + "radii": out["radii"].numpy(),
+                      t_ + "scales_out": out["scales"].detach().numpy(),
+                      t_ + "vsp_grad": out["viewspace_points"].grad.numpy(), t_ + "g_xyz": gm._xyz.grad.numpy(),
+                      t_ + "g_scaling": gm._scaling.grad.numpy(), t_ + "g_rotation": gm._rotation.grad.numpy(),
+                      t_ + "g_opacity": gm._opacity.grad.numpy(), t_ + "g_f_dc": gm._features_dc.grad.numpy(),
+                      t_ + "g_f_rest": gm._features_rest.grad.numpy()})
+    np.savez_compressed(os.path.join(HERE, "object_render_train.npz"), seeds=np.array([31, 7, 43, 1], np.int64), **train)
+    for prm in (gm._xyz, gm._scaling, gm._rotation, gm._opacity, gm._features_dc, gm._features_rest):
+        prm.grad = None
     # ---- the reference's scene_render (scene_gaussian.py:673-893) over the oracle: three models of different sizes,
     # test=True (no random augmentation). Pins the activation + concatenation glue the fused multi-model path replaces.
     random.seed(1)
