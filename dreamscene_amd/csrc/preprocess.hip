@@ -13,6 +13,7 @@
 // (depth bits, radius, tile rectangle) rounds exactly once, in the order written -- the same order as
 // oracle/gsr_oracle.c -- which is what makes radii / tile counts / sort keys bit-exact against the oracle.
 #include "gsr_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -1298,18 +1299,137 @@ struct K8Views {
   uint32_t stat_mask;
 };
 
-template <int KT, bool PVS>   // PVS: per-view scales
+// ------------------------------------------------------------------------------- K8, sparse over the Gaussians
+// K7 reaches few Gaussians: behind the first opaque layers nothing receives a gradient (C3: 4-5 % of the Gaussians
+// per view, 16 % in the union of four views; 2 M Gaussians: 8 %). A (Gaussian, view) pair whose ten K7 sums are all
+// zero contributes exactly zero to every output of K8 -- every term of the chain rule is a product with one of them --
+// so the ~1 200 instructions per pair, and the 236 B parameter row, are only worth touching for the Gaussians some
+// view reached. Those are scattered (nearly every wave holds one), so the REACHED form of the kernel below compacts
+// them inside the workgroup:
+//   A. thread = Gaussian: radii + K7 sums of every view -> "reached by some view?", counted over the workgroup. More
+//      than kK8SparseMax of its 256: the workgroup carries on as the dense kernel (the sums are read a second time, from
+//      the cache). Otherwise it clears the gradient rows of its 256 Gaussians with coalesced stores (unless
+//      accumulating); a Gaussian nothing reached gets its per-view zeros and visibility statistics here and is done;
+//   B. the reached ones are listed in LDS (ballot / popcount prefix, ascending); wave c of the workgroup (rotated by the
+//      block index so that the work does not pile up on one SIMD) takes entries [64 c, 64 c + 64) and runs the dense
+//      chain rule on them -- same arithmetic, same summation order over the views, bit-identical rows -- writing each
+//      row itself over the cleared one; waves without entries leave.
+// At C3 a workgroup lists ~40 of its 256 Gaussians: one wave instead of four runs the chain rule and 84 % of the
+// parameter rows are never read. Measured (us per view, dense -> this): C3 27.6 -> 27.0 (the dense kernel is
+// not bound by its instruction count there after all), 2 M Gaussians @512^2 94.5 -> 76, single-view calls 2 360 -> 2 530
+// views/s. Forms that were measured and dropped: (i) chunks of (Gaussian, view) pairs dealt to the waves with the results
+// summed by ds_add_f32 into a 256-row LDS tile (0.5 ns per pair: slower than dense once 5 % are active); (ii) a separate
+// classify launch appending to global lists kept in spare words of the K7 sums, then the dense kernel over the lists
+// (one list: 31 000 same-address atomics at 2 M Gaussians; one list per 8 192 Gaussians: the live workgroups of the
+// second launch all land on three of the eight XCDs); (iii) lane j of every wave holding the j-th reached Gaussian,
+// wave w running view w, results added to an LDS tile view after view between barriers: slower than this form
+// everywhere except at 2 M (72).
+constexpr int kK8SparseMax = 128;
+
+// one lane's row of F floats -> global memory (dword-aligned 16-byte pieces)
+template <int F>
+__device__ __forceinline__ void store_row(float* __restrict__ dst, const float* src, bool accumulate) {
+#pragma unroll
+  for (int q = 0; q + 3 < F; q += 4) {
+    gsr_f4u t;
+    t.x = src[q]; t.y = src[q + 1]; t.z = src[q + 2]; t.w = src[q + 3];
+    if (accumulate) {
+      const gsr_f4u o = *reinterpret_cast<const gsr_f4u*>(dst + q);
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    *reinterpret_cast<gsr_f4u*>(dst + q) = t;
+  }
+#pragma unroll
+  for (int q = F & ~3; q < F; ++q) dst[q] = accumulate ? dst[q] + src[q] : src[q];
+}
+
+// zeros over n floats starting at dst (n < 2^31), the 256 threads of the block together; VEC: dst is 16-byte aligned
+template <bool VEC>
+__device__ __forceinline__ void block_zero(float* __restrict__ dst, int n) {
+  const int tid = threadIdx.x;
+  if constexpr (VEC) {
+    const int n4 = n >> 2;
+    for (int q = tid; q < n4; q += 256) reinterpret_cast<float4*>(dst)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = (n4 << 2) + tid; q < n; q += 256) dst[q] = 0.f;
+  } else {
+    for (int q = tid; q < n; q += 256) dst[q] = 0.f;
+  }
+}
+
+template <int KT, bool PVS, bool REACHED = false>   // PVS: per-view scales; REACHED: the sparse form described above
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, const GsrGrads out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ uint32_t wcnt[4];
+  __shared__ uint8_t reached_list[256];
   constexpr int F = 3 * KT;
-  const int P = v.P, W = v.image_width, H = v.image_height;
+  const int W = v.image_width, H = v.image_height;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  const int64_t P = v.P;
+  const int64_t first = (int64_t)blockIdx.x * 256;
+  int64_t i = first + tid;
+  bool ok = i < P;
+  bool sparse = false;   // uniform over the workgroup
+  if constexpr (REACHED) {
+    // ---- A: which of the workgroup's Gaussians did some view reach?
+    bool reached = false;
+    for (int vv = 0; vv < vb.nv; ++vv) {
+      const int32_t r = ok ? vb.radii[vv][i] : 0;
+      if (r > 0) {
+        const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
+        const float4 pa = pp[0], pb = pp[1];
+        const float2 pc = *reinterpret_cast<const float2*>(vb.partials[vv] + 12 * i + 8);
+        reached = reached || (pa.x != 0.f) || (pa.y != 0.f) || (pa.z != 0.f) || (pa.w != 0.f) || (pb.x != 0.f) ||
+                  (pb.y != 0.f) || (pb.z != 0.f) || (pb.w != 0.f) || (pc.x != 0.f) || (pc.y != 0.f);
+      }
+    }
+    const unsigned long long m = __ballot(reached);
+    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    const int cnt = (int)((wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]));
+    sparse = cnt <= kK8SparseMax;
+    if (sparse) {
+      if (!out.accumulate) {
+        const int nblk = (int)min((int64_t)256, P - first);
+        block_zero<true>(out.dL_dshs + first * F, nblk * F);
+        block_zero<false>(out.dL_dmeans3D + first * 3, nblk * 3);
+        block_zero<false>(out.dL_dopacities + first, nblk);
+        if constexpr (!PVS) block_zero<false>(out.dL_dscales + first * 3, nblk * 3);
+        block_zero<true>(out.dL_drotations + first * 4, nblk * 4);
+      }
+      if (ok && !reached) {   // what the chain rule below would produce from zeros
+        for (int vv = 0; vv < vb.nv; ++vv) {
+          float* m2 = vb.dL_dmeans2D[vv];
+          m2[3 * i] = 0.f; m2[3 * i + 1] = 0.f; m2[3 * i + 2] = 0.f;
+          if constexpr (PVS) {
+            float* o = vb.dL_dscales[vv];
+            o[3 * i] = 0.f; o[3 * i + 1] = 0.f; o[3 * i + 2] = 0.f;
+          }
+          if (out.stat_denom && ((vb.stat_mask >> vv) & 1u)) {
+            const int32_t r = vb.radii[vv][i];
+            if (r > 0) {
+              out.stat_denom[i] += 1.0f;
+              out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)r);
+            }
+          }
+        }
+      }
+      // ---- B: the reached ones, ascending
+      if (reached) {
+        uint32_t off = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        reached_list[off] = (uint8_t)tid;
+      }
+      __syncthreads();   // (also orders the cleared rows before a lane of this workgroup rewrites one: same CU, same L2)
+      const int chunk = ((wave + 4 - (int)(blockIdx.x & 3u)) & 3) * 64;
+      if (chunk >= cnt) return;
+      ok = chunk + lane < cnt;
+      i = first + (ok ? (int)reached_list[chunk + lane] : 0);
+    }
+  }
   const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
-  const int n_valid = (int)min((int64_t)64, max((int64_t)0, (int64_t)P - wave_first));
+  const int n_valid = (int)min((int64_t)64, max((int64_t)0, P - wave_first));
   const float mod = v.scale_modifier;
-  const bool ok = i < P;
   constexpr int stride = F | 1;
   float* lw = lds + wave * (64 * stride);
   float* sh = lw + lane * stride;
@@ -1439,16 +1559,20 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   float dscale[3] = {0.f, 0.f, 0.f};
   if (any && !PVS) sigma_backward(dS, R, s3, mod, q, dscale, drot);
 
-  // gradient rows -> LDS (zeros for Gaussians no view saw) -> coalesced write-back
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (lane < n_valid) {
+  if (sparse) {   // the lane's own row over the cleared one
+    if (ok && out.dL_dshs && !(out.accumulate && !any)) store_row<F>(out.dL_dshs + (size_t)i * F, dsh, out.accumulate != 0);
+  } else {
+    // gradient rows -> LDS (zeros for Gaussians no view saw) -> coalesced write-back
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < n_valid) {
 #pragma unroll
-    for (int k = 0; k < F; ++k) sh[k] = dsh[k];
+      for (int k = 0; k < F; ++k) sh[k] = dsh[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (out.dL_dshs && !(out.accumulate && amask == 0ull))
+      stage_sh_out<KT>(out.dL_dshs, wave_first, n_valid, KT, lw, out.accumulate != 0);
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (out.dL_dshs && !(out.accumulate && amask == 0ull))
-    stage_sh_out<KT>(out.dL_dshs, wave_first, n_valid, KT, lw, out.accumulate != 0);
 
   if (ok && !(out.accumulate && !any)) {
     if (out.accumulate) {
@@ -1468,6 +1592,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     *reinterpret_cast<float4*>(out.dL_drotations + 4 * i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
   }
 }
+
 
 
 // K8 over several views of a SCENE: the raw rows are read once, every view has its own (possibly noisy) scales, the
@@ -1739,8 +1864,24 @@ int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom
   return GSR_OK;
 }
 
+// GSR_K8_SPARSE=0 keeps the dense kernels (one chain rule per visible Gaussian and view) for comparison runs.
+static bool gsr_k8_sparse() {
+  static const bool on = [] {
+    const char* e = getenv("GSR_K8_SPARSE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+bool gsr_preprocess_bwd_views_supported(const GsrView& v, const GsrGaussians& g, const GsrGrads& out);
+int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians* gs, const GsrGeom* geoms,
+                                    const GsrGrads* outs, hipStream_t stream);
+
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const GsrGeom& geom, const GsrGrads& out,
                               hipStream_t stream) {
+  // the trainers' case (SH rows, scales + rotations, no camera gradients): the sparse kernel with one view
+  if (!g.scene && gsr_k8_sparse() && !out.dL_dcolors && !out.dL_dcov3D && gsr_preprocess_bwd_views_supported(v, g, out))
+    return gsr_launch_preprocess_bwd_views(1, &v, &g, &geom, &out, stream);
   if (g.scene) {
     SceneTab t; SceneGradTab gt;
     const uint32_t nbs = scene_tables(*g.scene, out.scene, t, gt);
@@ -1835,6 +1976,23 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
     return GSR_OK;
   }
   const uint32_t nb = gsr_num_blocks(v.P);
+  if (gsr_k8_sparse()) {
+#define GSR_LAUNCH_K8SP(KT)                                                                                         \
+  if (vb.per_view_scales)                                                                                           \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, out0); \
+  else                                                                                                              \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, false, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, out0)
+    switch (v.sh_stride) {
+      case 16: GSR_LAUNCH_K8SP(16); break;
+      case 9: GSR_LAUNCH_K8SP(9); break;
+      case 4: GSR_LAUNCH_K8SP(4); break;
+      case 1: GSR_LAUNCH_K8SP(1); break;
+      default: return GSR_EINVAL;
+    }
+#undef GSR_LAUNCH_K8SP
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+  }
 #define GSR_LAUNCH_K8V(KT)                                                                                       \
   if (vb.per_view_scales)                                                                                        \
     hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, out0);  \
