@@ -1,0 +1,92 @@
+"""-m gpu: K8's sparse form (csrc/preprocess.hip, k_preprocess_bwd_views<K, PVS, REACHED>). A workgroup of 256
+Gaussians of which K7 reached at most 128 compacts them and runs the chain rule on those only; the others get zeros
+from coalesced clears. The scene below puts all three cases side by side -- workgroups nothing reached (opacity below
+1/255: visible, never blended), workgroups mostly reached (they stay dense) and mixed ones -- and the gradients are
+compared with the C oracle for single-view calls (write, then accumulate) and for one batched 4-view call."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import err, oracle_view, settings_for, small_scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+P, H, W, K, D = 2048, 80, 96, 16, 3
+
+
+def _scene():
+    g, _ = small_scene(P=P, H=H, W=W, K=K, seed=29, scale_mul=2.5)
+    op = g["opacities"].reshape(-1)
+    op[:768] = np.clip(op[:768], 0.05, 0.6)        # thin, translucent cloud: most of it is reached (dense workgroups)
+    op[768:1024:2] = 0.002                         # every other one of this workgroup can never pass alpha >= 1/255
+    op[1024:1536] = 0.003                          # two workgroups nothing reaches
+    op[1536:] = np.where(np.arange(512) % 5 == 0, op[1536:], 0.001)   # 20 % candidates: sparse workgroups
+    g["opacities"] = op.reshape(g["opacities"].shape).astype(np.float32)
+    return g
+
+
+def _oracle_sum(c_oracle, g, cams, bg, ups):
+    ref = {k: 0.0 for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dshs")}
+    m2, reached = [], np.zeros(P, bool)
+    for cam, (gi, gda) in zip(cams, ups):
+        v = oracle_view(c_oracle, cam, P, K, D, bg)
+        f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        b = c_oracle.backward(v, f, gi, gda, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        for k in ref:
+            ref[k] = ref[k] + np.asarray(b[k], dtype=np.float64)
+        m2.append(np.asarray(b["dL_dmeans2D"]))
+        reached |= (np.abs(np.asarray(b["dL_dopacity"]).reshape(P, -1)).sum(1) +
+                    np.abs(np.asarray(b["dL_dshs"]).reshape(P, -1)).sum(1)) > 0
+    return ref, m2, reached
+
+
+def _compare(arena, ref):
+    for ak, rk in [("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                   ("opacities", "dL_dopacity"), ("shs", "dL_dshs")]:
+        a = arena.views[ak].cpu().numpy().reshape(-1)
+        r = np.asarray(ref[rk]).reshape(-1)
+        assert err(a, r) <= TOL * max(1.0, float(np.abs(r).max())), ak
+
+
+def test_sparse_and_dense_workgroups_vs_oracle(built_lib, c_oracle):
+    from dreamscene_amd import multiview, rasterizer as R, synth
+    from dreamscene_amd.views import GaussianRasterizerViews
+    g = _scene()
+    cams = synth.object_cameras(5, H, W, radius=3.0)[1:]
+    bg = np.array([0.1, 0.3, 0.9], np.float32)
+    ups = [synth.upstream_grads(H, W, seed=k) for k in range(4)]
+    ref, ref_m2, reached = _oracle_sum(c_oracle, g, cams, bg, ups)
+    per_wg = reached.reshape(-1, 256).sum(1)
+    assert per_wg.min() == 0 and per_wg.max() > 128 and ((per_wg > 0) & (per_wg <= 128)).any(), per_wg   # all three cases
+    t = {k: torch.tensor(v, device=DEV) for k, v in g.items()}
+    dev = torch.device(DEV)
+    # (1) one call per view: the first writes the arena, the others accumulate into it
+    arena = multiview.GradArena(P, K, dev)
+    arena.flat.fill_(7.0)                          # stale contents: the first call must overwrite every row
+    for j, cam in enumerate(cams):
+        s = settings_for(cam, bg, D, DEV)
+        _, st = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None,
+                                        want_aux=False)
+        o = R.rasterize_backward_raw(st, torch.tensor(ups[j][0], device=DEV), torch.tensor(ups[j][1], device=DEV),
+                                     arena=arena, accumulate=j > 0)
+        a, r = o["dL_dmeans2D"].cpu().numpy().reshape(-1), ref_m2[j].reshape(-1)
+        assert err(a, r) <= TOL * max(1.0, float(np.abs(r).max())), ("dL_dmeans2D", j)
+    torch.cuda.synchronize()
+    _compare(arena, ref)
+    # (2) the same four views through one batched call
+    arena2 = multiview.GradArena(P, K, dev)
+    arena2.flat.fill_(-3.0)
+    sets = [settings_for(c, bg, D, dev) for c in cams]
+    tt = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    rast = GaussianRasterizerViews(sets, context=R.RasterContext(grad_arena=arena2))
+    m2d = torch.zeros((4, P, 3), device=dev, requires_grad=True)
+    outs = rast(means3D=tt["means3D"], means2D=m2d, shs=tt["shs"], opacities=tt["opacities"], scales=tt["scales"],
+                rotations=tt["rotations"])
+    grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], [m2d],
+                                [torch.tensor(y, device=dev) for k in range(4) for y in ups[k]])
+    torch.cuda.synchronize()
+    _compare(arena2, ref)
+    for j in range(4):
+        a, r = grads[0][j].cpu().numpy().reshape(-1), ref_m2[j].reshape(-1)
+        assert err(a, r) <= TOL * max(1.0, float(np.abs(r).max())), ("batched dL_dmeans2D", j)
