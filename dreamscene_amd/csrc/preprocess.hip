@@ -1324,7 +1324,10 @@ struct K8Views {
 // second launch all land on three of the eight XCDs); (iii) lane j of every wave holding the j-th reached Gaussian,
 // wave w running view w, results added to an LDS tile view after view between barriers: slower than this form
 // everywhere except at 2 M (72).
-constexpr int kK8SparseMax = 128;
+#ifndef GSR_K8_SPARSE_MAX
+#define GSR_K8_SPARSE_MAX 128
+#endif
+constexpr int kK8SparseMax = GSR_K8_SPARSE_MAX;
 
 // one lane's row of F floats -> global memory (dword-aligned 16-byte pieces)
 template <int F>
@@ -1880,7 +1883,7 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const GsrGeom& geom, const GsrGrads& out,
                               hipStream_t stream) {
   // the trainers' case (SH rows, scales + rotations, no camera gradients): the sparse kernel with one view
-  if (!g.scene && gsr_k8_sparse() && !out.dL_dcolors && !out.dL_dcov3D && gsr_preprocess_bwd_views_supported(v, g, out))
+  if (!g.scene && gsr_k8_sparse() && v.sh_stride >= 9 && !out.dL_dcolors && !out.dL_dcov3D && gsr_preprocess_bwd_views_supported(v, g, out))
     return gsr_launch_preprocess_bwd_views(1, &v, &g, &geom, &out, stream);
   if (g.scene) {
     SceneTab t; SceneGradTab gt;
@@ -1976,7 +1979,9 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
     return GSR_OK;
   }
   const uint32_t nb = gsr_num_blocks(v.P);
-  if (gsr_k8_sparse()) {
+  // (rows of 12 floats or fewer, K <= 4: skipping them saves less than the classification costs -- the 2 M indoor scene
+  //  at K = 4 measured 36 us per view sparse, 33 dense -- so those keep the dense kernel)
+  if (gsr_k8_sparse() && v.sh_stride >= 9) {
 #define GSR_LAUNCH_K8SP(KT)                                                                                         \
   if (vb.per_view_scales)                                                                                           \
     hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, out0); \
@@ -1985,8 +1990,6 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
     switch (v.sh_stride) {
       case 16: GSR_LAUNCH_K8SP(16); break;
       case 9: GSR_LAUNCH_K8SP(9); break;
-      case 4: GSR_LAUNCH_K8SP(4); break;
-      case 1: GSR_LAUNCH_K8SP(1); break;
       default: return GSR_EINVAL;
     }
 #undef GSR_LAUNCH_K8SP
