@@ -181,6 +181,8 @@ int gsr_pack_views(int32_t n_views, const GsrView* views, float* packed, void* s
   for (int k = 0; k < n_views; ++k) {
     const int rc = check_view(&views[k]);
     if (rc) return rc;
+    // the same bound check_gaussians applies at capture time: a replayed view must not ask for more SH bands than stored
+    if (views[k].sh_stride > 0 && (views[k].sh_degree + 1) * (views[k].sh_degree + 1) > views[k].sh_stride) return GSR_EINVAL;
     pv.bg[k] = views[k].bg; pv.viewmatrix[k] = views[k].viewmatrix; pv.projmatrix[k] = views[k].projmatrix;
     pv.campos[k] = views[k].campos;
     pv.tanfovx[k] = views[k].tanfovx; pv.tanfovy[k] = views[k].tanfovy; pv.sh_degree[k] = (float)views[k].sh_degree;

@@ -5,9 +5,10 @@
 // cov3D gs_renderer.py:124-172, SH utils/sh_utils.py:25-102, projection utils/graphics_utils.py:29-36.
 //
 // Both kernels are HBM-streaming (44 + 12K bytes in per Gaussian for K1; 276 in / 248 out for K8 at K=16).
-// One thread per Gaussian; the [P,K,3] SH block of a wave (64*3K contiguous floats) is moved with fully
-// coalesced 16-byte loads/stores and transposed through LDS (odd row stride => conflict-free per-lane rows)
-// instead of 64 lanes each walking its own 12K-byte row.
+// One thread per Gaussian. K1: every lane pulls its own 12K-byte SH row with 16-byte loads straight into registers (the
+// SH stride is a template parameter; the rows of a wave are contiguous, so L1/TA serve the pieces of a line to successive
+// loads -- measured faster than the LDS transpose of round 1, which cost 50 KB of LDS per block). K8: the SH rows are
+// read the same way; dL/dSH is written back coalesced through an LDS transpose (direct row stores measured 25 % slower).
 //
 // This translation unit is built with -ffp-contract=off: every fp32 operator that feeds an integer artefact
 // (depth bits, radius, tile rectangle) rounds exactly once, in the order written -- the same order as
@@ -846,14 +847,11 @@ __device__ __forceinline__ void geom_backward(const ViewConst& vc, const Ewa& e,
                                               float dS[9], float dp[3], float dview[12], float dproj[12]) {
   const float* V = vc.V;
   const float* PV = vc.PV;
-  // (2a) moments -> dL/d(ndc xy) and dL/dconic: power = -1/2 (A dx^2 + C dy^2) - B dx dy, dG/ddx = -G (A dx + B dy)
+  // (2a) K7's sums -> dL/d(ndc xy) and dL/dconic: power = -1/2 (A dx^2 + C dy^2) - B dx dy, dG/ddx = -G (A dx + B dy).
+  // S1 = sum q (dG/ddx)/G and S2 = sum q (dG/ddy)/G arrive contracted with the conic per pixel (render.hip, K7)
   const float ca = e.ca, cb = e.cb, cc = e.cc;
-  {
-    const float inv = 1.0f / e.det;
-    const float A = cc * inv, B = -cb * inv, C = ca * inv;
-    gndx = -(A * S1 + B * S2) * (0.5f * (float)W);
-    gndy = -(C * S2 + B * S1) * (0.5f * (float)H);
-  }
+  gndx = S1 * (0.5f * (float)W);
+  gndy = S2 * (0.5f * (float)H);
   const float gca = -0.5f * S3, gcb = -S4, gcc = -0.5f * S5;
   // (2b) conic -> cov2D (lineage denominator det^2 + 1e-7)
   const float d2i = 1.0f / (e.det * e.det + 0.0000001f);
@@ -946,7 +944,7 @@ __device__ __forceinline__ void sigma_backward(const float dS[9], const float R[
   drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
 }
 // --------------------------------------------------------------------------------------------------------- K8
-// partials [P,12] from K7: (S1 = sum q dx, S2 = sum q dy, S3 = sum q dx^2, S4 = sum q dx dy, S5 = sum q dy^2,
+// partials [P,12] from K7: (S1 = sum q u, S2 = sum q v  [u = -(A dx + B dy), v = -(C dy + B dx)], S3 = sum q dx^2, S4 = sum q dx dy, S5 = sum q dy^2,
 //                          dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -), q = dL/dG * G
 template <int KT, bool SCENE = false, typename TAB = NoScene, typename GTAB = NoScene>
 __global__ void __launch_bounds__(256)

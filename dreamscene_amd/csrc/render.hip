@@ -565,7 +565,7 @@ render_fwd_tile_body(const uint32_t item, const int W, const int H, const uint32
 // Transposed butterfly over the 64 lanes for 10 values (see file header): at every step a lane keeps one register of
 // a pair and hands the other one to its partner, so the number of live registers halves while the sums grow
 // (10 -> 5 by permlane32 swap, -> 3 by permlane16 swap, -> 2 by row_ror:8 = lane ^ 8, -> 1 by row_half_mirror =
-// lane ^ 7, then quad_perm xor 2 and xor 1: 8, 7, 2, 1 span the 16 lanes of a row). 25 VALU ops. On return lane L of
+// lane ^ 7, then quad_perm xor 2 and xor 1: 8, 7, 2, 1 span the 16 lanes of a row). 23 VALU ops. On return lane L of
 // row r = L >> 4 holds the wave total of component 4 w + ((r & 1) << 1 | (r >> 1)), where w = 2 if L & 4, else
 // 1 if L & 8, else 0:
 //   w = 0: rows -> v0 v2 v1 v3     w = 1: rows -> v4 v6 v5 v7     w = 2: rows -> v8 (pad) v9 (pad)
@@ -584,18 +584,39 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
   const float c67 = add_swap32(v[6], v[7]);
   const float c89 = add_swap32(v[8], v[9]);
   const float A = add_swap16(c01, c23), B = add_swap16(c45, c67), C = add_swap16(c89, 0.f);
-  const bool b8 = lane & 8, b4 = lane & 4;
-  const float AB = (b8 ? B : A) + gsr_dpp<0x128>(b8 ? A : B);      // row_ror:8: lane ^ 8
-  const float Cp = C + gsr_dpp<0x128>(C);
-  float R = (b4 ? Cp : AB) + gsr_dpp<0x141>(b4 ? AB : Cp);         // row_half_mirror: lane ^ 7
-  R += gsr_dpp<0x4E>(R);                                           // quad_perm [2,3,0,1]
-  R += gsr_dpp<0xB1>(R);                                           // quad_perm [1,0,3,2]
+  // 3 -> 2 -> 1 registers inside the 16-lane rows. Which register a lane keeps depends on a lane bit that is also a
+  // BANK of the row (lanes 4i..4i+3), so the "select, then add the partner's other register" of each step is two DPP adds
+  // with complementary bank masks (a bank-masked DPP write leaves the other lanes' destination alone) instead of two
+  // v_cndmask + one DPP add:   lanes 0-7 of a row: AB = A + A[lane ^ 8];  lanes 8-15: AB = B + B[lane ^ 8]
+  //                            lanes with bit 2 clear: R = AB + AB[lane ^ 7];  set: R = Cp + Cp[lane ^ 7]
+  // (s_nop 1: the inputs come straight from VALU instructions and a DPP operand needs two wait states after its producer;
+  //  the hazard recognizer does not look inside an asm block)
+  float AB, Cp, R;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(AB), "=&v"(Cp), "=&v"(R)
+      : "v"(A), "v"(B), "v"(C));
+  (void)lane;
   return R;
 }
 
 // Accumulates into partials [P,12], with q = dL/dG * G per (pixel, splat) and d = centre - pixel:
-//   (sum q dx, sum q dy, sum q dx^2, sum q dx dy, sum q dy^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
-// (K8 converts the five moments into dL/dmean2D and dL/dconic: they are linear in them with per-splat factors).
+//   (sum q u, sum q v, sum q dx^2, sum q dx dy, sum q dy^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
+// with u = -(A dx + B dy) = (dG/ddx) / G and v = -(C dy + B dx): the mean gradient is contracted with the conic PER
+// PIXEL, as the scalar oracle does (gsr_oracle.c, orc_pixel_bwd). Summing the raw first moments sum q dx, sum q dy and
+// contracting afterwards (rounds 1-2) cancels digits on needle-shaped splats (A dx and B dy of opposite sign and equal
+// size over the whole footprint: 1.4e-4 relative error where the oracle itself has 4e-5) -- what the reference's scale
+// noise + clamp(.., 0) produces (scene_gaussian.py:1005-1008). K8 only scales the two sums by 0.5 W / 0.5 H; the three
+// second moments give dL/dconic (linear in them with per-splat factors).
 //
 // Work item = (tile, segment): the <= 256 list entries [256 s, min(256 (s+1), tile_depth)) of one tile, for all of
 // its 256 pixels, traversed back to front. The reverse traversal of a pixel is a serial recurrence over its whole
@@ -720,8 +741,10 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       }
       float v[10];
       {
+        // u = -(A dx + B dy) = fma(2 hA, dx, nB dy), v = -(C dy + B dx) = fma(2 hC, dy, nB dx)  (hA = -A/2, nB = -B)
+        const float u = __fmaf_rn(a.z + a.z, dx, a.w * dy), w2 = __fmaf_rn(b.x + b.x, dy, a.w * dx);
         const float m1 = qv * dx, m2 = qv * dy;
-        v[0] = m1; v[1] = m2;
+        v[0] = qv * u; v[1] = qv * w2;
         v[2] = m1 * dx; v[3] = m1 * dy; v[4] = m2 * dy;
         v[5] = gdl;
         v[6] = wv * gC0; v[7] = wv * gC1; v[8] = wv * gC2;

@@ -42,6 +42,7 @@ from . import views as VW
 
 WARM_CALLS = 2          # eager calls (they learn the pair counts) before the first capture
 MAX_DIRECT_GRAPHS = 4   # backward graphs captured over callers' gradient addresses (beyond that: copy + the static one)
+PTR_MISSES_TO_STAGE = 2  # consecutive captures invalidated by nothing but new input ADDRESSES before the inputs are staged
 
 
 class _Captured:
@@ -49,10 +50,14 @@ class _Captured:
     pass
 
 
-def _sig(settings_list, tensors, rc, per_view):
+def _sig(settings_list, tensors, rc, per_view, by_ptr=True):
+    """What a capture is valid for. by_ptr: the graphs read the caller's parameter tensors in place (persistent leaves:
+    zero copies), so their addresses are part of the key; otherwise (staged inputs) only their shapes are. Everything that
+    is baked into the captured structs belongs here: `prefiltered` and the forward variant included."""
     s0 = settings_list[0]
     return (len(settings_list), int(s0.image_height), int(s0.image_width), float(s0.scale_modifier), per_view,
-            tuple((t.data_ptr(), tuple(t.shape)) if t is not None else None for t in tensors),
+            tuple(((t.data_ptr() if by_ptr else 0), tuple(t.shape)) if t is not None else None for t in tensors),
+            tuple(bool(s.prefiltered) for s in settings_list), rc.fwd_variant,
             id(rc.grad_arena), bool(rc.accumulate), rc.score_mode,
             tuple(t.data_ptr() for t in rc.densify_stats) if rc.densify_stats is not None else None,
             tuple(rc.stats_views) if isinstance(rc.stats_views, (list, tuple)) else rc.stats_views)
@@ -63,6 +68,7 @@ class _CapturedFn(torch.autograd.Function):
     def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, owner, settings_list, rc):
         outs, cap_state, eager_states = owner._forward(settings_list, means3D, opacities, shs, scales, rotations, rc)
         ctx.owner, ctx.rc, ctx.cap_state, ctx.eager_states = owner, rc, cap_state, eager_states
+        ctx.generation = cap_state.generation if cap_state is not None else -1
         ctx.opac_shape = opacities.shape
         ctx.per_view_scales = scales.dim() == 3
         ctx.set_materialize_grads(False)
@@ -74,6 +80,15 @@ class _CapturedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        cap = ctx.cap_state
+        if cap is not None and cap.generation != ctx.generation:
+            # the static forward state / outputs of a capture belong to its LATEST replay: a backward of an earlier call
+            # (gradient accumulation over two forwards, retain_graph, an eval render in between) would silently use the
+            # later step's state -- the eager path's version check has no equivalent here, so refuse
+            raise RuntimeError(
+                "CapturedViews: backward of a forward whose captured state has been overwritten by a later forward "
+                f"(replay {ctx.generation}, now {cap.generation}); run backward before the next forward of the same "
+                "CapturedViews, or use GaussianRasterizerViews for calls whose graphs must stay alive")
         o = ctx.owner._backward(ctx.cap_state, ctx.eager_states, grads, ctx.rc, ctx.per_view_scales)
         if ctx.rc.grad_arena is not None:
             return (None, o["dL_dmeans2D"], None, None, o["dL_dscales"] if ctx.per_view_scales else None, None,
@@ -92,9 +107,11 @@ class CapturedViews(torch.nn.Module):
         self.headroom = float(headroom)
         self._cap: Optional[_Captured] = None
         self._warm = 0
+        self._staged = False        # inputs copied into static buffers owned by the capture (see _forward)
+        self._ptr_misses = 0
         self._peak_n = 0
         self._fwd_mode = 0
-        self.stats = dict(captures=0, replays=0, eager_steps=0, overflows=0)
+        self.stats = dict(captures=0, replays=0, eager_steps=0, overflows=0, staged_inputs=False)
 
     # ------------------------------------------------------------------------------------------------ public
     def forward(self, raster_settings_list: Sequence, means3D, means2D, opacities, shs, scales, rotations) -> List[tuple]:
@@ -129,14 +146,30 @@ class CapturedViews(torch.nn.Module):
         for t in persistent + ((scales,) if per_view else ()):
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise ValueError("CapturedViews inputs must be contiguous fp32 tensors")
-        sig = _sig(settings_list, persistent, rc, per_view) + (tuple(scales.shape),)
+        # A capture reads the caller's parameter tensors IN PLACE (persistent leaves, updated in place by the optimizer:
+        # nothing is copied) and is therefore keyed on their addresses. Callers that hand over fresh tensors every step
+        # -- the reference's trainers pass activations: get_features is a torch.cat, get_opacity a sigmoid, get_scaling an
+        # exp (gs_renderer.py:464-488) -- can never repeat an address the capture itself keeps alive, and every miss
+        # would be a full re-capture. After PTR_MISSES_TO_STAGE captures lost to nothing but new addresses the inputs are
+        # STAGED instead: copied into static buffers owned by the capture (one fused copy, 236 B per Gaussian at K = 16)
+        # and the capture is keyed on shapes only.
+        shape_sig = _sig(settings_list, persistent, rc, per_view, by_ptr=False) + (tuple(scales.shape),)
+        sig = shape_sig if self._staged else _sig(settings_list, persistent, rc, per_view) + (tuple(scales.shape),)
         cap = self._cap
         if cap is None or cap.sig != sig:
+            if cap is not None and not self._staged and cap.shape_sig == shape_sig:
+                self._ptr_misses += 1
+                if self._ptr_misses >= PTR_MISSES_TO_STAGE:
+                    self._staged, sig = True, shape_sig
+                    self.stats["staged_inputs"] = True
             self._cap = cap = None
             if self._warm < WARM_CALLS or int(means3D.shape[0]) == 0:
                 self._warm += 1
                 return self._eager_forward(settings_list, means3D, opacities, shs, scales, rotations, rc)
             self._cap = cap = self._capture(sig, settings_list, means3D, opacities, shs, scales, rotations, rc, per_view)
+            cap.shape_sig = shape_sig
+        elif not self._staged:
+            self._ptr_misses = 0
         lib = L.load()
         V = len(settings_list)
         stream = torch.cuda.current_stream(dev)
@@ -144,9 +177,12 @@ class CapturedViews(torch.nn.Module):
             # this step's cameras -> the packed block the captured views point into (one small launch)
             structs = (L.GsrView * V)(*[self._user_view(s, cap.P, cap.K, rc) for s in settings_list])
             L.check(lib.gsr_pack_views(V, structs, cap.packed.data_ptr(), stream.cuda_stream), "gsr_pack_views")
-            if per_view:
+            if cap.staged is not None:
+                torch._foreach_copy_(cap.staged, [means3D, opacities, shs, rotations, scales])
+            elif per_view:
                 cap.scales.copy_(scales)
             cap.pinned_np[:] = -1
+            cap.generation += 1
             cap.gF.replay()
             cap.evF.record(stream)
             # The pair counts land in the pinned words when the column-count kernel of the projection phase has run -- a
@@ -174,6 +210,8 @@ class CapturedViews(torch.nn.Module):
         return cap.outs, cap, None
 
     def _user_view(self, s, P, K, rc):
+        if (int(s.sh_degree) + 1) ** 2 > K:     # the eager path answers GSR_EINVAL; a replay must not clamp silently
+            raise ValueError(f"sh_degree {int(s.sh_degree)} needs {(int(s.sh_degree) + 1) ** 2} SH coefficients, shs holds {K}")
         dev = s.viewmatrix.device
         f = lambda t, n: R._prep(t.reshape(-1), n, dev, align=4)
         bg, vm, pm, cp = f(s.bg, "bg"), f(s.viewmatrix, "viewmatrix"), f(s.projmatrix, "projmatrix"), f(s.campos, "campos")
@@ -196,7 +234,14 @@ class CapturedViews(torch.nn.Module):
         with torch.cuda.device(dev):
             cap.packed = torch.zeros((V, L.GSR_PACKED_VIEW_FLOATS), dtype=f32, device=dev)
             cap.pinned = torch.zeros(VW.MAX_VIEWS, dtype=torch.int64).pin_memory()
-            cap.scales = torch.empty_like(scales) if per_view else scales
+            cap.generation = 0
+            cap.staged = None
+            if self._staged:
+                # static copies of every input; the captured structs point at them
+                cap.staged = [torch.empty_like(t) for t in (means3D, opacities, shs, rotations, scales)]
+                torch._foreach_copy_(cap.staged, [means3D, opacities, shs, rotations, scales])
+                means3D, opacities, shs, rotations, scales = cap.staged
+            cap.scales = scales if (self._staged or not per_view) else torch.empty_like(scales)
             # the captured views: their camera tensors are slices of the packed block, tanfov / SH degree come from it too
             views = []
             for k, s in enumerate(settings_list):
@@ -224,7 +269,7 @@ class CapturedViews(torch.nn.Module):
             structs = (L.GsrView * V)(*[self._user_view(s, P, K, rc) for s in settings_list])
             cur = torch.cuda.current_stream(dev)
             L.check(lib.gsr_pack_views(V, structs, cap.packed.data_ptr(), cur.cuda_stream), "gsr_pack_views")
-            if per_view:
+            if per_view and cap.staged is None:
                 cap.scales.copy_(scales)
             torch.cuda.synchronize(dev)
             cap.gF, cap.gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

@@ -325,22 +325,45 @@ def shard_views(n_views: int, rank: int, world: int):
     return [i for i in range(n_views) if i % world == rank]
 
 
+def _accepts_accumulate(fn) -> bool:
+    """Does the per-view callback take the `accumulate` argument (by name, as a fifth positional, or through **kwargs)?"""
+    import inspect
+    try:
+        ps = list(inspect.signature(fn).parameters.values())
+    except (TypeError, ValueError):
+        return True
+    if any(p.kind is p.VAR_KEYWORD or p.name == "accumulate" for p in ps):
+        return True
+    return False
+
+
 def render_views_data_parallel(rasterize_view, params: Dict[str, torch.Tensor], cameras, upstream, arena: GradArena,
                                group=None, exchange: Optional[GradExchange] = None):
     """Render this rank's share of `cameras` (fwd+bwd) and leave the SUM over all views of every parameter
     gradient in `arena` on every rank.
 
-    rasterize_view(params, camera, grad_out, upstream, accumulate) runs one view forward+backward and writes that view's
-    parameter gradients into the tensors of grad_out (the arena's views): overwriting them when accumulate is False,
-    ADDING to them when it is True -- K8's accumulate mode (RasterContext.accumulate): the sum over a rank's views is
+    rasterize_view(params, camera, grad_out, upstream, accumulate=...) runs one view forward+backward and writes that
+    view's parameter gradients into the tensors of grad_out (the arena's views): overwriting them when accumulate is
+    False, ADDING to them when it is True (the argument is passed BY KEYWORD; a callback without a parameter of that
+    name is taken to overwrite always and the sum over the rank's views is then formed here on the host side) -- K8's accumulate mode (RasterContext.accumulate): the sum over a rank's views is
     formed on the device by the kernel that produces the gradients, no extra pass over the arena.
     Equivalent, to fp32 summation order, to the sequential accumulation the reference performs."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     mine = shard_views(len(cameras), rank, world)
     outs = []
+    # A callback written against the earlier contract takes four arguments and always OVERWRITES grad_out: for those the
+    # sum over this rank's views is formed here (clone + add per extra view), as it was before K8 learnt to accumulate.
+    takes_accumulate = _accepts_accumulate(rasterize_view)
     for j, vi in enumerate(mine):
-        outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi], j > 0))
+        if takes_accumulate:
+            outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi], accumulate=j > 0))
+        elif j == 0:
+            outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi]))
+        else:
+            held = arena.flat.clone()
+            outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi]))
+            arena.flat.add_(held)
     if not mine:
         arena.flat.zero_()
     if exchange is not None:

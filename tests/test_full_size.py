@@ -32,19 +32,32 @@ CONFIGS = {
     # before T < 1e-4 stops a pixel (SURVEY.md section 8d "init" variant)
     "C2-init": dict(scene="object", P=100_000, res=512, K=16, D=3, cams=[0], init_opacity=True),
     "C3-init": dict(scene="object", P=500_000, res=1024, K=16, D=3, cams=[0], init_opacity=True),
+    # what the reference's training augmentation hands the rasterizer (scene_gaussian.py:1005-1008): per-axis scale noise
+    # s + n * (sqrt(0.2) s / 4), then clamp(.., 0.0) -- some axes collapse to EXACTLY zero (flat / needle-shaped splats
+    # whose conic is ill-conditioned), on top of a share of strongly anisotropic ones
+    "C2-needles": dict(scene="object", P=100_000, res=512, K=16, D=3, cams=[0], needles=True),
 }
 _scene_cache = {}
 
 
 def _scene(cfg):
     from dreamscene_amd import synth
-    key = (cfg["scene"], cfg["P"], bool(cfg.get("init_opacity")))
+    key = (cfg["scene"], cfg["P"], bool(cfg.get("init_opacity")), bool(cfg.get("needles")))
     if key not in _scene_cache:
         _scene_cache.clear()          # one full-size scene at a time on the host
         if cfg["scene"] == "object":
             _scene_cache[key] = synth.g_object(cfg["P"], seed=0, K=cfg["K"], init_opacity=bool(cfg.get("init_opacity")))
         else:
             _scene_cache[key] = synth.g_indoor(seed=0, per_wall=cfg["P"] // 5, K=cfg["K"])
+        if cfg.get("needles"):
+            g = _scene_cache[key]
+            rng = np.random.default_rng(77)
+            s = g["scales"].astype(np.float32)
+            s[::7, 1] *= 0.01                                     # 1 : 100 needles / flat discs
+            s[3::11, 0] *= 10.0                                   # long streaks across many tiles
+            noise = rng.standard_normal(s.shape).astype(np.float32) * 8.0   # 8x the trainers' sigma: ~13 % of the axes clamp to 0
+            g["scales"] = np.maximum(s + noise * (np.float32(np.sqrt(0.2)) * s / 4.0), 0.0).astype(np.float32)
+            assert (g["scales"] == 0.0).mean() > 0.05
     g = _scene_cache[key]
     H = W = cfg["res"]
     cams = (synth.object_cameras if cfg["scene"] == "object" else synth.indoor_cameras)(8, H, W)
