@@ -97,11 +97,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GSR_BENCH_BACKEND=gloo + GSR_BENCH_SHARE_GPU=1: every rank on cuda:0 with the gloo backend -- lets the whole
+    # multi-rank control flow (view sharding, arena, exchange, barriers, max over ranks) run on a ONE-GPU box
+    # (tests/test_multirank_gpu.py); RCCL refuses two ranks on one device. Not a measurement configuration.
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    share_gpu = os.environ.get("GSR_BENCH_SHARE_GPU", "0") == "1"
+    dev = torch.device("cuda", 0 if share_gpu else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(dev)
+
+    def allreduce_scalars(vals, op):
+        """Small host-side reductions of the harness (timings, decisions) -- through the host under gloo."""
+        tt = torch.tensor(vals, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=op)
+        return [float(x) for x in tt.tolist()]
 
     from dreamscene_amd import _lib, multiview, rasterizer as R, synth
     from dreamscene_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, RasterContext
@@ -232,9 +246,8 @@ def main():
             sync()
             rates[flag] = 15 * V / (time.perf_counter() - tp)
         if world > 1:      # every rank must take the same decision
-            tt = torch.tensor([rates[False], rates[True]], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
-            rates = {False: float(tt[0]), True: float(tt[1])}
+            lo = allreduce_scalars([rates[False], rates[True]], dist.ReduceOp.MIN)
+            rates = {False: lo[0], True: lo[1]}
         use_capture[0] = rates[True] > rates[False]
         capture_probe = {"eager_views_per_s": round(rates[False], 1), "captured_views_per_s": round(rates[True], 1)}
     captured = bool(use_capture[0])
@@ -269,9 +282,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = allreduce_scalars([elapsed], dist.ReduceOp.MAX)[0]
 
     # the drop-in figure: the same views through one GaussianRasterizer call per view (untimed w.r.t. `value`)
     dropin = None

@@ -300,7 +300,7 @@ k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x,
   ids[lane] = in ? sorted_idx[s0 + lane] : 0u;
   mg[lane] = w > 1 ? 0xFFFFFFFFu / w + 1u : 0u;   // floor(q / w) == umulhi(q, mg) for q < 2^16, w <= 256
   __syncthreads();
-  volatile uint32_t* run = col_run;
+  uint32_t* run = col_run;
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (uint32_t q0 = 0; q0 < total; q0 += 64) {
     const uint32_t q = q0 + (uint32_t)lane;
@@ -325,6 +325,7 @@ k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x,
     old = (uint32_t)__shfl((int)old, valid ? leader : lane, 64);
     const uint32_t p = old + (uint32_t)__popcll(m & lt);
     if (valid && p < cap) vals[p] = gid | (ty << 24);
+    GSR_LDS_ORDER();
   }
 }
 
@@ -451,7 +452,7 @@ k_row_scatter(const uint32_t* __restrict__ vals_in, const RowOut ro, const uint3
     reinterpret_cast<uint2*>(ranges)[(uint32_t)tid * (uint32_t)gx + cb.col] = rg;
   }
   if (cb.base >= cb.end) return;
-  volatile uint32_t* mywh = wh[wave];
+  uint32_t* mywh = wh[wave];
   uint32_t val[kPass2Items];   // ty << 24 | Gaussian index; 0xFFFFFFFF = no element (index 0xFFFFFF never occurs)
   uint32_t rank[kPass2Items];
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -473,6 +474,7 @@ k_row_scatter(const uint32_t* __restrict__ vals_in, const RowOut ro, const uint3
     }
     old = (uint32_t)__shfl((int)old, valid ? leader : lane, 64);
     rank[it] = old + (uint32_t)__popcll(m & lt);
+    GSR_LDS_ORDER();
   }
   __syncthreads();
   {
@@ -521,7 +523,7 @@ static uint32_t col_runs(int32_t P) { return (uint32_t)(((P > 0 ? P : 1) + kColR
 // packed tile rectangles and the per-run column histogram of the column path.
 extern "C" size_t gsr_project_scratch_bytes(int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
-  return 5 * align256(m * 4) + align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4) + align256(kRadix * 4) +
+  return 5 * align256(m * 4) + sort_hist_bytes(m, kItemsSmall, kOsItemsSmall) + align256(kRadix * 4) +
          align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + align256(264 * 4) + 256 + 1024;
 }
 
@@ -529,7 +531,7 @@ extern "C" size_t gsr_project_scratch_bytes(int32_t P) {
 extern "C" size_t gsr_sort_scratch_bytes(uint64_t n, uint32_t n_tiles) {
   (void)n_tiles;
   const uint64_t m = n ? n : 1;
-  return 3 * align256(m * 4) + align256((size_t)kRadix * (sort_blocks(m, kItemsLarge) + 260) * 4) +
+  return 3 * align256(m * 4) + sort_hist_bytes(m, kItemsLarge, kItemsLarge) + align256((size_t)kRadix * 260 * 4) +
          align256(kRadix * 4) + 1024;
 }
 
@@ -545,7 +547,7 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
   s.k1 = (uint32_t*)b; b += align256(m * 4);
   s.v0 = (uint32_t*)b; b += align256(m * 4);
   s.v1 = (uint32_t*)b; b += align256(m * 4);
-  s.hist = (uint32_t*)b; b += align256((size_t)kRadix * sort_blocks(m, kItemsSmall) * 4);
+  s.hist = (uint32_t*)b; b += sort_hist_bytes(m, kItemsSmall, kOsItemsSmall);
   s.totals = (uint32_t*)b; b += align256(kRadix * 4);
   s.rects = (uint32_t*)b; b += align256(m * 4);
   s.hist1 = (uint32_t*)b; b += align256((size_t)256 * col_runs((int32_t)m) * 4);
@@ -576,7 +578,7 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
   int where;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    where = radix_sort_u32<kItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
+    where = radix_sort_u32<kItemsSmall, kOsItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
                                         s.totals, stream, batch, bstride);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
@@ -693,7 +695,7 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
   uint32_t* keys_a = (uint32_t*)base; base += align256(cap * 4);
   uint32_t* keys_b = (uint32_t*)base; base += align256(cap * 4);
   uint32_t* vals_t = (uint32_t*)base; base += align256(cap * 4);
-  uint32_t* hist = (uint32_t*)base; base += align256((size_t)kRadix * sort_blocks(cap, kItemsLarge) * 4);
+  uint32_t* hist = (uint32_t*)base; base += sort_hist_bytes(cap, kItemsLarge, kItemsLarge);
   uint32_t* totals = (uint32_t*)base;
 
   int tile_bits = 0;
@@ -713,7 +715,7 @@ int gsr_launch_binning(const GsrView& v, const GsrGeom& geom, uint64_t cap, cons
   uint32_t* sorted_keys;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    const int where = radix_sort_u32<kItemsLarge>(keys_a, va, keys_b, vb, n_dev, cap, tile_bits, false, nullptr, hist,
+    const int where = radix_sort_u32<kItemsLarge, kItemsLarge>(keys_a, va, keys_b, vb, n_dev, cap, tile_bits, false, nullptr, hist,
                                                    totals, stream);
     sorted_keys = where ? keys_b : keys_a;
     GSR_HIP(hipGetLastError());

@@ -166,7 +166,7 @@ extern "C" size_t gsr_knn_scratch_bytes(int32_t n) {
   const size_t cells = (size_t)kMaxR * kMaxR * kMaxR;
   const uint64_t r = (uint64_t)cbrt(0.5 * (double)m) + 1;
   const size_t rc = (size_t)std::min<uint64_t>(r * r * r, cells);
-  return 4 * align256(m * 4) + align256((size_t)256 * sort_blocks(m, kItemsSmall) * 4) + align256(256 * 4) +
+  return 4 * align256(m * 4) + sort_hist_bytes(m, kItemsSmall, kOsItemsSmall) + align256(256 * 4) +
          align256(rc * 8) + 256 + 1024;
 }
 
@@ -185,7 +185,7 @@ extern "C" int gsr_knn_mean_dist2(const float* points, int32_t n, float* out, vo
   uint32_t* k1 = (uint32_t*)b; b += align256(m * 4);
   uint32_t* v0 = (uint32_t*)b; b += align256(m * 4);
   uint32_t* v1 = (uint32_t*)b; b += align256(m * 4);
-  uint32_t* hist = (uint32_t*)b; b += align256((size_t)256 * sort_blocks(m, kItemsSmall) * 4);
+  uint32_t* hist = (uint32_t*)b; b += sort_hist_bytes(m, kItemsSmall, kOsItemsSmall);
   uint32_t* totals = (uint32_t*)b; b += align256(256 * 4);
   int* bbox = (int*)b; b += 256;
   uint32_t* ranges = (uint32_t*)b;
@@ -198,7 +198,7 @@ extern "C" int gsr_knn_mean_dist2(const float* points, int32_t n, float* out, vo
   const int nb = (n + 255) / 256;
   hipLaunchKernelGGL(k_knn_bbox, dim3(std::min(nb, 1024)), dim3(256), 0, stream, points, n, bbox);
   hipLaunchKernelGGL(k_knn_cells, dim3(nb), dim3(256), 0, stream, points, n, bbox, k0);
-  const int where = radix_sort_u32<kItemsSmall>(k0, v0, k1, v1, nullptr, m, 24, true, nullptr, hist, totals, stream);
+  const int where = radix_sort_u32<kItemsSmall, kOsItemsSmall>(k0, v0, k1, v1, nullptr, m, 24, true, nullptr, hist, totals, stream);
   const uint32_t* sk = where ? k1 : k0;
   const uint32_t* sv = where ? v1 : v0;
   hipLaunchKernelGGL(k_knn_ranges, dim3(nb), dim3(256), 0, stream, sk, n, ranges);

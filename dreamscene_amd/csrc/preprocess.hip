@@ -847,17 +847,18 @@ __device__ __forceinline__ void geom_backward(const ViewConst& vc, const Ewa& e,
                                               float dS[9], float dp[3], float dview[12], float dproj[12]) {
   const float* V = vc.V;
   const float* PV = vc.PV;
-  // (2a) K7's sums -> dL/d(ndc xy) and dL/dconic: power = -1/2 (A dx^2 + C dy^2) - B dx dy, dG/ddx = -G (A dx + B dy).
-  // S1 = sum q (dG/ddx)/G and S2 = sum q (dG/ddy)/G arrive contracted with the conic per pixel (render.hip, K7)
+  // (2) K7's sums -> dL/d(ndc xy) and dL/dcov2D. With d = centre - pixel, (u, v) = -conic d and q = dL/dG G per pixel:
+  // S1 = sum q u, S2 = sum q v are dL/d(pixel centre); dL/dSigma = 1/2 sum q (conic d)(conic d)^T, i.e. S3 = sum q u^2,
+  // S4 = sum q u v, S5 = sum q v^2 are the covariance gradient up to the factors below -- K7 forms them per pixel
+  // (render.hip). The lineage goes through dL/dconic and divides by det^2 + 1e-7 instead of det^2: the factor
+  // det^2 / (det^2 + 1e-7) keeps that regulariser (SEMANTICS.md section 5).
   const float ca = e.ca, cb = e.cb, cc = e.cc;
   gndx = S1 * (0.5f * (float)W);
   gndy = S2 * (0.5f * (float)H);
-  const float gca = -0.5f * S3, gcb = -S4, gcc = -0.5f * S5;
-  // (2b) conic -> cov2D (lineage denominator det^2 + 1e-7)
-  const float d2i = 1.0f / (e.det * e.det + 0.0000001f);
-  const float dca = d2i * ((-cc * cc * gca + cb * cc * gcb) - cb * cb * gcc);
-  const float dcc = d2i * ((-cb * cb * gca + cb * ca * gcb) - ca * ca * gcc);
-  const float dcb = d2i * ((2.0f * cb * cc * gca - (e.det + 2.0f * cb * cb) * gcb) + 2.0f * cb * ca * gcc);
+  const float det2 = e.det * e.det;
+  const float reg = det2 * (1.0f / (det2 + 0.0000001f));
+  const float dca = (0.5f * S3) * reg, dcb = S4 * reg, dcc = (0.5f * S5) * reg;
+  (void)ca; (void)cb; (void)cc;
   // (3) cov2D = M Sigma M^T
   const float h = 0.5f * dcb;
 #pragma unroll
@@ -944,7 +945,7 @@ __device__ __forceinline__ void sigma_backward(const float dS[9], const float R[
   drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
 }
 // --------------------------------------------------------------------------------------------------------- K8
-// partials [P,12] from K7: (S1 = sum q u, S2 = sum q v  [u = -(A dx + B dy), v = -(C dy + B dx)], S3 = sum q dx^2, S4 = sum q dx dy, S5 = sum q dy^2,
+// partials [P,12] from K7: (S1 = sum q u, S2 = sum q v, S3 = sum q u^2, S4 = sum q u v, S5 = sum q v^2  [(u, v) = -conic d],
 //                          dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -), q = dL/dG * G
 template <int KT, bool SCENE = false, typename TAB = NoScene, typename GTAB = NoScene>
 __global__ void __launch_bounds__(256)

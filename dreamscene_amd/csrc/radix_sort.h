@@ -2,6 +2,7 @@
 // (binning.hip) and the k-nearest-neighbour grid (knn.hip). See binning.hip for the design notes.
 #pragma once
 #include "gsr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -12,10 +13,17 @@ constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 
 // Batched launches (several views at once): blockIdx.y selects the view, whose buffers sit `bstride` bytes further.
+// (byte arithmetic on the pointer itself, not through an integer: the compiler then still knows the address is GLOBAL and
+//  emits global_load / global_store -- a round trip through uintptr_t gave flat_* accesses, which count against both
+//  memory counters and serialise with the LDS traffic of the same wave)
 template <typename T>
 __device__ __forceinline__ T* batch_ptr(T* p, size_t bstride) {
-  return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.y * bstride) : p;
+  typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+  return p ? reinterpret_cast<T*>(reinterpret_cast<B*>(p) + (size_t)blockIdx.y * bstride) : p;
 }
+// Wave-private LDS counters updated by a leader lane and read by the wave's next step: LDS operations of one wave execute
+// in program order, so ordinary accesses separated by a compiler barrier are enough (`volatile` made them flat_* sc0 sc1)
+#define GSR_LDS_ORDER() asm volatile("" ::: "memory")
 
 __device__ __forceinline__ uint64_t eff_count(const uint64_t* n_dev, uint64_t cap) {
   if (!n_dev) return cap;
@@ -159,7 +167,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     if (DROP && n_out && blockIdx.x == 0 && tid == kSortThreads - 1) *n_out = (uint64_t)(woff + inc);   // survivors
   }
   __syncthreads();
-  volatile uint32_t* mywh = wh[wave];
+  uint32_t* mywh = wh[wave];
   uint32_t key[ITEMS];
   uint32_t val[ITEMS];
   uint32_t rank[ITEMS];
@@ -188,6 +196,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     }
     old = (uint32_t)__shfl((int)old, valid ? leader : lane, 64);
     rank[it] = old + (uint32_t)__popcll(m & lt);
+    GSR_LDS_ORDER();
   }
   __syncthreads();
   {
@@ -211,6 +220,225 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
   }
 }
 
+// ================================================================================= one-sweep passes (round 3)
+// The three-kernel pass above (histogram -> 256-row scan -> scatter) costs 12 dependent launches for a 32-bit key on a
+// few MB: launch-latency bound (157 us per 4-view step for 8 MB of keys). The one-sweep form needs
+// 2 + passes launches:
+//   k_os_hist   reads the keys ONCE and leaves the global digit histograms of ALL passes (a digit histogram does not
+//               depend on the order of the keys, so it is valid for every later pass; culled keys are not counted);
+//   k_os_pass   one launch per pass: a workgroup takes the next tile (a ticket: tiles start in ticket order, so every
+//               predecessor of a tile is running or done -- nothing below depends on the dispatch order or on where a
+//               workgroup runs), ranks its keys, publishes its per-digit counts and obtains the number of equal digits
+//               in all earlier tiles by DECOUPLED LOOK-BACK over the predecessors' published words; then it sorts the
+//               tile by digit in LDS and writes runs of consecutive positions (coalesced; the old scatter stored
+//               element by element).
+// Look-back words: one u32 per (tile, digit) = tag << 28 | value, tag = 2 pass + 1 (this tile's count: "aggregate") or
+// 2 pass + 2 (count of this and all earlier tiles: "inclusive"), 0 = nothing yet. The table is zeroed ONCE per sort (tags
+// tell the passes apart). Written and polled with relaxed agent-scope atomics ONLY -- a single aligned word is its own
+// flag, so no fence is needed (an agent-scope release fence writes the XCD's L2 back: measured 3.5x on K8 in round 2).
+// Values need 28 bits: sorts of 2^28 elements or more take the three-kernel passes.
+constexpr int kOsItemsSmall = 8;      // keys per thread, P-sized sorts (2048-key tiles)
+constexpr int kOsMaxPasses = 4;
+constexpr uint32_t kOsHistTile = 4096;  // keys per workgroup of k_os_hist
+constexpr uint32_t kOsTableOff = kOsMaxPasses * kRadix + 16;   // u32 words: [passes][256] histograms | 4 tickets (+ pad) | table
+constexpr uint64_t kOsMaxN = 1ull << 28;
+
+typedef __attribute__((address_space(1))) uint32_t gsr_gu32;
+__device__ __forceinline__ gsr_gu32* gsr_global(uint32_t* p) { return (gsr_gu32*)(uintptr_t)p; }
+
+__host__ __device__ inline uint32_t os_tiles(uint64_t n, int items) {
+  const uint64_t t = (uint64_t)kSortThreads * items;
+  return (uint32_t)((n + t - 1) / t);
+}
+// u32 words of the one-sweep state of a sort of up to n keys
+__host__ inline size_t os_state_words(uint64_t n, int items) { return (size_t)kOsTableOff + (size_t)kRadix * os_tiles(n, items); }
+
+template <bool DROP>
+__global__ void __launch_bounds__(kSortThreads)
+k_os_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev, uint64_t cap, int passes,
+          uint32_t* __restrict__ os, size_t bstride) {
+  keys = batch_ptr(keys, bstride); n_dev = batch_ptr(n_dev, bstride); os = batch_ptr(os, bstride);
+  __shared__ uint32_t h[kOsMaxPasses][kRadix];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint64_t n = eff_count(n_dev, cap);
+  const uint64_t base = (uint64_t)blockIdx.x * kOsHistTile;
+  if (base >= n) return;
+#pragma unroll
+  for (int p = 0; p < kOsMaxPasses; ++p) h[p][tid] = 0;
+  __syncthreads();
+  constexpr int kPer = kOsHistTile / kSortThreads;
+  uint32_t kk[kPer];
+#pragma unroll
+  for (int it = 0; it < kPer; ++it) {
+    const uint64_t e = base + (uint64_t)(it * kSortThreads + tid);
+    kk[it] = e < n ? keys[e] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int it = 0; it < kPer; ++it) {
+    const uint64_t e = base + (uint64_t)(it * kSortThreads + tid);
+    const bool valid = (e < n) && (!DROP || kk[it] != 0xFFFFFFFFu);
+    const unsigned long long vm = __ballot(valid);
+    if (vm == 0ull) continue;
+    const int first = __ffsll((long long)vm) - 1;
+    for (int p = 0; p < passes; ++p) {
+      const uint32_t d = (kk[it] >> (p * kRadixBits)) & (kRadix - 1);
+      // the high digits of depth bits / tile ids / cell ids are the same for the whole wave most of the time: one LDS
+      // atomic per wave then, instead of 64 on one address
+      const uint32_t d0 = (uint32_t)__shfl((int)d, first, 64);
+      if (__ballot(valid && d != d0) == 0ull) {
+        if (lane == first) atomicAdd(&h[p][d0], (uint32_t)__popcll(vm));
+      } else if (valid) {
+        atomicAdd(&h[p][d], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < passes; ++p) {
+    const uint32_t c = h[p][tid];
+    if (c) atomicAdd(&os[p * kRadix + tid], c);
+  }
+}
+
+template <bool IOTA, int ITEMS, bool DROP>
+__global__ void __launch_bounds__(kSortThreads)
+k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+          uint32_t* __restrict__ vals_out, const uint64_t* __restrict__ n_dev, uint64_t cap, int pass,
+          uint32_t* __restrict__ os, uint64_t* __restrict__ n_out, size_t bstride) {
+  keys_in = batch_ptr(keys_in, bstride); vals_in = batch_ptr(vals_in, bstride);
+  keys_out = batch_ptr(keys_out, bstride); vals_out = batch_ptr(vals_out, bstride);
+  n_dev = batch_ptr(n_dev, bstride); os = batch_ptr(os, bstride); n_out = batch_ptr(n_out, bstride);
+  constexpr uint32_t T = kSortThreads * ITEMS;
+  __shared__ uint32_t wh[4][kRadix];   // running per-wave digit counters, then the waves' offsets inside the tile's digit run
+  __shared__ uint32_t gbase[kRadix];   // global position of local position 0 of digit d's run (may wrap: used modulo 2^32)
+  __shared__ uint32_t skey[T], sval[T];
+  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t s_tile, s_ntile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int shift = pass * kRadixBits;
+  if (tid == 0) s_tile = atomicAdd(&os[kOsMaxPasses * kRadix + pass], 1u);      // the ticket: tiles START in this order
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint64_t n = eff_count(n_dev, cap);
+  if ((uint64_t)tile * T >= n) return;     // (every later ticket is beyond n as well: nobody waits for this tile)
+  // exclusive scan of the pass's global digit histogram: where digit d starts in the output
+  uint32_t dbase;
+  {
+    const uint32_t x = os[pass * kRadix + tid];
+    uint32_t inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wtot[w];
+    dbase = woff + inc - x;
+    if (DROP && n_out && tile == 0 && tid == kSortThreads - 1) *n_out = (uint64_t)(woff + inc);   // survivors
+  }
+  uint32_t* mywh = wh[wave];
+  uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const uint64_t e = sort_index<ITEMS>(tile, wave, it, lane);
+    const bool valid = e < n;
+    key[it] = valid ? keys_in[e] : 0xFFFFFFFFu;
+    val[it] = IOTA ? (uint32_t)e : (valid ? vals_in[e] : 0u);
+  }
+  const auto is_valid = [&](int it) {
+    const uint64_t e = sort_index<ITEMS>(tile, wave, it, lane);
+    return (e < n) && (!DROP || key[it] != 0xFFFFFFFFu);
+  };
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const bool valid = is_valid(it);
+    const uint32_t d = (key[it] >> shift) & (kRadix - 1);
+    const unsigned long long m = match_digit(d, valid);
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t old = 0;
+    if (valid && lane == leader) {
+      old = mywh[d];
+      mywh[d] = old + (uint32_t)__popcll(m);
+    }
+    old = (uint32_t)__shfl((int)old, valid ? leader : lane, 64);
+    rank[it] = old + (uint32_t)__popcll(m & lt);
+    GSR_LDS_ORDER();
+  }
+  __syncthreads();
+  // thread d: this tile's count of digit d, the waves' offsets inside the run, the run's start inside the tile
+  uint32_t cnt;
+  {
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = wh[w][tid];
+      wh[w][tid] = run;
+      run += c;
+    }
+    cnt = run;
+  }
+  // publish the count, then look back (thread d for digit d)
+  gsr_gu32* table = gsr_global(os + kOsTableOff);
+  const uint32_t tagA = (uint32_t)(2 * pass + 1) << 28, tagI = (uint32_t)(2 * pass + 2) << 28;
+  uint32_t excl = 0;
+  if (tile == 0) {
+    __hip_atomic_store(table + tid, tagI | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagA | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t p = tile - 1;
+    for (;;) {
+      const uint32_t w = __hip_atomic_load(table + (size_t)p * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t tag = w & 0xF0000000u;
+      if (tag == tagI) { excl += w & 0x0FFFFFFFu; break; }
+      if (tag == tagA) { excl += w & 0x0FFFFFFFu; --p; continue; }     // (tile 0 only ever publishes inclusive words)
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagI | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // start of digit d's run inside the tile: exclusive scan of cnt over the digits
+  uint32_t lstart;
+  {
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    __syncthreads();                       // (wtot is free again: everybody is past the first scan)
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wtot[w];
+    lstart = woff + inc - cnt;
+    if (tid == kSortThreads - 1) s_ntile = woff + inc;
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wh[w][tid] += lstart;        // wave w's first local position of digit d
+  gbase[tid] = dbase + excl - lstart;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    if (is_valid(it)) {
+      const uint32_t d = (key[it] >> shift) & (kRadix - 1);
+      const uint32_t lp = wh[wave][d] + rank[it];
+      skey[lp] = key[it];
+      sval[lp] = val[it];
+    }
+  }
+  __syncthreads();
+  const uint32_t ntile = s_ntile;
+  for (uint32_t i = tid; i < ntile; i += kSortThreads) {
+    const uint32_t k = skey[i];
+    const uint32_t pos = gbase[(k >> shift) & (kRadix - 1)] + i;
+    keys_out[pos] = k;
+    vals_out[pos] = sval[i];
+  }
+}
+
 __host__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 uint32_t sort_blocks(uint64_t n, int items) {
@@ -222,10 +450,62 @@ uint32_t sort_blocks(uint64_t n, int items) {
 // (k1,v1); returns 0 if the result is in (k0,v0), 1 if in (k1,v1). iota: values of the first pass are the element
 // indices. n_compact (device, may be NULL; only with iota): the first pass drops the elements keyed 0xFFFFFFFF and
 // stores the number of survivors there; the remaining passes (and the caller) work on that many elements.
+// bytes of the `hist` scratch region a sort of up to n keys needs (three-kernel passes or one-sweep state, whichever is larger)
+__host__ inline size_t sort_hist_bytes(uint64_t n, int items_legacy, int items_os) {
+  const size_t legacy = (size_t)kRadix * sort_blocks(n, items_legacy) * 4;
+  const size_t os = os_state_words(n, items_os) * 4;
+  return align256(legacy > os ? legacy : os);
+}
+
 template <int ITEMS>
+int radix_sort_u32_legacy(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
+                          int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream,
+                          int batch = 1, size_t bstride = 0);
+
+// One full LSD sort of (u32 key, u32 value) over the key bits [0, bits). Buffers ping-pong between (k0,v0) and
+// (k1,v1); returns 0 if the result is in (k0,v0), 1 if in (k1,v1). iota: values of the first pass are the element
+// indices. n_compact (device, may be NULL; only with iota): the first pass drops the elements keyed 0xFFFFFFFF and
+// stores the number of survivors there; the remaining passes (and the caller) work on that many elements.
+// hist: sort_hist_bytes(cap, ITEMS, OS_ITEMS) bytes; totals: kRadix words (three-kernel passes only).
+// 2 + passes launches (one-sweep, see above); sorts of 2^28 keys or more take the three-kernel passes.
+template <int ITEMS, int OS_ITEMS>
 int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
                    int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream,
                    int batch = 1, size_t bstride = 0) {
+  const int passes = (bits + kRadixBits - 1) / kRadixBits;
+  if (cap >= kOsMaxN || passes > kOsMaxPasses)
+    return radix_sort_u32_legacy<ITEMS>(k0, v0, k1, v1, n_dev, cap, bits, iota, n_compact, hist, totals, stream, batch, bstride);
+  const uint32_t ntile = os_tiles(cap, OS_ITEMS), nhist = (uint32_t)((cap + kOsHistTile - 1) / kOsHistTile);
+  const dim3 grid(ntile, (uint32_t)batch), grid_h(nhist ? nhist : 1, (uint32_t)batch);
+  if (gsr_zero_async(hist, os_state_words(cap, OS_ITEMS) * 4, stream, bstride, (uint32_t)batch) != hipSuccess) return passes & 1;
+  const bool drop = iota && n_compact;
+  if (drop)
+    hipLaunchKernelGGL((k_os_hist<true>), grid_h, dim3(kSortThreads), 0, stream, k0, n_dev, cap, passes, hist, bstride);
+  else
+    hipLaunchKernelGGL((k_os_hist<false>), grid_h, dim3(kSortThreads), 0, stream, k0, n_dev, cap, passes, hist, bstride);
+  uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
+  for (int p = 0; p < passes; ++p) {
+    if (p == 0 && drop) {
+      hipLaunchKernelGGL((k_os_pass<true, OS_ITEMS, true>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap, p,
+                         hist, n_compact, bstride);
+      n_dev = n_compact;
+    } else if (p == 0 && iota) {
+      hipLaunchKernelGGL((k_os_pass<true, OS_ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap, p,
+                         hist, (uint64_t*)nullptr, bstride);
+    } else {
+      hipLaunchKernelGGL((k_os_pass<false, OS_ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap, p,
+                         hist, (uint64_t*)nullptr, bstride);
+    }
+    uint32_t* t = ka; ka = kb; kb = t;
+    t = va; va = vb; vb = t;
+  }
+  return passes & 1;
+}
+
+template <int ITEMS>
+int radix_sort_u32_legacy(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
+                   int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream,
+                   int batch, size_t bstride) {
   const uint32_t nblk = sort_blocks(cap, ITEMS);
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
   const dim3 grid(nblk, (uint32_t)batch), grid_scan(kRadix, (uint32_t)batch);

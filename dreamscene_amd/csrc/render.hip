@@ -609,14 +609,17 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
   return R;
 }
 
-// Accumulates into partials [P,12], with q = dL/dG * G per (pixel, splat) and d = centre - pixel:
-//   (sum q u, sum q v, sum q dx^2, sum q dx dy, sum q dy^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
-// with u = -(A dx + B dy) = (dG/ddx) / G and v = -(C dy + B dx): the mean gradient is contracted with the conic PER
-// PIXEL, as the scalar oracle does (gsr_oracle.c, orc_pixel_bwd). Summing the raw first moments sum q dx, sum q dy and
-// contracting afterwards (rounds 1-2) cancels digits on needle-shaped splats (A dx and B dy of opposite sign and equal
-// size over the whole footprint: 1.4e-4 relative error where the oracle itself has 4e-5) -- what the reference's scale
-// noise + clamp(.., 0) produces (scene_gaussian.py:1005-1008). K8 only scales the two sums by 0.5 W / 0.5 H; the three
-// second moments give dL/dconic (linear in them with per-splat factors).
+// Accumulates into partials [P,12], with q = dL/dG * G per (pixel, splat), d = centre - pixel and (u, v) = -Sigma^-1 d =
+// (-(A dx + B dy), -(C dy + B dx)) (Sigma^-1 = the conic):
+//   (sum q u, sum q v, sum q u^2, sum q u v, sum q v^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
+// dG/dd = G (u, v), so the first two sums are dL/d(pixel centre), and dL/dSigma = 1/2 sum q (Sigma^-1 d)(Sigma^-1 d)^T, so
+// the other three are the gradient of the 2-D covariance itself (K8 only scales them) -- both formed PER PIXEL, as the
+// scalar oracle does (gsr_oracle.c, orc_pixel_bwd; SEMANTICS.md section 5). Rounds 1-2 summed the raw moments of d
+// (sum q dx, ..., sum q dy^2) and contracted them with the conic afterwards: exact in exact arithmetic, but the
+// contraction cancels digits on needle-shaped splats -- A dx and B dy are of opposite sign and equal size along the
+// needle -- and the lineage's conic -> covariance step amplifies the rounding of the sums by cond(Sigma)^2 (measured
+// against float64 autograd: 1e-1 on dL/dscales of 1000 : 1 splats, which the reference's scale noise + clamp(.., 0)
+// produces, scene_gaussian.py:1005-1008).
 //
 // Work item = (tile, segment): the <= 256 list entries [256 s, min(256 (s+1), tile_depth)) of one tile, for all of
 // its 256 pixels, traversed back to front. The reverse traversal of a pixel is a serial recurrence over its whole
@@ -741,11 +744,12 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       }
       float v[10];
       {
-        // u = -(A dx + B dy) = fma(2 hA, dx, nB dy), v = -(C dy + B dx) = fma(2 hC, dy, nB dx)  (hA = -A/2, nB = -B)
-        const float u = __fmaf_rn(a.z + a.z, dx, a.w * dy), w2 = __fmaf_rn(b.x + b.x, dy, a.w * dx);
-        const float m1 = qv * dx, m2 = qv * dy;
-        v[0] = qv * u; v[1] = qv * w2;
-        v[2] = m1 * dx; v[3] = m1 * dy; v[4] = m2 * dy;
+        // (u, v) = -Sigma^-1 d:  u = -(A dx + B dy) = fma(2 hA, dx, nB dy),  v = -(C dy + B dx) = fma(2 hC, dy, nB dx)
+        // (hA = -A/2, nB = -B, hC = -C/2: the doublings are exact; the same expression tree as orc_pixel_bwd)
+        const float u = __fmaf_rn(a.z + a.z, dx, gsr_mul(a.w, dy)), w2 = __fmaf_rn(b.x + b.x, dy, gsr_mul(a.w, dx));
+        const float m1 = qv * u, m2 = qv * w2;
+        v[0] = m1; v[1] = m2;
+        v[2] = m1 * u; v[3] = m1 * w2; v[4] = m2 * w2;
         v[5] = gdl;
         v[6] = wv * gC0; v[7] = wv * gC1; v[8] = wv * gC2;
         v[9] = wv * gD;

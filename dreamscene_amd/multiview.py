@@ -48,6 +48,31 @@ def allreduce_grads(arena: GradArena, group=None, async_op: bool = False):
     return dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+def _host_staged(group, *tensors) -> bool:
+    """gloo is the debugging / one-GPU-box backend here: its collectives take device tensors through the host."""
+    return dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors)
+
+
+def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    if _host_staged(group, out, inp):
+        W = dist.get_world_size(group)
+        parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(W)]
+        dist.all_gather(parts, inp.cpu(), group=group)
+        out.copy_(torch.cat([p.reshape(-1) for p in parts]).reshape(out.shape))
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _all_gather_list(outs, inp: torch.Tensor, group) -> None:
+    if _host_staged(group, inp):
+        parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in outs]
+        dist.all_gather(parts, inp.cpu(), group=group)
+        for o, p in zip(outs, parts):
+            o.copy_(p)
+    else:
+        dist.all_gather(outs, inp, group=group)
+
+
 class GradExchange:
     """Sum of the arena over the ranks of a step, moving only what can be non-zero.
 
@@ -161,8 +186,7 @@ class GradExchange:
         if mode in ("auto", "rows"):      # ("sparse_rs" counts per owner itself)
             idx = self.nonzero_rows()
             cnt = torch.empty(W, dtype=torch.int64, device=idx.device)
-            dist.all_gather_into_tensor(cnt, torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device),
-                                        group=self.group)
+            _all_gather_into(cnt, torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device), self.group)
             counts = [int(c) for c in cnt.tolist()]           # (the one host read of the exchange)
             if mode == "auto":
                 # received bytes: rows format sum_r n_r (4 + 4F) vs dense ring 2 (W-1)/W 4 F P (the same decision on every
@@ -175,7 +199,12 @@ class GradExchange:
                 mode = "rows" if use_rows else "dense"
         if mode == "dense":
             wire = self.wire_buffer()
-            dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
+            if _host_staged(self.group, wire):
+                host = wire.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                wire.copy_(host)
+            else:
+                dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
             self._unpack(wire)
             self.last = dict(format="dense", row_floats=F, bytes_per_rank=int(2 * (W - 1) / W * 4 * wire.numel()))
             return
@@ -208,8 +237,8 @@ class GradExchange:
             my_rows[:n] = self._rows_of(idx)
         all_idx = [torch.empty_like(my_idx) for _ in range(W)]
         all_rows = [torch.empty_like(my_rows) for _ in range(W)]
-        dist.all_gather(all_idx, my_idx, group=self.group)
-        dist.all_gather(all_rows, my_rows, group=self.group)
+        _all_gather_list(all_idx, my_idx, self.group)
+        _all_gather_list(all_rows, my_rows, self.group)
         self.arena.flat.zero_()
         for r in range(W):                                    # rank order: the same association on every rank
             if counts[r]:

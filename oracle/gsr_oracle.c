@@ -417,7 +417,7 @@ void orc_render_fwd(const OrcView* v, const uint32_t* ranges, const uint32_t* po
 
 /* --------------------------------------------------------------------------------------------------- K7 */
 /* Accumulates (+=) into dL_dxy_ndc[P,2] (already scaled to d/d(ndc): x0.5W, x0.5H), dL_dconic[P,3]
- * (true partials w.r.t. conic a,b,c), dL_dopacity[P], dL_drgb[P,3], dL_ddepth[P]. Caller zeroes them.
+ * (the covariance-gradient sums sum q u^2, sum q u v, sum q v^2 -- see the loop body), dL_dopacity[P], dL_drgb[P,3], dL_ddepth[P]. Caller zeroes them.
  * bwd_pixel: one pixel's reverse traversal; the sums go to row `g` of the five arrays (scalar build) or, when `local`
  * is set, to row k = position in the tile's list (OpenMP build: per-tile sums first, merged afterwards). */
 static void bwd_pixel(const OrcView* v, int px, int py, const uint32_t* ranges, const uint32_t* point_list,
@@ -466,15 +466,21 @@ static void bwd_pixel(const OrcView* v, int px, int py, const uint32_t* ranges, 
     dL_dalpha *= T;
     last_alpha = alpha;
     dL_dalpha += (-Tf / (1.0f - alpha)) * bg_dot;
-    const float dL_dG = co[3] * dL_dalpha;
-    const float gdx = G * dx, gdy = G * dy;
-    const float dG_ddx = -gdx * co[0] - gdy * co[1];
-    const float dG_ddy = -gdy * co[2] - gdx * co[1];
-    dL_dxy_ndc[2 * r] += dL_dG * dG_ddx * sx;
-    dL_dxy_ndc[2 * r + 1] += dL_dG * dG_ddy * sy;
-    dL_dconic[3 * r] += -0.5f * gdx * dx * dL_dG;
-    dL_dconic[3 * r + 1] += -gdx * dy * dL_dG;
-    dL_dconic[3 * r + 2] += -0.5f * gdy * dy * dL_dG;
+    /* With (u, v) = -Sigma^-1 d = -(A dx + B dy, C dy + B dx) and q = dL/dG G:  dG/dd = G (u, v), so q (u, v) is this
+     * pixel's share of dL/d(pixel centre); and dL/dSigma = 1/2 sum q (Sigma^-1 d)(Sigma^-1 d)^T, so q (u^2, u v, v^2) is its
+     * share of the gradient of the 2-D covariance ITSELF. Both are formed here, per pixel; the `dL_dconic` rows hold
+     * (sum q u^2, sum q u v, sum q v^2) and orc_preprocess_bwd only scales them (SEMANTICS.md section 5). The lineage
+     * sums dL/dconic = -1/2 q (dx^2, 2 dx dy, dy^2) and converts afterwards, which is the same in exact arithmetic and
+     * loses cond(Sigma)^2 digits in fp32 (needle-shaped splats: 1e-1 against float64 autograd).
+     * Expression tree of u, v: identical to render.hip (fma of the exact -A / -C with the rounded -B product). */
+    const float q = (co[3] * dL_dalpha) * G;
+    const float u = fmaf(-co[0], dx, (-co[1]) * dy), w2 = fmaf(-co[2], dy, (-co[1]) * dx);
+    const float m1 = q * u, m2 = q * w2;
+    dL_dxy_ndc[2 * r] += m1 * sx;
+    dL_dxy_ndc[2 * r + 1] += m2 * sy;
+    dL_dconic[3 * r] += m1 * u;
+    dL_dconic[3 * r + 1] += m1 * w2;
+    dL_dconic[3 * r + 2] += m2 * w2;
     dL_dopacity[r] += G * dL_dalpha;
   }
 }
@@ -626,12 +632,11 @@ void orc_preprocess_bwd(const OrcView* v, const float* means3D, const float* sca
     const float cc = ((U1[0] * M1[0] + U1[1] * M1[1]) + U1[2] * M1[2]) + LOWPASS;
     const float det = ca * cc - cb * cb;
 
-    /* (2) conic -> cov2D, lineage denominator det^2 + 1e-7 */
-    const float d2i = 1.0f / (det * det + 0.0000001f);
-    const float ga = dL_dconic[3 * i], gb = dL_dconic[3 * i + 1], gc = dL_dconic[3 * i + 2];
-    const float dca = d2i * ((-cc * cc * ga + cb * cc * gb) - cb * cb * gc);
-    const float dcc = d2i * ((-cb * cb * ga + cb * ca * gb) - ca * ca * gc);
-    const float dcb = d2i * ((2.0f * cb * cc * ga - (det + 2.0f * cb * cb) * gb) + 2.0f * cb * ca * gc);
+    /* (2) the per-pixel sums (bwd_pixel) -> dL/dcov2D = 1/2 sum q (Sigma^-1 d)(Sigma^-1 d)^T; the lineage reaches the same
+     * quantity through dL/dconic with the denominator det^2 + 1e-7 instead of det^2: the factor below keeps that */
+    const float det2 = det * det;
+    const float reg = det2 * (1.0f / (det2 + 0.0000001f));
+    const float dca = (0.5f * dL_dconic[3 * i]) * reg, dcb = dL_dconic[3 * i + 1] * reg, dcc = (0.5f * dL_dconic[3 * i + 2]) * reg;
 
     /* (3) cov2D = M Sigma M^T: dSigma = M^T G2 M (G2 symmetric with off-diagonal dcb/2), dM = 2 G2 M Sigma */
     const float h = 0.5f * dcb;

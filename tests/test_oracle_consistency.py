@@ -66,6 +66,34 @@ def test_forward_backward_c_vs_torch(c_oracle, D, K, seed):
         assert err(a, c) <= 1e-5 * max(1.0, float(np.abs(a).max())), tk
 
 
+def test_needles_vs_float64(c_oracle):
+    """Needle-shaped, flat and zero-size splats (scale noise + clamp(.., 0), scene_gaussian.py:1005-1008): the scalar
+    fp32 oracle against float64 autograd. The covariance gradient is accumulated per pixel as q (Sigma^-1 d)(Sigma^-1 d)^T
+    (SEMANTICS.md section 5); with the lineage's order (sum dL/dconic, convert afterwards) this case is 1e-5 .. 1e-1 off."""
+    from dreamscene_amd import synth
+    P = 800
+    g, cam = small_scene(P=P, H=96, W=96, K=16, seed=5, scale_mul=3.0)
+    rng = np.random.default_rng(77)
+    s = g["scales"].astype(np.float32)
+    s[::7, 1] *= 0.01
+    s[3::11, 0] *= 10.0
+    noise = rng.standard_normal(s.shape).astype(np.float32) * 8.0
+    g["scales"] = np.maximum(s + noise * (np.float32(np.sqrt(0.2)) * s / 4.0), 0.0).astype(np.float32)
+    assert (g["scales"] == 0).mean() > 0.05
+    bg = np.ones(3, np.float32)
+    gi, gda = synth.upstream_grads(96, 96, 3)
+    r = _torch_run(g, cam, bg, 3, gi=gi, gda=gda, cam_grad=False)
+    v = oracle_view(c_oracle, cam, P, 16, 3, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    b = c_oracle.backward(v, f, gi, gda, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    assert np.array_equal(f["n_contrib"], r["aux"]["n_contrib"])
+    for tk, ck in (("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                   ("opacities", "dL_dopacity"), ("shs", "dL_dshs"), ("means2D", "dL_dmeans2D")):
+        a = r["grads"][tk]
+        c = np.asarray(b[ck]).reshape(a.shape)
+        assert err(a, c) <= 2e-6 * max(1.0, float(np.abs(a).max())), tk
+
+
 def test_colors_precomp_and_cov3d_precomp(c_oracle):
     from dreamscene_amd import synth
     from oracle import torch_oracle as TO
