@@ -279,16 +279,25 @@ k_os_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev,
     const bool valid = (e < n) && (!DROP || kk[it] != 0xFFFFFFFFu);
     const unsigned long long vm = __ballot(valid);
     if (vm == 0ull) continue;
-    const int first = __ffsll((long long)vm) - 1;
-    for (int p = 0; p < passes; ++p) {
-      const uint32_t d = (kk[it] >> (p * kRadixBits)) & (kRadix - 1);
-      // the high digits of depth bits / tile ids / cell ids are the same for the whole wave most of the time: one LDS
-      // atomic per wave then, instead of 64 on one address
-      const uint32_t d0 = (uint32_t)__shfl((int)d, first, 64);
-      if (__ballot(valid && d != d0) == 0ull) {
-        if (lane == first) atomicAdd(&h[p][d0], (uint32_t)__popcll(vm));
+    const uint32_t k = kk[it];
+    // low digits: effectively random -> one LDS atomic per key and digit
+    if (valid) {
+      atomicAdd(&h[0][k & (kRadix - 1)], 1u);
+      if (passes > 1) atomicAdd(&h[1][(k >> kRadixBits) & (kRadix - 1)], 1u);
+    }
+    if (passes > 2) {
+      // high digits (depth exponent / high mantissa bits, high tile or cell bits): the same for the whole wave most of
+      // the time -> one atomic per wave and digit instead of 64 on one address
+      const int first = __ffsll((long long)vm) - 1;
+      const uint32_t hi = k >> (2 * kRadixBits), hi0 = (uint32_t)__shfl((int)hi, first, 64);
+      if (__ballot(valid && hi != hi0) == 0ull) {
+        if (lane == first) {
+          atomicAdd(&h[2][hi0 & (kRadix - 1)], (uint32_t)__popcll(vm));
+          if (passes > 3) atomicAdd(&h[3][hi0 >> kRadixBits], (uint32_t)__popcll(vm));
+        }
       } else if (valid) {
-        atomicAdd(&h[p][d], 1u);
+        atomicAdd(&h[2][hi & (kRadix - 1)], 1u);
+        if (passes > 3) atomicAdd(&h[3][hi >> kRadixBits], 1u);
       }
     }
   }
@@ -296,6 +305,33 @@ k_os_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev,
   for (int p = 0; p < passes; ++p) {
     const uint32_t c = h[p][tid];
     if (c) atomicAdd(&os[p * kRadix + tid], c);
+  }
+}
+
+// Look-back of one digit (column `col` of the table) from tile `tile` - 1 downwards: sum of the aggregates met, up to and
+// including the first inclusive word. The words of the next kOsWindow predecessors are requested together (independent
+// loads in flight) and consumed in order, so a walk over k published words costs k / kOsWindow round trips, not k.
+constexpr int kOsWindow = 4;
+__device__ __forceinline__ uint32_t os_look_back(gsr_gu32* table, uint32_t tile, int col, uint32_t tagA, uint32_t tagI) {
+  uint32_t excl = 0;
+  int p = (int)tile - 1;
+  for (;;) {
+    uint32_t w[kOsWindow];
+#pragma unroll
+    for (int j = 0; j < kOsWindow; ++j)
+      w[j] = (p - j >= 0) ? __hip_atomic_load(table + (size_t)(p - j) * kRadix + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                          : 0u;
+    bool done = false, stalled = false;
+#pragma unroll
+    for (int j = 0; j < kOsWindow; ++j) {
+      if (done || stalled) continue;
+      const uint32_t tag = w[j] & 0xF0000000u;
+      if (tag == tagI) { excl += w[j] & 0x0FFFFFFFu; done = true; }
+      else if (tag == tagA) { excl += w[j] & 0x0FFFFFFFu; --p; }
+      else stalled = true;                  // not published yet: poll again from here (tile 0 publishes inclusive words)
+    }
+    if (done) return excl;
+    if (stalled) __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -349,6 +385,20 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     key[it] = valid ? keys_in[e] : 0xFFFFFFFFu;
     val[it] = IOTA ? (uint32_t)e : (valid ? vals_in[e] : 0u);
   }
+  if constexpr (!DROP) {
+    // Every key carries the same digit (the top byte of the depths of one object, the high byte of 10-bit tile ids, ...):
+    // the pass is the identity permutation -- a coalesced copy, no ranking, no look-back (nobody waits for this tile: all
+    // tiles of the pass take this branch).
+    const uint32_t x = os[pass * kRadix + tid];
+    if (__syncthreads_or((uint64_t)x == n && n > 0)) {
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        const uint64_t e = sort_index<ITEMS>(tile, wave, it, lane);
+        if (e < n) { keys_out[e] = key[it]; vals_out[e] = val[it]; }
+      }
+      return;
+    }
+  }
   const auto is_valid = [&](int it) {
     const uint64_t e = sort_index<ITEMS>(tile, wave, it, lane);
     return (e < n) && (!DROP || key[it] != 0xFFFFFFFFu);
@@ -389,14 +439,7 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     __hip_atomic_store(table + tid, tagI | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagA | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t p = tile - 1;
-    for (;;) {
-      const uint32_t w = __hip_atomic_load(table + (size_t)p * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t tag = w & 0xF0000000u;
-      if (tag == tagI) { excl += w & 0x0FFFFFFFu; break; }
-      if (tag == tagA) { excl += w & 0x0FFFFFFFu; --p; continue; }     // (tile 0 only ever publishes inclusive words)
-      __builtin_amdgcn_s_sleep(1);
-    }
+    excl = os_look_back(table, tile, tid, tagA, tagI);
     __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagI | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // start of digit d's run inside the tile: exclusive scan of cnt over the digits
@@ -471,13 +514,18 @@ int radix_sort_u32_legacy(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1
 template <int ITEMS, int OS_ITEMS>
 int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
                    int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream,
-                   int batch = 1, size_t bstride = 0) {
+                   int batch = 1, size_t bstride = 0, size_t zero_before = 0) {
+  // zero_before: bytes directly in front of `hist` (a multiple of 16) that the caller wants cleared along with the sort state
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
-  if (cap >= kOsMaxN || passes > kOsMaxPasses)
+  if (cap >= kOsMaxN || passes > kOsMaxPasses) {
+    if (zero_before) (void)gsr_zero_async((char*)hist - zero_before, zero_before, stream, bstride, (uint32_t)batch);
     return radix_sort_u32_legacy<ITEMS>(k0, v0, k1, v1, n_dev, cap, bits, iota, n_compact, hist, totals, stream, batch, bstride);
+  }
   const uint32_t ntile = os_tiles(cap, OS_ITEMS), nhist = (uint32_t)((cap + kOsHistTile - 1) / kOsHistTile);
   const dim3 grid(ntile, (uint32_t)batch), grid_h(nhist ? nhist : 1, (uint32_t)batch);
-  if (gsr_zero_async(hist, os_state_words(cap, OS_ITEMS) * 4, stream, bstride, (uint32_t)batch) != hipSuccess) return passes & 1;
+  if (gsr_zero_async((char*)hist - zero_before, zero_before + os_state_words(cap, OS_ITEMS) * 4, stream, bstride,
+                     (uint32_t)batch) != hipSuccess)
+    return passes & 1;
   const bool drop = iota && n_compact;
   if (drop)
     hipLaunchKernelGGL((k_os_hist<true>), grid_h, dim3(kSortThreads), 0, stream, k0, n_dev, cap, passes, hist, bstride);

@@ -420,11 +420,21 @@ void orc_render_fwd(const OrcView* v, const uint32_t* ranges, const uint32_t* po
  * (the covariance-gradient sums sum q u^2, sum q u v, sum q v^2 -- see the loop body), dL_dopacity[P], dL_drgb[P,3], dL_ddepth[P]. Caller zeroes them.
  * bwd_pixel: one pixel's reverse traversal; the sums go to row `g` of the five arrays (scalar build) or, when `local`
  * is set, to row k = position in the tile's list (OpenMP build: per-tile sums first, merged afterwards). */
+/* The per-(pixel, splat) terms are fp32 with a fixed operator order; their SUMS over the pixels are accumulated in double by
+ * the scalar build (the checker): the rasterizer lineage adds these terms with atomics in no particular order, so the value
+ * an implementation is held to is the exact sum of the fp32 terms, not one particular fp32 summation order (with random
+ * upstream gradients the terms of a large splat cancel to ~1/sqrt(#pixels) of their magnitude, and a sequential fp32 sum over
+ * 10^4 pixels is itself 1e-5 .. 1e-4 off). The OpenMP build (used for timing only) keeps float sums. */
+#ifdef ORC_OMP
+typedef float acc_t;
+#else
+typedef double acc_t;
+#endif
 static void bwd_pixel(const OrcView* v, int px, int py, const uint32_t* ranges, const uint32_t* point_list,
                       const float* xy, const float* conic_opacity, const float* rgb, const float* depth,
                       const float* final_T, const uint32_t* n_contrib, const float* dL_dimage,
-                      const float* dL_ddepth_alpha, float* dL_dxy_ndc, float* dL_dconic, float* dL_dopacity,
-                      float* dL_drgb, float* dL_ddepth, int local) {
+                      const float* dL_ddepth_alpha, acc_t* dL_dxy_ndc, acc_t* dL_dconic, acc_t* dL_dopacity,
+                      acc_t* dL_drgb, acc_t* dL_ddepth, int local) {
   const int W = v->W, H = v->H;
   const int gx = (W + BLOCK - 1) / BLOCK;
   const float sx = 0.5f * (float)W, sy = 0.5f * (float)H;
@@ -526,10 +536,19 @@ void orc_render_bwd(const OrcView* v, const uint32_t* ranges, const uint32_t* po
     free(loc);
   }
 #else
+  const size_t P = (size_t)v->P;
+  acc_t* acc = (acc_t*)calloc(P * 10 + 1, sizeof(acc_t));
+  acc_t *axy = acc, *acon = acc + 2 * P, *aop = acc + 5 * P, *argb = acc + 6 * P, *adep = acc + 9 * P;
   for (int py = 0; py < H; ++py)
     for (int px = 0; px < W; ++px)
       bwd_pixel(v, px, py, ranges, point_list, xy, conic_opacity, rgb, depth, final_T, n_contrib, dL_dimage,
-                dL_ddepth_alpha, dL_dxy_ndc, dL_dconic, dL_dopacity, dL_drgb, dL_ddepth, 0);
+                dL_ddepth_alpha, axy, acon, aop, argb, adep, 0);
+  for (size_t i = 0; i < 2 * P; ++i) dL_dxy_ndc[i] += (float)axy[i];
+  for (size_t i = 0; i < 3 * P; ++i) dL_dconic[i] += (float)acon[i];
+  for (size_t i = 0; i < P; ++i) dL_dopacity[i] += (float)aop[i];
+  for (size_t i = 0; i < 3 * P; ++i) dL_drgb[i] += (float)argb[i];
+  for (size_t i = 0; i < P; ++i) dL_ddepth[i] += (float)adep[i];
+  free(acc);
 #endif
 }
 

@@ -77,7 +77,7 @@ def _worker(rank, world, port, mode, out_dir):
         ex.reduce()
         torch.cuda.synchronize(dev)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=arena.flat.cpu().numpy(), own=own.cpu().numpy(),
-             img0=outs[0][0].cpu().numpy(), last=json.dumps(ex.last))
+             img0=outs[0][0].detach().cpu().numpy(), last=json.dumps(ex.last))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -102,7 +102,7 @@ def test_two_ranks_share_the_gpu(built_lib, tmp_path, mode):
     e = float(np.abs(r0["flat"].astype(np.float64) - ref).max())
     assert e <= 1e-5 * scale, f"exchanged sum differs from the single-process 4-view sum by {e:.3e} (scale {scale:.3e})"
     # per-view outputs do not depend on how the views are grouped into calls: rank 0's first view is view 0
-    assert np.array_equal(r0["img0"], outs[0][0].cpu().numpy()), "view 0 rendered differently in the sharded run"
+    assert np.array_equal(r0["img0"], outs[0][0].detach().cpu().numpy()), "view 0 rendered differently in the sharded run"
     assert json.loads(str(r0["last"]))["format"] == mode
 
 
