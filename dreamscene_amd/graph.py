@@ -122,7 +122,7 @@ class CapturedViews(torch.nn.Module):
         if not VW._uniform(settings_list):
             raise ValueError("all views of a call must have the same image_height, image_width and scale_modifier")
         if any(s.score_flag for s in settings_list):
-            raise ValueError("score_flag views return a 4-tuple: render them with GaussianRasterizer")
+            raise ValueError("score_flag views are forward-only: GaussianRasterizerViews / views.importance_scores render them batched")
         if means2D.shape[0] != V:
             raise ValueError(f"means2D must be [V,P,3] with V = {V} views")
         rc = (self.context or R.DEFAULT_CONTEXT).snapshot()

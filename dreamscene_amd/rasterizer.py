@@ -272,7 +272,10 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
         radii = torch.empty(Pm, dtype=i32, device=dev)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth_alpha = torch.empty((2, H, W), dtype=torch.float32, device=dev)
-        score = torch.zeros(P, dtype=torch.float32, device=dev) if s.score_flag else None
+        if s.score_flag and batch is not None and batch.get("score") is not None:
+            score = batch["score"]       # the batch's views add into the caller's [P] buffer (views.importance_scores)
+        else:
+            score = torch.zeros(P, dtype=torch.float32, device=dev) if s.score_flag else None
         proj_bytes = int(lib.gsr_project_scratch_bytes(P))
         proj_scratch = batch["scratch"] if batch is not None else ws.scratch("proj_scratch", proj_bytes)
 
@@ -394,7 +397,9 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                     ptrs[k] = ptrs2[k]
                     view_src[k] = (buf2, offs2[k])
                 bind(ptrs, N, False)
-                if score is not None:
+                if score is not None and batch is not None and batch.get("score") is not None:
+                    batch["score_dirty"][0] = True     # shared accumulator: the caller recomputes the whole batch
+                elif score is not None:
                     score.zero_()
                 L.check(lib.gsr_forward_render(C.byref(st.view), C.byref(geom), N, C.byref(b), C.byref(im), stream,
                                                prof), "gsr_forward_render")

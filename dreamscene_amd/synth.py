@@ -83,6 +83,18 @@ def object_cameras(n: int, H: int, W: int, radius: float = 5.35, theta: float = 
     return [orbit_camera(radius, theta, 45.0 * i, fovx, H, W) for i in range(n)]
 
 
+def sphere_cameras(n: int, H: int, W: int, radius: float = 5.35, fovx: float = 0.46) -> List[Camera]:
+    """n cameras spread over the sphere around the object, looking at the origin -- the kind of set the reference's
+    importance scoring renders (loadSphereCam, utils/cam_utils.py:1847: 48 cameras). Fibonacci lattice, poles avoided."""
+    cams = []
+    for i in range(n):
+        z = 1.0 - 2.0 * (i + 0.5) / n
+        theta = float(np.degrees(np.arccos(np.clip(z, -0.985, 0.985))))
+        phi = float((i * 137.50776405) % 360.0)
+        cams.append(orbit_camera(radius, theta, phi, fovx, H, W))
+    return cams
+
+
 def indoor_cameras(n: int, H: int, W: int, fovx: float = 0.96) -> List[Camera]:
     """Cameras inside the room looking outward (utils/cam_utils.py:952, 2278-2327)."""
     cams = []

@@ -32,11 +32,14 @@ def _uniform(settings_list) -> bool:
 
 
 def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs, colors_precomp, scales, rotations,
-                                cov3D_precomp, want_aux: bool = False, scenes=None, rc=None):
+                                cov3D_precomp, want_aux: bool = False, scenes=None, rc=None, score_sum=None):
     """Forward of V views. Returns [(outputs, state)] like rasterize_forward_raw per view.
     scales: [P,3] shared by the views, or [V,P,3] (every view its own, e.g. with the trainers' per-view scale noise).
     scenes: instead of the tensors, one `scene` dict per view (rasterize_forward_raw): the same models' raw leaves,
-    per-view noise samples."""
+    per-view noise samples.
+    score_flag views (all of them or none): every view's outputs carry its own `score` [P]; with score_sum = a [P] fp32
+    tensor the scores of ALL views are ADDED to it instead (K6's per-splat atomics of every view land in the one buffer:
+    the `imp_list` of the reference's prune_list, scene_gaussian.py:1063-1079) and the views' `score` entries alias it."""
     lib = L.load()
     rc = rc or R.DEFAULT_CONTEXT
     V = len(settings_list)
@@ -54,11 +57,25 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
     same = _uniform(settings_list)
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = R._workspace(dev, stream)
+    n_score = sum(bool(s.score_flag) for s in settings_list)
+    if n_score not in (0, V):
+        raise ValueError("the views of one call must all have score_flag set, or none of them")
+    if score_sum is not None and (n_score != V or score_sum.dtype != torch.float32 or tuple(score_sum.shape) != (P,)
+                                  or not score_sum.is_contiguous() or score_sum.device != dev):
+        raise ValueError("score_sum must be a contiguous fp32 [P] tensor on the Gaussians' device, with score_flag views")
     batched = (1 < V <= MAX_VIEWS and same and P > 0 and rc.forward_mode == "auto" and ws.hint.get((P, H, W)) is not None
-               and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24) and not any(s.score_flag for s in settings_list))
+               and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24))
+
+    def one_by_one():
+        res = [R.rasterize_forward_raw(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp,
+                                       want_aux=want_aux, rc=rc) for k, s in enumerate(settings_list)]
+        if score_sum is not None:
+            for o, _ in res:
+                score_sum.add_(o["score"])
+                o["score"] = score_sum
+        return res
     if not batched:
-        return [R.rasterize_forward_raw(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp,
-                                        want_aux=want_aux, rc=rc) for k, s in enumerate(settings_list)]
+        return one_by_one()
     prof = rc.profile.handle if rc.profile is not None else None
     stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
     with torch.cuda.device(dev):
@@ -67,12 +84,21 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
         synced = [False]          # the first generator to resume waits for the projection; the others find it done
         if ws.batch_pinned is None:
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
+        dirty = [False]
+        held = score_sum.clone() if score_sum is not None else None      # (restored if a view outgrows its capacity)
         gens = [R._forward_steps(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp, False,
                                  want_aux, None, None,
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
-                                      event=ws.event, sort=sort_of(k), synced=synced), rc)
+                                      event=ws.event, sort=sort_of(k), synced=synced, score=score_sum, score_dirty=dirty),
+                                 rc)
                 for k, s in enumerate(settings_list)]
         results = _drive_batch(lib, ws, gens, V, dev, stream, prof)
+        if dirty[0]:
+            # a view's pair count exceeded the speculated capacity: its clamped lists already added to the shared buffer.
+            # Rare (the capacity follows the recent maximum with 1.5x headroom): put the buffer back and take the views one
+            # at a time (exact sizes)
+            score_sum.copy_(held)
+            return one_by_one()
     return results
 
 
@@ -208,8 +234,37 @@ class GaussianRasterizerViews(torch.nn.Module):
         if means2D.shape[0] != V:
             raise ValueError(f"means2D must be [V,P,3] with V = {V} views")
         if any(s.score_flag for s in self.raster_settings_list):
-            raise ValueError("score_flag views return a 4-tuple: render them with GaussianRasterizer")
+            # forward-only, like the reference's score_render (scene_gaussian.py:546-671): per view the 4-tuple
+            # (important_score, image, radii, depth_alpha) of GaussianRasterizer with score_flag
+            if not all(s.score_flag for s in self.raster_settings_list):
+                raise ValueError("the views of one call must all have score_flag set, or none of them")
+            with torch.no_grad():
+                res = rasterize_views_forward_raw(self.raster_settings_list, means3D, opacities, shs, colors_precomp, scales,
+                                                  rotations, cov3D_precomp, rc=(self.context or R.DEFAULT_CONTEXT).snapshot())
+            return [(o["score"], o["color"], o["radii"], o["depth_alpha"]) for o, _ in res]
         rc = (self.context or R.DEFAULT_CONTEXT).snapshot()
         flat = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                      tuple(self.raster_settings_list), rc)
         return [tuple(flat[3 * k:3 * k + 3]) for k in range(V)]
+
+
+def importance_scores(settings_list: Sequence, means3D, opacities, shs=None, colors_precomp=None, scales=None,
+                      rotations=None, cov3D_precomp=None, context=None, chunk: int = MAX_VIEWS, out=None):
+    """Sum over the given cameras of the per-Gaussian importance score -- `prune_list` of the reference
+    (scene_gaussian.py:1063-1079: 48 sphere cameras, one `score_render` each, `imp_list += important_score`). The cameras
+    go through the batched forward `chunk` at a time: K1 once per chunk, the binning of all views through shared launches,
+    K6 (score variant) of all views in ONE launch, every view's per-splat sums added to the one [P] buffer by the kernel's
+    own atomics. settings_list: GaussianRasterizationSettings with score_flag=True (same image size / scale_modifier).
+    Forward only. Returns the [P] fp32 sum (`out` if given: added to)."""
+    settings_list = list(settings_list)
+    if not settings_list or not all(s.score_flag for s in settings_list):
+        raise ValueError("importance_scores needs at least one view, all with score_flag=True")
+    rc = (context or R.DEFAULT_CONTEXT).snapshot()
+    P = int(means3D.shape[0])
+    total = out if out is not None else torch.zeros(P, dtype=torch.float32, device=means3D.device)
+    chunk = max(1, min(int(chunk), MAX_VIEWS))
+    with torch.no_grad():
+        for i in range(0, len(settings_list), chunk):
+            rasterize_views_forward_raw(settings_list[i:i + chunk], means3D, opacities, shs, colors_precomp, scales, rotations,
+                                        cov3D_precomp, rc=rc, score_sum=total)
+    return total

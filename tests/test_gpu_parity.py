@@ -414,3 +414,34 @@ def test_thousands_of_equal_depths_keep_index_order(built_lib, c_oracle):
     for rep in range(3):
         out, _ = _run_hip(g, cam, bg, D)
         _check_forward(out, f, P)
+
+
+def test_c1_workload_vs_both_oracles(built_lib, c_oracle):
+    """BASELINE.json configs[0] at its actual size -- 10 k random Gaussians, 1 camera @256^2 (the reference's CPU-runnable
+    plumbing case) -- through the HIP path against BOTH oracles: the scalar C restatement (integer artefacts bit-exact,
+    everything else 1e-5) and float64 autograd of the vectorised PyTorch restatement (the definition of the gradients)."""
+    from dreamscene_amd import rasterizer as R, synth
+    from tests.test_oracle_consistency import _torch_run
+    P, K, D, RES = 10_000, 16, 3, 256
+    g = synth.g_object(P, seed=1, K=K)
+    cam = synth.object_cameras(1, RES, RES)[0]
+    bg = np.array([1.0, 1.0, 1.0], np.float32)
+    out, _ = _run_hip(g, cam, bg, D)
+    v = oracle_view(c_oracle, cam, P, K, D, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    _check_forward(out, f, P)
+    _grad_check(g, cam, bg, D, c_oracle, seed=1, tol=1e-5)
+    gi, gda = synth.upstream_grads(RES, RES, 1)
+    out, st = _run_hip(g, cam, bg, D, want_keys=False)
+    o = R.rasterize_backward_raw(st, torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV))
+    torch.cuda.synchronize()
+    r = _torch_run(g, cam, bg, D, gi=gi, gda=gda, cam_grad=False)
+    assert np.array_equal(out["radii"].cpu().numpy(), r["radii"])
+    assert err(out["color"].cpu().numpy(), r["img"]) <= 1e-5
+    if np.array_equal(out["n_contrib"].cpu().numpy().view(np.uint32), r["aux"]["n_contrib"]):
+        # (float64 may take a hard gate the other way on a pixel -- then the two are different functions there)
+        for tk, hk in (("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                       ("opacities", "dL_dopacities"), ("shs", "dL_dshs"), ("means2D", "dL_dmeans2D")):
+            ref = np.asarray(r["grads"][tk], dtype=np.float64)
+            got = o[hk].cpu().numpy().astype(np.float64).reshape(ref.shape)
+            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max())), f"{hk} vs float64 autograd"
