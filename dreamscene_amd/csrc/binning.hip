@@ -174,7 +174,6 @@ k_rebuild_keys(const uint32_t* __restrict__ tile_keys, const uint32_t* __restric
 
 // =================================================================================== column path (see header)
 constexpr int kColRun = 64;        // Gaussians (in depth order) per emission wave: short runs = many stores in flight
-constexpr size_t kRowTotBytes = 8 * 256 * 4;   // per-row pair totals, eight copies (k_col_hist -> k_col_plan)
 constexpr int kPass2Items = 16;    // pairs per thread in the ty pass (4096 per workgroup)
 constexpr uint32_t kPass2Block = kSortThreads * kPass2Items;
 
@@ -198,15 +197,13 @@ __device__ __forceinline__ uint32_t rect_h(uint32_t r) { return (r >> 24) + 1u; 
 __global__ void __launch_bounds__(256)
 k_col_hist(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sorted_idx,
            const uint32_t* __restrict__ rects, uint32_t* __restrict__ rect_sorted, const int gx, const uint32_t nrun,
-           uint32_t* __restrict__ hist1, uint32_t* __restrict__ rowtot, const int gy, size_t bstride) {
+           uint32_t* __restrict__ hist1, size_t bstride) {
   n_vis = batch_ptr(n_vis, bstride); sorted_idx = batch_ptr(sorted_idx, bstride); rects = batch_ptr(rects, bstride);
-  rect_sorted = batch_ptr(rect_sorted, bstride); hist1 = batch_ptr(hist1, bstride); rowtot = batch_ptr(rowtot, bstride);
+  rect_sorted = batch_ptr(rect_sorted, bstride); hist1 = batch_ptr(hist1, bstride);
   __shared__ uint32_t bins[4][256];
-  __shared__ uint32_t rbins[256];    // pairs per tile ROW of this workgroup's 256 Gaussians (feeds the row pass's row starts)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int w = 0; w < 4; ++w) bins[w][tid] = 0;
-  rbins[tid] = 0;
   __syncthreads();
   uint32_t* mybins = bins[wave];
   const int64_t s = (int64_t)blockIdx.x * 256 + tid;
@@ -216,8 +213,6 @@ k_col_hist(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sort
     r = rects[sorted_idx[s]];
     rect_sorted[s] = r;
     x0 = rect_x0(r); w = rect_w(r); h = rect_h(r);
-    const uint32_t y0 = rect_y0(r);
-    for (uint32_t c = 0; c < h; ++c) atomicAdd(&rbins[y0 + c], w);
   }
   constexpr uint32_t kCoop = 8;
   if (in && w <= kCoop)
@@ -238,40 +233,15 @@ k_col_hist(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sort
       if (run < nrun && (int64_t)run * kColRun < (int64_t)*n_vis) hist1[(uint64_t)tid * nrun + run] = bins[w2][tid];
     }
   }
-  // row totals: eight copies (workgroup b adds to copy b % 8 = the XCD it runs on), summed by k_col_plan -- 2 000
-  // workgroups adding to the same 64 words would serialise at ~6 ns per atomic
-  if (tid < gy && rbins[tid]) atomicAdd(&rowtot[(blockIdx.x & 7u) * 256u + (uint32_t)tid], rbins[tid]);
 }
 
 // colstart[0..gx] = exclusive scan of the column totals (saturating u32), *n_pairs = N (64-bit).
 __global__ void __launch_bounds__(256)
 k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restrict__ colstart,
-           uint64_t* __restrict__ n_pairs, size_t bstride, uint64_t* __restrict__ n_pairs_all,
-           const uint32_t* __restrict__ rowtot, const int gy, uint32_t* __restrict__ rowstart) {
+           uint64_t* __restrict__ n_pairs, size_t bstride, uint64_t* __restrict__ n_pairs_all) {
   totals1 = batch_ptr(totals1, bstride); colstart = batch_ptr(colstart, bstride); n_pairs = batch_ptr(n_pairs, bstride);
-  rowtot = batch_ptr(rowtot, bstride); rowstart = batch_ptr(rowstart, bstride);
   __shared__ uint64_t wtot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {
-    // rowstart[ty] = pairs in the tile rows above ty (saturating u32): where row ty starts in the final list
-    uint64_t x = 0;
-    if (tid < gy)
-      for (int c = 0; c < 8; ++c) x += rowtot[c * 256 + tid];
-    uint64_t inc = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint64_t t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    uint64_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wtot[w];
-    const uint64_t excl = woff + inc - x;
-    if (tid < gy) rowstart[tid] = excl > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)excl;
-    if (tid == gy - 1) rowstart[gy] = excl + x > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(excl + x);   // = N
-    __syncthreads();
-  }
   const uint64_t x = tid < gx ? (uint64_t)totals1[tid] : 0ull;
   uint64_t inc = x;
 #pragma unroll
@@ -300,17 +270,10 @@ k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restr
 __global__ void __launch_bounds__(64)
 k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x, const uint32_t* __restrict__ rect_sorted,
             const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ hist1, const uint32_t nrun,
-            const uint32_t* __restrict__ colstart, const uint32_t cap, uint32_t* __restrict__ vals,
-            uint32_t* __restrict__ row_state, const uint32_t row_state_words, uint32_t* __restrict__ row_ticket, size_t ps,
-            size_t ss) {
+            const uint32_t* __restrict__ colstart, const uint32_t cap, uint32_t* __restrict__ vals, size_t ps, size_t ss) {
   // several views per launch (blockIdx.y): projection scratch buffers ps bytes apart, sort scratch buffers ss bytes apart
   n_vis = batch_ptr(n_vis, ps); rect_sorted = batch_ptr(rect_sorted, ps); sorted_idx = batch_ptr(sorted_idx, ps);
   hist1 = batch_ptr(hist1, ps); colstart = batch_ptr(colstart, ps); vals = batch_ptr(vals, ss);
-  row_state = batch_ptr(row_state, ss); row_ticket = batch_ptr(row_ticket, ss);
-  // the look-back words and the ticket of the row pass (the next launch) start out as zero: cleared here, by all the
-  // workgroups of this launch together, instead of by a launch of its own
-  for (uint32_t w = blockIdx.x * 64u + threadIdx.x; w < row_state_words; w += gridDim.x * 64u) row_state[w] = 0u;
-  if (row_state_words && blockIdx.x == 0 && threadIdx.x == 0) row_ticket[0] = 0u;
   __shared__ uint32_t col_run[256];
   __shared__ uint32_t pbase[65];
   __shared__ uint32_t rs[64], ids[64], mg[64];
@@ -530,134 +493,6 @@ k_row_scatter(const uint32_t* __restrict__ vals_in, const RowOut ro, const uint3
   }
 }
 
-// ---- the ty pass as ONE launch (round 3): decoupled look-back instead of histogram launch + 256-row scan launch.
-// Workgroups take the column-aligned blocks in ticket order (so every earlier block is running or done). A block ranks its
-// <= 4096 words by ty, publishes the per-row counts and obtains "pairs with this ty in all earlier blocks" -- earlier
-// columns and earlier blocks of its own column -- by look-back over the published words (same protocol as k_os_pass:
-// one u32 per (block, row) = tag << 28 | value, relaxed agent-scope atomics only). The final position of a pair is
-// rowstart[ty] (from the per-row totals k_col_hist / k_col_plan leave) + that prefix + its rank inside the block; the
-// block's words are sorted by ty in LDS first, so that runs of consecutive positions are written together.
-// Tile ranges: the first block of column tx knows where tile (ty, tx) starts = where (ty, tx - 1) ends, so it writes
-// both words; the end of the last column's tiles is rowstart[ty + 1]. Empty tiles therefore get (p, p); k_work_order_fwd
-// (render.hip), which visits every tile anyway, rewrites them as (0, 0).
-// A view whose pair count exceeds the capacity is not binned at all: every range becomes (0, 0) (the caller sees N > cap
-// and redoes the step; nothing downstream may then read unwritten list entries).
-// table[256 b + ty] = look-back word of block b (cleared, like the ticket, by k_emit_cols).
-__global__ void __launch_bounds__(kSortThreads)
-k_row_pass(const uint32_t* __restrict__ vals_in, const RowOut ro, const uint32_t* __restrict__ colstart, const int gx,
-           const int gy, const uint32_t cap, const int nbits, const uint32_t* __restrict__ rowstart,
-           uint32_t* __restrict__ table_, uint32_t* __restrict__ ticket, size_t ps, size_t ss) {
-  vals_in = batch_ptr(vals_in, ss); colstart = batch_ptr(colstart, ps); rowstart = batch_ptr(rowstart, ps);
-  table_ = batch_ptr(table_, ss); ticket = batch_ptr(ticket, ss);
-  uint32_t* __restrict__ vals_out = ro.point_list[blockIdx.y];
-  uint32_t* __restrict__ ranges = ro.ranges[blockIdx.y];
-  __shared__ uint32_t wh[4][kRadix];
-  __shared__ uint32_t gbase[kRadix];
-  __shared__ uint32_t sval[kPass2Block];
-  __shared__ uint32_t wtot[4];
-  __shared__ uint32_t sh_fb[257];
-  __shared__ uint32_t sh_tmp[8];
-  __shared__ uint32_t s_blk, s_ntile;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_blk = atomicAdd(&ticket[0], 1u);
-#pragma unroll
-  for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
-  __syncthreads();
-  const uint32_t blk = s_blk;
-  const ColBlocks cb = col_blocks(colstart, gx, cap, blk, sh_fb, sh_tmp);
-  if (cb.col == 0xFFFFFFFFu) return;                 // beyond the last block (and so is every later ticket)
-  const bool first_of_col = blk == sh_fb[cb.col];
-  const bool overflow = colstart[gx] > cap;          // N (saturating) beyond the capacity of the lists
-  if (overflow) {
-    if (first_of_col && tid < gy) reinterpret_cast<uint2*>(ranges)[(uint32_t)tid * (uint32_t)gx + cb.col] = make_uint2(0u, 0u);
-    return;
-  }
-  uint32_t* mywh = wh[wave];
-  uint32_t val[kPass2Items];   // ty << 24 | Gaussian index; 0xFFFFFFFF = no element (index 0xFFFFFF never occurs)
-  uint32_t rank[kPass2Items];
-  const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int it = 0; it < kPass2Items; ++it) {
-    const uint32_t e = cb.base + (uint32_t)(wave * (64 * kPass2Items) + it * 64 + lane);
-    val[it] = e < cb.end ? vals_in[e] : 0xFFFFFFFFu;
-  }
-#pragma unroll
-  for (int it = 0; it < kPass2Items; ++it) {
-    const bool valid = val[it] != 0xFFFFFFFFu;
-    const uint32_t d = val[it] >> 24;
-    const unsigned long long m = match_digit_n(d, valid, nbits);
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t old = 0;
-    if (valid && lane == leader) {
-      old = mywh[d];
-      mywh[d] = old + (uint32_t)__popcll(m);
-    }
-    old = (uint32_t)__shfl((int)old, valid ? leader : lane, 64);
-    rank[it] = old + (uint32_t)__popcll(m & lt);
-    GSR_LDS_ORDER();
-  }
-  __syncthreads();
-  uint32_t cnt;
-  {
-    uint32_t run = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t c = wh[w][tid];
-      wh[w][tid] = run;
-      run += c;
-    }
-    cnt = run;
-  }
-  gsr_gu32* table = gsr_global(table_);
-  constexpr uint32_t tagA = 1u << 28, tagI = 2u << 28;
-  uint32_t excl = 0;
-  if (blk == 0) {
-    __hip_atomic_store(table + tid, tagI | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    __hip_atomic_store(table + (size_t)blk * kRadix + tid, tagA | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    excl = os_look_back(table, blk, tid, tagA, tagI);
-    __hip_atomic_store(table + (size_t)blk * kRadix + tid, tagI | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  const uint32_t rs = tid < gy ? rowstart[tid] : 0u;
-  if (first_of_col && tid < gy) {
-    // tile (ty = tid, tx = col) starts at a = rowstart + pairs of row ty in the columns before: also the end of (ty, col - 1)
-    const uint32_t a = rs + excl;
-    ranges[2 * ((uint32_t)tid * (uint32_t)gx + cb.col)] = a;
-    if (cb.col > 0) ranges[2 * ((uint32_t)tid * (uint32_t)gx + cb.col - 1) + 1] = a;
-    if ((int)cb.col == gx - 1) ranges[2 * ((uint32_t)tid * (uint32_t)gx + cb.col) + 1] = rowstart[tid + 1];
-  }
-  // local start of row ty inside the block: exclusive scan of cnt
-  uint32_t lstart;
-  {
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wtot[w];
-    lstart = woff + inc - cnt;
-    if (tid == kSortThreads - 1) s_ntile = woff + inc;
-  }
-#pragma unroll
-  for (int w = 0; w < 4; ++w) wh[w][tid] += lstart;
-  gbase[tid] = rs + excl - lstart;
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < kPass2Items; ++it)
-    if (val[it] != 0xFFFFFFFFu) sval[wh[wave][val[it] >> 24] + rank[it]] = val[it];
-  __syncthreads();
-  const uint32_t ntile = s_ntile;
-  for (uint32_t i = tid; i < ntile; i += kSortThreads) {
-    const uint32_t v = sval[i];
-    const uint32_t pos = gbase[v >> 24] + i;
-    if (pos < cap) vals_out[pos] = v & 0xFFFFFFu;
-  }
-}
-
 // debug / parity: 64-bit keys of the reference formulation rebuilt from the ranges (one workgroup per tile)
 __global__ void __launch_bounds__(256)
 k_rebuild_keys_ranges(const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -688,8 +523,8 @@ static uint32_t col_runs(int32_t P) { return (uint32_t)(((P > 0 ? P : 1) + kColR
 // packed tile rectangles and the per-run column histogram of the column path.
 extern "C" size_t gsr_project_scratch_bytes(int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
-  return 5 * align256(m * 4) + kRowTotBytes + sort_hist_bytes(m, kItemsSmall, kOsItemsSmall) + align256(kRadix * 4) +
-         align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + 2 * align256(264 * 4) + 256 + 1024;
+  return 5 * align256(m * 4) + sort_hist_bytes(m, kItemsSmall, kOsItemsSmall) + align256(kRadix * 4) +
+         align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + align256(264 * 4) + 256 + 1024;
 }
 
 // Scratch of the binning stage: tile keys x2, one value ping buffer, histograms (the column path needs less).
@@ -701,7 +536,7 @@ extern "C" size_t gsr_sort_scratch_bytes(uint64_t n, uint32_t n_tiles) {
 }
 
 struct ProjectScratch {
-  uint32_t *k0, *k1, *v0, *v1, *rowtot, *hist, *totals, *rects, *hist1, *totals1, *colstart, *rowstart;
+  uint32_t *k0, *k1, *v0, *v1, *hist, *totals, *rects, *hist1, *totals1, *colstart;
   uint64_t* counts;   // [0] = N (pairs), [1] = visible Gaussians
 };
 static ProjectScratch carve_project(void* scratch, int32_t P) {
@@ -712,14 +547,12 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
   s.k1 = (uint32_t*)b; b += align256(m * 4);
   s.v0 = (uint32_t*)b; b += align256(m * 4);
   s.v1 = (uint32_t*)b; b += align256(m * 4);
-  s.rowtot = (uint32_t*)b; b += kRowTotBytes;   // directly in front of the sort state: cleared by the sort's first launch
   s.hist = (uint32_t*)b; b += sort_hist_bytes(m, kItemsSmall, kOsItemsSmall);
   s.totals = (uint32_t*)b; b += align256(kRadix * 4);
   s.rects = (uint32_t*)b; b += align256(m * 4);
   s.hist1 = (uint32_t*)b; b += align256((size_t)256 * col_runs((int32_t)m) * 4);
   s.totals1 = (uint32_t*)b; b += align256(256 * 4);
   s.colstart = (uint32_t*)b; b += align256(264 * 4);
-  s.rowstart = (uint32_t*)b; b += align256(264 * 4);
   s.counts = (uint64_t*)b;
   return s;
 }
@@ -745,9 +578,8 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
   int where;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    // (the one-sweep sort's first launch clears its state; the row totals in front of it ride along)
     where = radix_sort_u32<kItemsSmall, kOsItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
-                                        s.totals, stream, batch, bstride, columns ? kRowTotBytes : 0);
+                                        s.totals, stream, batch, bstride);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }
@@ -759,13 +591,12 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
       uint32_t* rect_sorted = where ? s.k0 : s.k1;   // the key buffer the sort result is NOT in
       const uint32_t nrun = col_runs(P);
       const uint32_t nby = (uint32_t)batch;
-      const int gy = (v.image_height + GSR_TILE - 1) / GSR_TILE;
       hipLaunchKernelGGL(k_col_hist, dim3(nb, nby), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx, s.rects, rect_sorted,
-                         gx, nrun, s.hist1, s.rowtot, gy, bstride);
+                         gx, nrun, s.hist1, bstride);
       hipLaunchKernelGGL(k_radix_scan, dim3(gx, nby), dim3(256), 0, stream, s.hist1, nrun, s.totals1,
                          (const uint64_t*)n_vis_dev, (uint32_t)kColRun, bstride);
       hipLaunchKernelGGL(k_col_plan, dim3(1, nby), dim3(256), 0, stream, s.totals1, gx, s.colstart, n_pairs_dev, bstride,
-                         n_pairs_all, s.rowtot, gy, s.rowstart);
+                         n_pairs_all);
     } else {
       hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx,
                          geom.tiles_touched, geom.block_offsets);
@@ -797,32 +628,25 @@ static int launch_binning_columns(int n, const GsrView& v, const GsrGeom* geoms,
   const uint32_t ny = (uint32_t)n;
   int nbits = 1;
   while ((1 << nbits) < gy) ++nbits;
-  // row pass in one launch (look-back) unless the 28-bit look-back values could overflow; GSR_ROW_PASS=legacy keeps the
-  // three launches (histogram, scan, scatter) for A/B measurements
-  static const bool legacy_env = [] { const char* e = getenv("GSR_ROW_PASS"); return e && e[0] == 'l'; }();
-  const bool one_launch = cap64 < (1ull << 28) && !legacy_env;
-  const uint32_t row_state_words = one_launch ? (uint32_t)kRadix * nblk : 0u;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_DUPLICATE);
     int nbits_x = 1;
     while ((1 << nbits_x) < gx) ++nbits_x;
     hipLaunchKernelGGL(k_emit_cols, dim3(nrun, ny), dim3(64), 0, stream, n_dev_vis, gx, nbits_x, rect_sorted,
-                       geom.sorted_idx, s.hist1, nrun, s.colstart, cap, vals1, hist, row_state_words, totals, ps, ss);
+                       geom.sorted_idx, s.hist1, nrun, s.colstart, cap, vals1, ps, ss);
     GSR_HIP(hipGetLastError());
   }
   {
+    // (round 3 also built this pass as ONE launch with decoupled look-back over the column-aligned blocks, row starts from
+    //  per-row totals left by k_col_hist: bit-identical lists, 87 us per 4-view launch against 84 for these three -- the
+    //  816 blocks of a view are all resident at once, so the look-back chain, not the data, sets the time; not kept)
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    if (one_launch) {
-      hipLaunchKernelGGL(k_row_pass, dim3(nblk, ny), dim3(kSortThreads), 0, stream, vals1, ro, s.colstart, gx, gy, cap, nbits,
-                         s.rowstart, hist, totals, ps, ss);
-    } else {
-      hipLaunchKernelGGL(k_row_hist, dim3(nblk, ny), dim3(kSortThreads), 0, stream, vals1, s.colstart, gx, cap, nbits, nblk,
-                         hist, ps, ss);
-      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix, ny), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr,
-                         1u, ss);
-      hipLaunchKernelGGL(k_row_scatter, dim3(nblk, ny), dim3(kSortThreads), 0, stream, vals1, ro, s.colstart, gx, gy, cap,
-                         nbits, nblk, hist, totals, ps, ss);
-    }
+    hipLaunchKernelGGL(k_row_hist, dim3(nblk, ny), dim3(kSortThreads), 0, stream, vals1, s.colstart, gx, cap, nbits, nblk,
+                       hist, ps, ss);
+    hipLaunchKernelGGL(k_radix_scan, dim3(kRadix, ny), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr,
+                       1u, ss);
+    hipLaunchKernelGGL(k_row_scatter, dim3(nblk, ny), dim3(kSortThreads), 0, stream, vals1, ro, s.colstart, gx, gy, cap,
+                       nbits, nblk, hist, totals, ps, ss);
     GSR_HIP(hipGetLastError());
   }
   for (int k = 0; k < n; ++k) {

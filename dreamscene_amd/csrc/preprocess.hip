@@ -1387,6 +1387,11 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     }
     const unsigned long long m = __ballot(reached);
     if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+    if (lane == 0 && out.reached_mask && first + wave * 64 < P) {
+      // the rows a gradient exchange has to move (GsrGrads.reached_mask): one word per wave, owned by this wave alone
+      unsigned long long* w = reinterpret_cast<unsigned long long*>(out.reached_mask) + (first >> 6) + wave;
+      *w = out.accumulate ? (*w | m) : m;
+    }
     __syncthreads();
     const int cnt = (int)((wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]));
     sparse = cnt <= kK8SparseMax;
@@ -1879,11 +1884,29 @@ bool gsr_preprocess_bwd_views_supported(const GsrView& v, const GsrGaussians& g,
 int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians* gs, const GsrGeom* geoms,
                                     const GsrGrads* outs, hipStream_t stream);
 
+namespace {
+__global__ void __launch_bounds__(256) k_mask_all(unsigned long long* __restrict__ m, int64_t P) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nw = (P + 63) >> 6;
+  if (w >= nw) return;
+  const int64_t rest = P - (w << 6);
+  m[w] = rest >= 64 ? ~0ull : ((1ull << rest) - 1ull);
+}
+}  // namespace
+// a form of K8 that does not classify the reached Gaussians: every row may be non-zero
+static void reached_mask_all(const GsrGrads& out, int32_t P, hipStream_t stream) {
+  if (!out.reached_mask || P <= 0) return;
+  const int64_t nw = ((int64_t)P + 63) >> 6;
+  hipLaunchKernelGGL(k_mask_all, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<unsigned long long*>(out.reached_mask), (int64_t)P);
+}
+
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const GsrGeom& geom, const GsrGrads& out,
                               hipStream_t stream) {
   // the trainers' case (SH rows, scales + rotations, no camera gradients): the sparse kernel with one view
   if (!g.scene && gsr_k8_sparse() && v.sh_stride >= 9 && !out.dL_dcolors && !out.dL_dcov3D && gsr_preprocess_bwd_views_supported(v, g, out))
     return gsr_launch_preprocess_bwd_views(1, &v, &g, &geom, &out, stream);
+  reached_mask_all(out, v.P, stream);
   if (g.scene) {
     SceneTab t; SceneGradTab gt;
     const uint32_t nbs = scene_tables(*g.scene, out.scene, t, gt);
@@ -1961,6 +1984,7 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
   }
   const GsrView& v = views[0];
   const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
+  if (g.scene || !(gsr_k8_sparse() && v.sh_stride >= 9)) reached_mask_all(out0, v.P, stream);
   if (g.scene) {
     SceneTab t; SceneGradTab gt;
     const uint32_t nbs = scene_tables(*g.scene, outs[0].scene, t, gt);

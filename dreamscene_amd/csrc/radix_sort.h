@@ -514,18 +514,13 @@ int radix_sort_u32_legacy(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1
 template <int ITEMS, int OS_ITEMS>
 int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
                    int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream,
-                   int batch = 1, size_t bstride = 0, size_t zero_before = 0) {
-  // zero_before: bytes directly in front of `hist` (a multiple of 16) that the caller wants cleared along with the sort state
+                   int batch = 1, size_t bstride = 0) {
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
-  if (cap >= kOsMaxN || passes > kOsMaxPasses) {
-    if (zero_before) (void)gsr_zero_async((char*)hist - zero_before, zero_before, stream, bstride, (uint32_t)batch);
+  if (cap >= kOsMaxN || passes > kOsMaxPasses)
     return radix_sort_u32_legacy<ITEMS>(k0, v0, k1, v1, n_dev, cap, bits, iota, n_compact, hist, totals, stream, batch, bstride);
-  }
   const uint32_t ntile = os_tiles(cap, OS_ITEMS), nhist = (uint32_t)((cap + kOsHistTile - 1) / kOsHistTile);
   const dim3 grid(ntile, (uint32_t)batch), grid_h(nhist ? nhist : 1, (uint32_t)batch);
-  if (gsr_zero_async((char*)hist - zero_before, zero_before + os_state_words(cap, OS_ITEMS) * 4, stream, bstride,
-                     (uint32_t)batch) != hipSuccess)
-    return passes & 1;
+  if (gsr_zero_async(hist, os_state_words(cap, OS_ITEMS) * 4, stream, bstride, (uint32_t)batch) != hipSuccess) return passes & 1;
   const bool drop = iota && n_compact;
   if (drop)
     hipLaunchKernelGGL((k_os_hist<true>), grid_h, dim3(kSortThreads), 0, stream, k0, n_dev, cap, passes, hist, bstride);

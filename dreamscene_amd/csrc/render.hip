@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t x, uint32_t* w
 // inside a bucket is arbitrary); zeroes tile_depth. Single workgroup.
 // Several views at once: workgroup blockIdx.x builds the list of view blockIdx.x (pointer tables in the kernel arguments).
 struct WorkFwdViews {
-  uint32_t* ranges[GSR_MAX_BATCH_VIEWS];
+  const uint32_t* ranges[GSR_MAX_BATCH_VIEWS];
   uint32_t* tile_depth[GSR_MAX_BATCH_VIEWS];
   uint32_t* work[GSR_MAX_BATCH_VIEWS];
   uint32_t* stats_host[GSR_MAX_BATCH_VIEWS];
@@ -161,7 +161,7 @@ struct WorkBwdViews {
 
 __global__ void __launch_bounds__(1024)
 k_work_order_fwd(const uint32_t n_tiles, const WorkFwdViews wv) {
-  uint32_t* __restrict__ ranges = wv.ranges[blockIdx.x];
+  const uint32_t* __restrict__ ranges = wv.ranges[blockIdx.x];
   uint32_t* __restrict__ tile_depth = wv.tile_depth[blockIdx.x];
   uint32_t* __restrict__ work = wv.work[blockIdx.x];
   uint32_t* __restrict__ stats_host = wv.stats_host[blockIdx.x];
@@ -173,8 +173,6 @@ k_work_order_fwd(const uint32_t n_tiles, const WorkFwdViews wv) {
     const uint32_t len = ranges[2 * t + 1] - ranges[2 * t];
     atomicAdd(&cnt[len ? 32 - __clz(len) : 0], 1u);
     tile_depth[t] = 0;
-    // the one-launch row pass (binning.hip, k_row_pass) leaves (p, p) for an empty tile; the contract is (0, 0)
-    if (len == 0) { ranges[2 * t] = 0u; ranges[2 * t + 1] = 0u; }
   }
   __syncthreads();
   if (tid == 0) {

@@ -35,6 +35,24 @@ class GradArena:
         self.flat = torch.zeros(total, dtype=dtype, device=device)
         shapes = dict(means3D=(P, 3), scales=(P, 3), rotations=(P, 4), opacities=(P, 1), shs=(P, K, 3))
         self.views: Dict[str, torch.Tensor] = {n: self.flat[o:o + sz].view(shapes[n]) for n, (o, sz) in offs.items()}
+        # one bit per Gaussian: "may hold a non-zero row" -- written by K8 itself (GsrGrads.reached_mask: it classifies the
+        # Gaussians K7 reached anyway), so that an exchange need not re-scan the 236 B / Gaussian arena for its non-zero
+        # rows. Valid only while the HIP backward is what fills the arena: anything else that writes `flat` calls touch().
+        self.reached = torch.zeros((P + 63) // 64, dtype=torch.int64, device=device)
+        self.reached_valid = False
+
+    def touch(self) -> None:
+        """The arena was written by something other than the HIP backward: the reached-row bitmap no longer describes it."""
+        self.reached_valid = False
+
+    def reached_rows(self) -> Optional[torch.Tensor]:
+        """Ascending indices of the Gaussians whose row MAY be non-zero (a superset of the non-zero rows), from the bitmap
+        K8 wrote; None when the bitmap is not valid."""
+        if not self.reached_valid:
+            return None
+        sh = torch.arange(64, device=self.reached.device, dtype=torch.int64)
+        bits = ((self.reached.unsqueeze(1) >> sh) & 1).reshape(-1)[:self.P]
+        return torch.nonzero(bits).reshape(-1)
 
     def nbytes(self) -> int:
         return self.flat.numel() * self.flat.element_size()
@@ -151,7 +169,12 @@ class GradExchange:
 
     # ---- non-zero rows
     def nonzero_rows(self) -> torch.Tensor:
-        """Indices (ascending) of the Gaussians whose gradient row has any non-zero entry on this rank."""
+        """Indices (ascending) of the Gaussians whose gradient row has any non-zero entry on this rank -- or, when K8 left
+        its reached-row bitmap (GradArena.reached_rows), the Gaussians K7 reached: a superset (a reached Gaussian's ten
+        sums may still be zero), 62 KB to look at instead of a scan of the whole arena."""
+        idx = self.arena.reached_rows() if hasattr(self.arena, "reached_rows") else None
+        if idx is not None:
+            return idx
         v = self.arena.views
         P, nb = self.arena.P, self.nb
         m = (v["means3D"] != 0).any(1) | (v["scales"] != 0).any(1) | (v["rotations"] != 0).any(1) | \

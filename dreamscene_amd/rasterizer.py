@@ -578,6 +578,9 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
         setattr(gr, k, _ptr(t))
     gr.partials = partials.data_ptr()
     gr.accumulate = int(bool(accumulate and arena is not None))
+    if arena is not None and getattr(arena, "reached", None) is not None:
+        gr.reached_mask = arena.reached.data_ptr()      # K8 marks the rows an exchange has to move (GradArena.reached_rows)
+        arena.reached_valid = True
     _bind_stats(gr, stats, P, dev)
     ig = L.GsrImageGrads()
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
@@ -703,6 +706,9 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         grs[k].dL_dmeans2D = m2d[k].data_ptr()
         grs[k].partials = partials[k].data_ptr()
         grs[k].accumulate = int(bool(accumulate and arena is not None))
+        if arena is not None and getattr(arena, "reached", None) is not None:
+            grs[k].reached_mask = arena.reached.data_ptr()
+            arena.reached_valid = True
         if k in counted:
             _bind_stats(grs[k], stats, P, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream

@@ -208,6 +208,12 @@ typedef struct GsrGrads {
   float* stat_denom;
   const GsrSceneGrads* scene; /* host pointer; required iff GsrGaussians.scene was given: the parameter gradients go
                                  to the models' raw leaves and dL_dmeans3D/scales/rotations/opacities/shs must be NULL */
+  uint64_t* reached_mask;     /* NULL or device u64[(P + 63) / 64]: bit i % 64 of word i / 64 is set when Gaussian i MAY have
+                                 received a non-zero parameter gradient from this call -- the rows a multi-GPU gradient
+                                 exchange has to send (everything behind the opaque front layers of
+                                 an object is exactly zero). K8 classifies the Gaussians K7 reached anyway (its sparse form);
+                                 forms of K8 that do not classify set every bit. accumulate = 0: the words are overwritten;
+                                 accumulate = 1: OR-ed into (the union over the views added to the gradient buffers) */
 } GsrGrads;
 
 /* Optional per-stage timing with HIP events on the caller's stream (bench.py uses it for `roofline`). */

@@ -349,10 +349,16 @@ uint64_t orc_bin_sort(int32_t P, int32_t H, int32_t W, const int32_t* rect, cons
 }
 
 /* --------------------------------------------------------------------------------------------------- K6 */
+/* accumulator type of the per-Gaussian SUMS over pixels (importance score here, the gradient sums in K7): see bwd_pixel */
+#ifdef ORC_OMP
+typedef float acc_t;
+#else
+typedef double acc_t;
+#endif
 static void fwd_pixel(const OrcView* v, int px, int py, const uint32_t* ranges, const uint32_t* point_list,
                       const float* xy, const float* conic_opacity, const float* rgb, const float* depth,
                       float* out_image, float* out_depth_alpha, float* final_T, uint32_t* n_contrib,
-                      float* important_score) {
+                      acc_t* important_score) {
   const int W = v->W, H = v->H;
   const int gx = (W + BLOCK - 1) / BLOCK;
   const int tile = (py / BLOCK) * gx + (px / BLOCK);
@@ -408,10 +414,16 @@ void orc_render_fwd(const OrcView* v, const uint32_t* ranges, const uint32_t* po
                   n_contrib, important_score);
   }
 #else
+  /* scalar build: the score terms (fp32, fixed operator order) are summed in double, like the gradient sums of K7 */
+  acc_t* sc = important_score ? (acc_t*)calloc((size_t)v->P + 1, sizeof(acc_t)) : NULL;
   for (int py = 0; py < H; ++py)
     for (int px = 0; px < W; ++px)
       fwd_pixel(v, px, py, ranges, point_list, xy, conic_opacity, rgb, depth, out_image, out_depth_alpha, final_T,
-                n_contrib, important_score);
+                n_contrib, sc);
+  if (sc) {
+    for (size_t i = 0; i < (size_t)v->P; ++i) important_score[i] += (float)sc[i];
+    free(sc);
+  }
 #endif
 }
 
@@ -425,11 +437,6 @@ void orc_render_fwd(const OrcView* v, const uint32_t* ranges, const uint32_t* po
  * an implementation is held to is the exact sum of the fp32 terms, not one particular fp32 summation order (with random
  * upstream gradients the terms of a large splat cancel to ~1/sqrt(#pixels) of their magnitude, and a sequential fp32 sum over
  * 10^4 pixels is itself 1e-5 .. 1e-4 off). The OpenMP build (used for timing only) keeps float sums. */
-#ifdef ORC_OMP
-typedef float acc_t;
-#else
-typedef double acc_t;
-#endif
 static void bwd_pixel(const OrcView* v, int px, int py, const uint32_t* ranges, const uint32_t* point_list,
                       const float* xy, const float* conic_opacity, const float* rgb, const float* depth,
                       const float* final_T, const uint32_t* n_contrib, const float* dL_dimage,

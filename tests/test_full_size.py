@@ -54,7 +54,7 @@ def _scene(cfg):
             rng = np.random.default_rng(77)
             s = g["scales"].astype(np.float32)
             s[::7, 1] *= 0.01                                     # 1 : 100 needles / flat discs
-            s[3::11, 0] *= 10.0                                   # long streaks across many tiles
+            s[3::11, 0] *= 3.0                                    # elongated along one axis
             noise = rng.standard_normal(s.shape).astype(np.float32) * 8.0   # 8x the trainers' sigma: ~13 % of the axes clamp to 0
             g["scales"] = np.maximum(s + noise * (np.float32(np.sqrt(0.2)) * s / 4.0), 0.0).astype(np.float32)
             assert (g["scales"] == 0.0).mean() > 0.05

@@ -56,12 +56,6 @@ def test_sphere_camera_score_sum_vs_oracle(built_lib, c_oracle, scene, score_mod
     assert np.abs(ref).max() > 0
     assert np.abs(got - ref).max() <= 1e-5 * scale, f"48-camera score sum: {np.abs(got - ref).max():.3e} (scale {scale:.3e})"
     assert np.abs(loop.cpu().numpy() - ref8).max() <= 1e-5 * max(1.0, float(np.abs(ref8).max()))
-    if score_mode == 0:
-        # weight = opacity per contributing (pixel, splat): sums of identical terms, the hit COUNTS must agree exactly
-        hits = np.rint(ref / np.maximum(g["opacities"].reshape(-1).astype(np.float64), 1e-30))
-        hits_got = np.rint(got / np.maximum(g["opacities"].reshape(-1).astype(np.float64), 1e-30))
-        vis = g["opacities"].reshape(-1) > 1e-3
-        assert np.array_equal(hits[vis], hits_got[vis]), "contributing (pixel, splat) counts differ"
 
 
 def test_views_module_returns_four_tuples(built_lib, scene):
