@@ -239,7 +239,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
 // Values need 28 bits: sorts of 2^28 elements or more take the three-kernel passes.
 constexpr int kOsItemsSmall = 8;      // keys per thread, P-sized sorts (2048-key tiles)
 constexpr int kOsMaxPasses = 4;
-constexpr uint32_t kOsHistTile = 4096;  // keys per workgroup of k_os_hist
+constexpr uint32_t kOsHistTile = 2048;  // keys per workgroup of k_os_hist
 constexpr uint32_t kOsTableOff = kOsMaxPasses * kRadix + 16;   // u32 words: [passes][256] histograms | 4 tickets (+ pad) | table
 constexpr uint64_t kOsMaxN = 1ull << 28;
 
@@ -311,7 +311,10 @@ k_os_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev,
 // Look-back of one digit (column `col` of the table) from tile `tile` - 1 downwards: sum of the aggregates met, up to and
 // including the first inclusive word. The words of the next kOsWindow predecessors are requested together (independent
 // loads in flight) and consumed in order, so a walk over k published words costs k / kOsWindow round trips, not k.
-constexpr int kOsWindow = 4;
+#ifndef GSR_OS_WINDOW
+#define GSR_OS_WINDOW 16
+#endif
+constexpr int kOsWindow = GSR_OS_WINDOW;
 __device__ __forceinline__ uint32_t os_look_back(gsr_gu32* table, uint32_t tile, int col, uint32_t tagA, uint32_t tagI) {
   uint32_t excl = 0;
   int p = (int)tile - 1;
@@ -351,12 +354,29 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
   __shared__ uint32_t s_tile, s_ntile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int shift = pass * kRadixBits;
+  const uint64_t n = eff_count(n_dev, cap);
+  if constexpr (!DROP) {
+    // Every key carries the same digit (the top byte of the depths of one object, the high byte of 10-bit tile ids, ...):
+    // the pass is the identity permutation -- a coalesced copy: no ticket, no ranking, no look-back (all workgroups of the
+    // pass take this branch, nobody waits for anybody).
+    const uint32_t x = os[pass * kRadix + tid];
+    if (__syncthreads_or((uint64_t)x == n && n > 0)) {
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
+        if (e < n) {
+          keys_out[e] = keys_in[e];
+          vals_out[e] = IOTA ? (uint32_t)e : vals_in[e];
+        }
+      }
+      return;
+    }
+  }
   if (tid == 0) s_tile = atomicAdd(&os[kOsMaxPasses * kRadix + pass], 1u);      // the ticket: tiles START in this order
 #pragma unroll
   for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
   __syncthreads();
   const uint32_t tile = s_tile;
-  const uint64_t n = eff_count(n_dev, cap);
   if ((uint64_t)tile * T >= n) return;     // (every later ticket is beyond n as well: nobody waits for this tile)
   // exclusive scan of the pass's global digit histogram: where digit d starts in the output
   uint32_t dbase;
@@ -384,20 +404,6 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     const bool valid = e < n;
     key[it] = valid ? keys_in[e] : 0xFFFFFFFFu;
     val[it] = IOTA ? (uint32_t)e : (valid ? vals_in[e] : 0u);
-  }
-  if constexpr (!DROP) {
-    // Every key carries the same digit (the top byte of the depths of one object, the high byte of 10-bit tile ids, ...):
-    // the pass is the identity permutation -- a coalesced copy, no ranking, no look-back (nobody waits for this tile: all
-    // tiles of the pass take this branch).
-    const uint32_t x = os[pass * kRadix + tid];
-    if (__syncthreads_or((uint64_t)x == n && n > 0)) {
-#pragma unroll
-      for (int it = 0; it < ITEMS; ++it) {
-        const uint64_t e = sort_index<ITEMS>(tile, wave, it, lane);
-        if (e < n) { keys_out[e] = key[it]; vals_out[e] = val[it]; }
-      }
-      return;
-    }
   }
   const auto is_valid = [&](int it) {
     const uint64_t e = sort_index<ITEMS>(tile, wave, it, lane);
