@@ -63,6 +63,9 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
     if score_sum is not None and (n_score != V or score_sum.dtype != torch.float32 or tuple(score_sum.shape) != (P,)
                                   or not score_sum.is_contiguous() or score_sum.device != dev):
         raise ValueError("score_sum must be a contiguous fp32 [P] tensor on the Gaussians' device, with score_flag views")
+    if score_sum is not None and int(rc.score_mode) == 0:
+        raise ValueError("score_sum with score_mode 0: use views.importance_scores (it sums raw pixel counts, score_mode 2, "
+                         "and applies the opacity once)")
     batched = (1 < V <= MAX_VIEWS and same and P > 0 and rc.forward_mode == "auto" and ws.hint.get((P, H, W)) is not None
                and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24))
 
@@ -71,7 +74,10 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
                                        want_aux=want_aux, rc=rc) for k, s in enumerate(settings_list)]
         if score_sum is not None:
             for o, _ in res:
-                score_sum.add_(o["score"])
+                if int(rc.score_mode) == 2:       # raw pixel counts: u32 bit patterns in the float32 tensors
+                    score_sum.view(torch.int32).add_(o["score"].view(torch.int32))
+                else:
+                    score_sum.add_(o["score"])
                 o["score"] = score_sum
         return res
     if not batched:
@@ -261,10 +267,24 @@ def importance_scores(settings_list: Sequence, means3D, opacities, shs=None, col
         raise ValueError("importance_scores needs at least one view, all with score_flag=True")
     rc = (context or R.DEFAULT_CONTEXT).snapshot()
     P = int(means3D.shape[0])
-    total = out if out is not None else torch.zeros(P, dtype=torch.float32, device=means3D.device)
+    dev = means3D.device
     chunk = max(1, min(int(chunk), MAX_VIEWS))
+    # weight 0 (opacity per contributing pixel): the kernels COUNT the pixels with integer atomics (score_mode 2: raw counts
+    # in the buffer) over all cameras and the opacity is multiplied in once, in float64 -- exact up to the final rounding
+    # (a float sum of ~10^4 equal increments is only good to ~1e-4). weight 1 (alpha * T): float atomics into the one buffer.
+    counts_mode = int(rc.score_mode) == 0
+    if counts_mode:
+        rc.score_mode = 2
+        acc = torch.zeros(P, dtype=torch.int32, device=dev).view(torch.float32)
+    else:
+        acc = torch.zeros(P, dtype=torch.float32, device=dev)
     with torch.no_grad():
         for i in range(0, len(settings_list), chunk):
             rasterize_views_forward_raw(settings_list[i:i + chunk], means3D, opacities, shs, colors_precomp, scales, rotations,
-                                        cov3D_precomp, rc=rc, score_sum=total)
-    return total
+                                        cov3D_precomp, rc=rc, score_sum=acc)
+        if counts_mode:
+            acc = (acc.view(torch.int32).to(torch.float64) * opacities.reshape(-1).to(torch.float64)).to(torch.float32)
+    if out is not None:
+        out.add_(acc)
+        return out
+    return acc

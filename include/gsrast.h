@@ -53,7 +53,10 @@ typedef struct GsrView {
   int32_t image_height, image_width;
   float tanfovx, tanfovy, scale_modifier;
   int32_t prefiltered;  /* accepted for API parity; no effect (frustum test always runs)               */
-  int32_t score_mode;   /* important_score weight: 0 = opacity per contributing (pixel,splat), 1 = alpha*T */
+  int32_t score_mode;   /* important_score weight: 0 = opacity per contributing (pixel,splat), 1 = alpha*T, 2 = RAW COUNTS:
+                           the number of contributing pixels as uint32 in the (zero-initialised) score buffer, no opacity
+                           factor -- for callers that add many views into one buffer and weight once at the end (mode 0
+                           counts the same way internally, integer atomics, and multiplies by the opacity itself) */
   const float* bg;         /* device f32[3]  */
   const float* viewmatrix; /* device f32[16] */
   const float* projmatrix; /* device f32[16] */
