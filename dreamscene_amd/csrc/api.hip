@@ -10,8 +10,7 @@ bool gsr_preprocess_views_supported(const GsrView&, const GsrGaussians&);
 int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaussians* gs, GsrGeom* geoms, hipStream_t);
 bool gsr_preprocess_bwd_views_supported(const GsrView&, const GsrGaussians&, const GsrGrads&);
 int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians* gs, const GsrGeom* geoms,
-                                    const GsrGrads* outs, hipStream_t, uint32_t pre_cleared);
-bool gsr_k8_views_sparse_form(const GsrView&, const GsrGaussians&);
+                                    const GsrGrads* outs, hipStream_t);
 int gsr_launch_depth_order(GsrGeom&, const GsrView&, hipStream_t, GsrProfile*, int batch, size_t bstride,
                            uint64_t* n_pairs_all);
 uint64_t* gsr_pair_counts(const GsrGeom&, int32_t P);
@@ -24,8 +23,7 @@ int gsr_launch_render_fwd(const GsrView&, const GsrGeom&, const GsrBinning&, Gsr
 int gsr_launch_render_fwd_views(int n, const GsrView* views, const GsrGeom* geoms, const GsrBinning* bs, GsrImages* imgs,
                                 hipStream_t, GsrProfile*);
 int gsr_launch_render_bwd_views(int n, const GsrView* views, const GsrGeom* geoms, const GsrBinning* bs,
-                                const GsrImages* imgs, const GsrImageGrads* igs, GsrGrads* outs, hipStream_t, GsrProfile*,
-                                const GsrZeroFill* side);
+                                const GsrImages* imgs, const GsrImageGrads* igs, GsrGrads* outs, hipStream_t, GsrProfile*);
 int gsr_launch_work_order_fwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
 int gsr_launch_work_order_bwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
 int gsr_launch_render_bwd(const GsrView&, const GsrGeom&, const GsrBinning&, const GsrImages&, const GsrImageGrads&,
@@ -457,29 +455,11 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
     const int rc = gsr_launch_work_order_bwd(n_views, views, bs, imgs, stream);   // all views' work lists in one launch
     if (rc) return rc;
   }
-  uint32_t pre_cleared = 0;
   if (fused) {
     // K7 of all views in one launch
     if (!contiguous)
       for (int k = 0; k < n_views; ++k) GSR_HIP(gsr_zero_async(outs[k].partials, pbytes, stream));
-    // K7 is bound by VALU issue and leaves the memory system idle: it zero-fills, on the side, the gradient buffers the
-    // sparse form of K8 would otherwise clear itself inside its own (HBM-bound) time
-    GsrZeroFill side;
-    if (gsr_k8_views_sparse_form(views[0], *g) && !outs[0].accumulate) {
-      const uint64_t P = (uint64_t)views[0].P, K = (uint64_t)views[0].sh_stride;
-      side.add(outs[0].dL_dshs, P * K * 3); side.add(outs[0].dL_dmeans3D, P * 3); side.add(outs[0].dL_dopacities, P);
-      side.add(outs[0].dL_drotations, P * 4);
-      if (!per_view_scales) side.add(outs[0].dL_dscales, P * 3);
-      pre_cleared |= 1u;
-      bool m2_contig = true, sc_contig = per_view_scales;
-      for (int k = 1; k < n_views; ++k) {
-        m2_contig = m2_contig && outs[k].dL_dmeans2D == outs[0].dL_dmeans2D + (size_t)k * P * 3;
-        sc_contig = sc_contig && outs[k].dL_dscales == outs[0].dL_dscales + (size_t)k * P * 3;
-      }
-      if (m2_contig) { side.add(outs[0].dL_dmeans2D, P * 3 * (uint64_t)n_views); pre_cleared |= 2u; }
-      if (sc_contig) { side.add(outs[0].dL_dscales, P * 3 * (uint64_t)n_views); pre_cleared |= 4u; }
-    }
-    const int rc = gsr_launch_render_bwd_views(n_views, views, geoms, bs, imgs, igs, outs, stream, prof, &side);
+    const int rc = gsr_launch_render_bwd_views(n_views, views, geoms, bs, imgs, igs, outs, stream, prof);
     if (rc) return rc;
   } else {
     for (int k = 0; k < n_views; ++k) {
@@ -500,7 +480,7 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   }
   if (fused) {
     GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
-    const int rc = gsr_launch_preprocess_bwd_views(n_views, views, gs, geoms, outs, stream, pre_cleared);
+    const int rc = gsr_launch_preprocess_bwd_views(n_views, views, gs, geoms, outs, stream);
     if (rc) return rc;
   }
   return GSR_OK;

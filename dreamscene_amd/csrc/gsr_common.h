@@ -80,16 +80,6 @@ struct GsrStageTimer {
   ~GsrStageTimer() { stop(); }
 };
 
-// buffers a compositing launch clears on the side (render.hip, ZeroFill): up to 8 regions of n floats
-struct GsrZeroFill {
-  float* p[8];
-  uint64_t n[8];
-  int count = 0;
-  void add(float* q, uint64_t floats) {
-    if (q && floats && count < 8) { p[count] = q; n[count] = floats; ++count; }
-  }
-};
-
 // ---- clearing device memory with a KERNEL, never hipMemsetAsync: a captured step (hipGraph) whose first node is a memset
 // node was observed to start before the work enqueued ahead of the graph launch had finished (ROCm 7.2: the backward
 // graph ran into the tail of the forward's compositing kernel; tests/test_graph.py). Plain kernel nodes keep stream order.

@@ -1293,9 +1293,6 @@ struct K8Views {
   const float* scale_noise[GSR_MAX_BATCH_VIEWS];
   const float* sh_noise[GSR_MAX_BATCH_VIEWS];
   const float* dL_dscales_out[GSR_MAX_BATCH_VIEWS];
-  // bits: 1 = the parameter-gradient buffers, 2 = the views' dL_dmeans2D, 4 = the per-view dL_dscales arrive CLEARED (K7
-  // zero-filled them on the side, render.hip ZeroFill): the sparse form then writes the reached rows only
-  uint32_t pre_cleared;
   // bit k set: view k's densification statistics count (the reference's trainers use the LAST view of a step only,
   // object_trainer.py:386-390; a caller sets the stat_* pointers on the GsrGrads entries of the views that count)
   uint32_t stat_mask;
@@ -1399,7 +1396,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     const int cnt = (int)((wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]));
     sparse = cnt <= kK8SparseMax;
     if (sparse) {
-      if (!out.accumulate && !(vb.pre_cleared & 1u)) {
+      if (!out.accumulate) {
         const int nblk = (int)min((int64_t)256, P - first);
         block_zero<true>(out.dL_dshs + first * F, nblk * F);
         block_zero<false>(out.dL_dmeans3D + first * 3, nblk * 3);
@@ -1409,15 +1406,11 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       }
       if (ok && !reached) {   // what the chain rule below would produce from zeros
         for (int vv = 0; vv < vb.nv; ++vv) {
-          if (!(vb.pre_cleared & 2u)) {
-            float* m2 = vb.dL_dmeans2D[vv];
-            m2[3 * i] = 0.f; m2[3 * i + 1] = 0.f; m2[3 * i + 2] = 0.f;
-          }
+          float* m2 = vb.dL_dmeans2D[vv];
+          m2[3 * i] = 0.f; m2[3 * i + 1] = 0.f; m2[3 * i + 2] = 0.f;
           if constexpr (PVS) {
-            if (!(vb.pre_cleared & 4u)) {
-              float* o = vb.dL_dscales[vv];
-              o[3 * i] = 0.f; o[3 * i + 1] = 0.f; o[3 * i + 2] = 0.f;
-            }
+            float* o = vb.dL_dscales[vv];
+            o[3 * i] = 0.f; o[3 * i + 1] = 0.f; o[3 * i + 2] = 0.f;
           }
           if (out.stat_denom && ((vb.stat_mask >> vv) & 1u)) {
             const int32_t r = vb.radii[vv][i];
@@ -1889,7 +1882,7 @@ static bool gsr_k8_sparse() {
 
 bool gsr_preprocess_bwd_views_supported(const GsrView& v, const GsrGaussians& g, const GsrGrads& out);
 int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians* gs, const GsrGeom* geoms,
-                                    const GsrGrads* outs, hipStream_t stream, uint32_t pre_cleared = 0);
+                                    const GsrGrads* outs, hipStream_t stream);
 
 namespace {
 __global__ void __launch_bounds__(256) k_mask_all(unsigned long long* __restrict__ m, int64_t P) {
@@ -1960,18 +1953,11 @@ bool gsr_preprocess_bwd_views_supported(const GsrView& v, const GsrGaussians& g,
          out.dL_dshs && out.dL_dscales && out.dL_drotations && out.dL_dmeans3D && out.dL_dopacities;
 }
 
-// Will gsr_launch_preprocess_bwd_views run the sparse form (the one that clears gradient rows itself unless told they
-// arrive cleared)?
-bool gsr_k8_views_sparse_form(const GsrView& v, const GsrGaussians& g) {
-  return !g.scene && gsr_k8_sparse() && v.sh_stride >= 9;
-}
-
 int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians* gs, const GsrGeom* geoms,
-                                    const GsrGrads* outs, hipStream_t stream, uint32_t pre_cleared) {
+                                    const GsrGrads* outs, hipStream_t stream) {
   const GsrGaussians& g = gs[0];
   K8Views vb = K8Views{};
   vb.nv = n_views;
-  vb.pre_cleared = gsr_k8_views_sparse_form(views[0], g) ? pre_cleared : 0u;
   for (int k = 0; k < n_views; ++k) {
     if (g.scene) {
       vb.scale_noise[k] = gs[k].scene->scale_noise; vb.sh_noise[k] = gs[k].scene->sh_noise;
