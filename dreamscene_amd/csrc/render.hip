@@ -631,6 +631,13 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 // checkpoint at the segment end (prefix transmittance T_c and prefix sums C_c, D_c, W_c): the colour / depth /
 // alpha composited BEHIND that point, normalised to start there, is (X_final - X_c) / T_c, which is exactly the
 // `rec` state the sequential traversal would carry at that position. Other pixels start from their final state.
+// Round 3, measured and not kept (both bit-identical in their results; A/B in one gpurun call, C3, 4-view launch):
+//  * two pixels per lane (a wave owns a 16x8 half tile, 2 waves per item, the reduction and the atomic shared by the two
+//    8x8 blocks; NOT v_pk_* arithmetic: v_pk_fma_f32 issues at half the rate of v_fma_f32 on gfx950, tools/probe): 279 us
+//    against 238 -- what the shared reduction saves (37 of ~95 instructions per block) the three-way control flow and
+//    its register copies give back, and half as many waves hide less latency;
+//  * the launch zero-filling the 142 MB of gradient buffers K8's sparse form otherwise clears itself ("K7 is VALU-bound,
+//    the stores are free"): K8 100 -> 86 us, K7 236 -> 274 us. The stores are not free: K7's atomics share the path.
 __device__ __forceinline__ void
 render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* __restrict__ items, const uint32_t* __restrict__ tile_depth,
              const float* __restrict__ ckpt,
@@ -765,198 +772,6 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
 }
 
 
-// --------------------------------------------------------------------------------------- K7, two pixels per lane
-// Same work item (tile, 256-entry segment), same arithmetic per (pixel, splat), same sums -- but a wave owns a 16x8
-// HALF tile: lane (x, y) holds the pixels (x, y) of the left 8x8 block and (x + 8, y) of the right one, and a workgroup
-// is 2 waves. What a wave pays once per (splat, block) in the one-pixel kernel -- loop control on the scalar unit, the
-// LDS reads of the staged record, the 23-instruction transposed reduction, the atomic -- it now pays once per
-// (splat, half tile): the splats of these workloads are 10-30 px wide, two neighbouring 8x8 blocks see mostly the same
-// candidates. The 8x8-block culling granularity is kept: the staged reach mask still has one bit per 8x8 block and a
-// block the splat cannot reach is skipped by a scalar branch.
-// (Measured on this part, tools/probe/valu_rate*.hip: v_pk_fma_f32 issues at half the rate of v_fma_f32 -- packed fp32
-// does not raise the fp32 rate on gfx950 -- so the pixel pair is NOT packed into v_pk_* operations; the gain is the
-// amortisation above, not wider arithmetic.)
-struct BwdPixel {
-  float pxf, Tf, T, R, gC0, gC1, gC2, gD, gA, bg_dot;
-  uint32_t last;
-};
-
-
-// One pixel of the lane against one splat: alpha, gates, the recurrences, the per-pixel factors of the ten sums (zero for
-// lanes that do not composite the splat). Returns the lane mask of the compositing pixels.
-__device__ __forceinline__ unsigned long long
-bwd2_pixel(BwdPixel& p, const unsigned long long livem, const float dx, const float dy, const float nBdy, const float hCdy2,
-           const float4 a, const float4 b, const float4* s2, const int j, float& qv, float& wv, float& gdl, float& u,
-           float& w2) {
-  // gsr_power(hA, nB, hC, dx, dy) with the dy-only products shared by the two pixels of the lane (same bits)
-  const float power = __fmaf_rn(dx, __fmaf_rn(a.z, dx, nBdy), hCdy2);
-  const float G = gsr_exp(power);
-  const float alpha = fminf(GSR_ALPHA_MAX, gsr_mul(b.y, G));
-  const unsigned long long hitm = livem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
-                                  __builtin_amdgcn_ballot_w64(alpha >= GSR_ALPHA_MIN);
-  // Branch-free: a lane that does not composite the splat runs the same instructions on alpha = 0, G = 0, which leave
-  // its recurrences untouched bit for bit (T * rcp(1) = T, 0 * s + 1 * R = R) and its factors of the sums at zero -- two
-  // selects instead of an exec-masked region whose merged values cost a register copy each.
-  const bool hit = __builtin_amdgcn_inverse_ballot_w64(hitm);
-  const float al = hit ? alpha : 0.0f, Gh = hit ? G : 0.0f;
-  const float2 c = *reinterpret_cast<const float2*>(&s2[j]);
-  const float om = 1.0f - al;
-  const float inv = __builtin_amdgcn_rcpf(om);
-  p.T = p.T * inv;
-  wv = al * p.T;
-  const float sdot = b.w * p.gC0 + c.x * p.gC1 + c.y * p.gC2 + b.z * p.gD + p.gA;
-  float dL_dalpha = (sdot - p.R) * p.T;
-  dL_dalpha -= (p.Tf * inv) * p.bg_dot;
-  p.R = al * sdot + om * p.R;
-  gdl = Gh * dL_dalpha;
-  qv = (b.y * dL_dalpha) * Gh;
-  u = __fmaf_rn(a.z + a.z, dx, nBdy);
-  w2 = __fmaf_rn(b.x + b.x, dy, gsr_mul(a.w, dx));
-  return hitm;
-}
-
-__device__ __forceinline__ void
-bwd2_one(BwdPixel& p, const float pyf, const uint32_t pos, const float4 a, const float4 b, const float4* s2, const int j,
-         const int lane, const bool commit, float* row0, const uint32_t* sid) {
-  const unsigned long long livem = __builtin_amdgcn_ballot_w64(pos < p.last);
-  if (livem == 0ull) return;
-  const float dx = a.x - p.pxf, dy = a.y - pyf;
-  const float nBdy = gsr_mul(a.w, dy), hCdy2 = gsr_mul(gsr_mul(b.x, dy), dy);
-  float qv, wv, gdl, u, w2;
-  if (bwd2_pixel(p, livem, dx, dy, nBdy, hCdy2, a, b, s2, j, qv, wv, gdl, u, w2) == 0ull) return;
-  float v[10];
-  const float m1 = qv * u, m2 = qv * w2;
-  v[0] = m1; v[1] = m2; v[2] = m1 * u; v[3] = m1 * w2; v[4] = m2 * w2; v[5] = gdl;
-  v[6] = wv * p.gC0; v[7] = wv * p.gC1; v[8] = wv * p.gC2; v[9] = wv * p.gD;
-  const float sred = reduce10(v, lane);
-  if (commit) unsafeAtomicAdd(row0 + 12 * (size_t)sid[j], sred);
-}
-
-__device__ __forceinline__ void
-bwd2_both(BwdPixel& p0, BwdPixel& p1, const float pyf, const uint32_t pos, const float4 a, const float4 b, const float4* s2,
-          const int j, const int lane, const bool commit, float* row0, const uint32_t* sid) {
-  const unsigned long long live0 = __builtin_amdgcn_ballot_w64(pos < p0.last), live1 = __builtin_amdgcn_ballot_w64(pos < p1.last);
-  if ((live0 | live1) == 0ull) return;
-  const float dy = a.y - pyf;
-  const float nBdy = gsr_mul(a.w, dy), hCdy2 = gsr_mul(gsr_mul(b.x, dy), dy);
-  float q0, w0, g0, u0, t0, q1, w1, g1, u1, t1;
-  const unsigned long long h0 = bwd2_pixel(p0, live0, a.x - p0.pxf, dy, nBdy, hCdy2, a, b, s2, j, q0, w0, g0, u0, t0);
-  const unsigned long long h1 = bwd2_pixel(p1, live1, a.x - p1.pxf, dy, nBdy, hCdy2, a, b, s2, j, q1, w1, g1, u1, t1);
-  if ((h0 | h1) == 0ull) return;
-  float v[10];
-  const float m1 = q0 * u0, m2 = q0 * t0, n1 = q1 * u1, n2 = q1 * t1;
-  v[0] = m1 + n1; v[1] = m2 + n2;
-  v[2] = __fmaf_rn(n1, u1, m1 * u0); v[3] = __fmaf_rn(n1, t1, m1 * t0); v[4] = __fmaf_rn(n2, t1, m2 * t0);
-  v[5] = g0 + g1;
-  v[6] = __fmaf_rn(w1, p1.gC0, w0 * p0.gC0); v[7] = __fmaf_rn(w1, p1.gC1, w0 * p0.gC1);
-  v[8] = __fmaf_rn(w1, p1.gC2, w0 * p0.gC2); v[9] = __fmaf_rn(w1, p1.gD, w0 * p0.gD);
-  const float sred = reduce10(v, lane);
-  if (commit) unsafeAtomicAdd(row0 + 12 * (size_t)sid[j], sred);
-}
-
-__device__ __forceinline__ void
-render_bwd2_body(const uint32_t item, const int W, const int H, const uint32_t* __restrict__ items,
-                 const uint32_t* __restrict__ tile_depth, const float* __restrict__ ckpt, const uint32_t* __restrict__ ranges,
-                 const uint32_t* __restrict__ point_list, const float4* __restrict__ splat, const float* __restrict__ bg,
-                 const float* __restrict__ color, const float* __restrict__ depth_alpha, const float* __restrict__ final_T,
-                 const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-                 const float* __restrict__ dL_dda, float* __restrict__ partials) {
-  __shared__ float4 s0[kBatch], s1[kBatch], s2[kBatch];
-  __shared__ uint32_t sid[kBatch], smask[kBatch];
-  const int gx = (W + GSR_TILE - 1) / GSR_TILE;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;     // 128 threads: wave 0 = upper half tile, 1 = lower
-  if (item >= items[0]) return;
-  const int tile = (int)items[2 + 2 * item];
-  const uint32_t seg = items[3 + 2 * item];
-  const uint32_t depth = tile_depth[tile];
-  const uint32_t lo = seg * kBatch, hi = min(lo + (uint32_t)kBatch, depth);
-  const int n = (int)(hi - lo);
-  const int ty = tile / gx, tx = tile - ty * gx;
-  const int tile_x0 = tx * GSR_TILE, tile_y0 = ty * GSR_TILE;
-  const uint32_t r0 = ranges[2 * tile];
-  const size_t HW = (size_t)H * W;
-
-  // stage the segment, last entry first: two gathers per thread
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int e = tid + 128 * r;
-    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = make_float4(0, 0, -1.f, -1.f);
-    uint32_t nid = 0;
-    if (e < n) {
-      nid = point_list[r0 + (hi - 1u - (uint32_t)e)];
-      const float4* rr = splat + 3 * (size_t)nid;
-      n0 = rr[0]; n1 = rr[1]; n2 = rr[2];
-    }
-    s0[e] = make_float4(n0.x, n0.y, -0.5f * n0.z, -n0.w);              // conic staged as (hA, nB, hC)
-    s1[e] = make_float4(-0.5f * n1.x, n1.y, n1.z, n1.w);
-    s2[e] = n2;
-    sid[e] = nid;
-    smask[e] = (e < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u;
-  }
-
-  // the lane's two pixels: same row, 8 columns apart
-  const int py = tile_y0 + wave * 8 + (lane >> 3);
-  const float pyf = (float)py;
-  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-  BwdPixel px[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int pxi = tile_x0 + 8 * s + (lane & 7);
-    const bool inside = (pxi < W) && (py < H);
-    const size_t pix = (size_t)py * W + pxi;
-    BwdPixel& p = px[s];
-    p.pxf = (float)pxi;
-    p.Tf = inside ? final_T[pix] : 0.f;
-    p.last = inside ? n_contrib[pix] : 0u;
-    p.gC0 = p.gC1 = p.gC2 = p.gD = p.gA = 0.f;
-    if (inside) {
-      p.gC0 = dL_dcolor[pix]; p.gC1 = dL_dcolor[HW + pix]; p.gC2 = dL_dcolor[2 * HW + pix];
-      p.gD = dL_dda[pix]; p.gA = dL_dda[HW + pix];
-    }
-    p.bg_dot = (bg0 * p.gC0 + bg1 * p.gC1) + bg2 * p.gC2;
-    p.T = p.Tf;
-    p.R = 0.f;
-    if (p.last > hi) {
-      // this pixel keeps compositing beyond the segment: start from the forward's checkpoint at position hi
-      const float* ck = ckpt + (size_t)((r0 + hi) / kBatch) * (6 * 256) + ((py - tile_y0) * GSR_TILE + (pxi - tile_x0));
-      const float Tc = ck[0];
-      const float inv = 1.0f / Tc;
-      p.T = Tc;
-      const float rc0 = ((color[pix] - p.Tf * bg0) - ck[256]) * inv;
-      const float rc1 = ((color[HW + pix] - p.Tf * bg1) - ck[512]) * inv;
-      const float rc2 = ((color[2 * HW + pix] - p.Tf * bg2) - ck[768]) * inv;
-      const float rec_z = (depth_alpha[pix] - ck[1024]) * inv;
-      const float rec_a = (depth_alpha[HW + pix] - ck[1280]) * inv;
-      p.R = rc0 * p.gC0 + rc1 * p.gC1 + rc2 * p.gC2 + rec_z * p.gD + rec_a * p.gA;
-    }
-  }
-
-  const int l16 = lane & 15, rr = lane >> 4;
-  const int comp = 4 * ((l16 & 4) ? 2 : ((l16 & 8) ? 1 : 0)) + (((rr & 1) << 1) | (rr >> 1));
-  const bool commit = (l16 == 0 || l16 == 4 || l16 == 8) && (comp < 10);
-  __syncthreads();
-
-  const int mshift = 2 * wave;      // this wave's two blocks are bits (2 wave) and (2 wave + 1) of a reach mask
-  float* const row0 = partials + comp;
-  for (int k = 0; k < kBatch / 64; ++k) {
-    if (k * 64 >= n) break;
-    const uint32_t mymask = (smask[k * 64 + lane] >> mshift) & 3u;
-    unsigned long long bits = __ballot(mymask != 0u);
-    const unsigned long long bitsA = __ballot((mymask & 1u) != 0u), bitsB = __ballot((mymask & 2u) != 0u);
-    while (bits) {
-      const int jj = __builtin_ctzll(bits);
-      bits &= bits - 1ull;
-      const int j = k * 64 + jj;
-      const uint32_t pos = hi - 1u - (uint32_t)j;      // 0-based list position
-      const bool inA = (bitsA >> jj) & 1ull, inB = (bitsB >> jj) & 1ull;       // wave-uniform
-      // three straight-line bodies (each ends in its own reduction + atomic: no values merge across the branches)
-      if (inA && inB) bwd2_both(px[0], px[1], pyf, pos, s0[j], s1[j], s2, j, lane, commit, row0, sid);
-      else if (inA) bwd2_one(px[0], pyf, pos, s0[j], s1[j], s2, j, lane, commit, row0, sid);
-      else bwd2_one(px[1], pyf, pos, s0[j], s1[j], s2, j, lane, commit, row0, sid);
-    }
-  }
-}
-
 }  // namespace
 
 // fixed grid for strided kernels: workgroups per CU x CU count (cached per device)
@@ -1035,15 +850,6 @@ k_render_bwd(const int W, const int H, const BwdViews bv, const uint32_t n_views
   render_bwd_body(item, W, H, bv.items[y], bv.tile_depth[y], bv.ckpt[y], bv.ranges[y], bv.point_list[y], bv.splat[y], bv.bg[y],
                   bv.color[y], bv.depth_alpha[y], bv.final_T[y], bv.n_contrib[y], bv.dL_dcolor[y], bv.dL_dda[y],
                   bv.partials[y]);
-}
-
-__global__ void __launch_bounds__(128)
-k_render_bwd2(const int W, const int H, const BwdViews bv, const uint32_t n_views, const uint32_t per_view) {
-  const uint32_t item = per_view ? blockIdx.x % per_view : blockIdx.x / n_views;
-  const int y = (int)(per_view ? blockIdx.x / per_view : blockIdx.x - item * n_views);
-  render_bwd2_body(item, W, H, bv.items[y], bv.tile_depth[y], bv.ckpt[y], bv.ranges[y], bv.point_list[y], bv.splat[y], bv.bg[y],
-                   bv.color[y], bv.depth_alpha[y], bv.final_T[y], bv.n_contrib[y], bv.dL_dcolor[y], bv.dL_dda[y],
-                   bv.partials[y]);
 }
 
 // The stage timers (GSR_STAGE_RENDER_FWD / _BWD) bracket the compositing kernel alone (not the work-list kernel), so
@@ -1144,14 +950,8 @@ int gsr_launch_render_bwd_views(int n, const GsrView* views, const GsrGeom* geom
     items_cap = bs[k].bwd_items_cap > items_cap ? bs[k].bwd_items_cap : items_cap;
   }
   GsrStageTimer timer(prof, stream, GSR_STAGE_RENDER_BWD);
-  // GSR_K7=1: the one-pixel-per-lane kernel (4 waves per item), kept for A/B measurements
-  static const bool one_px = [] { const char* e = getenv("GSR_K7"); return e && e[0] == '1'; }();
-  if (one_px)
-    hipLaunchKernelGGL(k_render_bwd, dim3(items_cap * (uint32_t)n), dim3(256), 0, stream, v.image_width, v.image_height, bv,
-                       (uint32_t)n, bs[0].fwd_mode == 1 ? items_cap : 0u);   // same regime switch as the forward variant
-  else
-    hipLaunchKernelGGL(k_render_bwd2, dim3(items_cap * (uint32_t)n), dim3(128), 0, stream, v.image_width, v.image_height, bv,
-                       (uint32_t)n, bs[0].fwd_mode == 1 ? items_cap : 0u);
+  hipLaunchKernelGGL(k_render_bwd, dim3(items_cap * (uint32_t)n), dim3(256), 0, stream, v.image_width, v.image_height, bv, (uint32_t)n,
+                     bs[0].fwd_mode == 1 ? items_cap : 0u);   // same regime switch as the forward variant
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }
