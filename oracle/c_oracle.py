@@ -140,3 +140,84 @@ def backward(view: OrcView, fwd: dict, dL_dimage, dL_ddepth_alpha, means3D, shs=
                          _p(g["dL_dview"]), _p(g["dL_dproj"]), _p(g["dL_dcampos"]))
     g["dL_dcolors"] = g["dL_drgb"] if shs is None else None
     return g
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The scalar fp32 oracle behind the reference's module interface (`GaussianRasterizer(raster_settings)(means3D=..., ...)`),
+# with autograd: forward = orc_* forward, backward = the oracle's hand-derived backward. Used by tests/golden/make_golden.py
+# to run the reference's UNCHANGED object_render / scene_render in fp32 and record what crosses the rasterizer boundary
+# (tests/golden/raster_boundary.npz), and by the tests that replay those records. Test infrastructure only.
+def _torch():
+    import torch
+    return torch
+
+
+class _Recorder(dict):
+    pass
+
+
+def make_rasterizer_module(recorder: Optional[dict] = None, score_mode: int = 0):
+    """Returns a class with the reference's constructor signature; every call appends what it saw to `recorder`."""
+    torch = _torch()
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, opacities, shs, scales, rotations, s):
+            P = int(means3D.shape[0])
+            M = int(shs.shape[1])
+            v = make_view(P, M, int(s.sh_degree), int(s.image_height), int(s.image_width), float(s.tanfovx), float(s.tanfovy),
+                          s.bg.detach().cpu().numpy(), s.viewmatrix.detach().cpu().numpy(), s.projmatrix.detach().cpu().numpy(),
+                          s.campos.detach().cpu().numpy(), scale_modifier=float(s.scale_modifier), score_mode=score_mode)
+            n = lambda t: t.detach().cpu().numpy().astype(np.float32)
+            a = dict(means3D=n(means3D), opacities=n(opacities), shs=n(shs), scales=n(scales), rotations=n(rotations))
+            f = forward(v, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"],
+                        score=bool(s.score_flag))
+            ctx.v, ctx.f, ctx.a = v, f, a
+            ctx.rec = None
+            if recorder is not None:
+                ctx.rec = dict(inputs=a, image=f["image"].copy(), radii=f["radii"].copy(), depth_alpha=f["depth_alpha"].copy(),
+                               settings=dict(image_height=int(s.image_height), image_width=int(s.image_width),
+                                             tanfovx=float(s.tanfovx), tanfovy=float(s.tanfovy),
+                                             bg=s.bg.detach().cpu().numpy().astype(np.float32),
+                                             scale_modifier=float(s.scale_modifier),
+                                             viewmatrix=s.viewmatrix.detach().cpu().numpy().astype(np.float32),
+                                             projmatrix=s.projmatrix.detach().cpu().numpy().astype(np.float32),
+                                             sh_degree=int(s.sh_degree),
+                                             campos=s.campos.detach().cpu().numpy().astype(np.float32)))
+                recorder.setdefault("calls", []).append(ctx.rec)
+            img, da = torch.tensor(f["image"]), torch.tensor(f["depth_alpha"])
+            radii = torch.tensor(f["radii"])
+            ctx.mark_non_differentiable(radii)
+            ctx.opac_shape = tuple(opacities.shape)
+            return img, radii, da
+
+        @staticmethod
+        def backward(ctx, g_img, _g_radii, g_da):
+            torch = _torch()
+            H, W = ctx.v.H, ctx.v.W
+            gi = np.zeros((3, H, W), np.float32) if g_img is None else g_img.detach().cpu().numpy().astype(np.float32)
+            gd = np.zeros((2, H, W), np.float32) if g_da is None else g_da.detach().cpu().numpy().astype(np.float32)
+            a = ctx.a
+            b = backward(ctx.v, ctx.f, gi, gd, a["means3D"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+            if ctx.rec is not None:
+                ctx.rec["upstream"] = dict(dL_dimage=gi, dL_ddepth_alpha=gd)
+                ctx.rec["grads"] = {k: np.asarray(b[k]).copy() for k in
+                                    ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dshs", "dL_dscales", "dL_drotations")}
+            t = lambda k: torch.tensor(np.asarray(b[k]))
+            return (t("dL_dmeans3D"), t("dL_dmeans2D"), t("dL_dopacity").reshape(ctx.opac_shape), t("dL_dshs"),
+                    t("dL_dscales"), t("dL_drotations"), None)
+
+    class GaussianRasterizer(torch.nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None):
+            if shs is None or colors_precomp is not None or scales is None or rotations is None or cov3D_precomp is not None:
+                raise Exception("this oracle module covers the trainers' call: shs + scales + rotations")
+            if self.raster_settings.score_flag:
+                raise Exception("score_flag: use oracle.c_oracle.forward(score=True)")
+            return _Fn.apply(means3D, means2D, opacities, shs, scales, rotations, self.raster_settings)
+
+    return GaussianRasterizer

@@ -11,6 +11,11 @@ plain input/output arrays. What each fixture pins:
                      oracle, three models, test=True: activation + torch.cat glue and gradient landing sites
   ply_elements.npz   the vertex table GaussianModel.save_ply (gs_renderer.py:728-744) hands to plyfile
   prune.npz          calculate_v_imp_score + GaussianModel.prune_gaussians' mask (importance filtering threshold)
+  raster_boundary.npz what crosses the rasterizer boundary when the reference's UNCHANGED object_render / scene_render run
+                     in fp32 over the scalar C oracle (oracle/c_oracle.py: make_rasterizer_module): the settings, the
+                     activated / augmented inputs, the outputs, the upstream gradients autograd delivers and the gradients
+                     the rasterizer returns -- object_render test=True and test=False (2 seeds), scene_render test=True and
+                     test=False. The HIP rasterizer replays these records at 1e-5 (tests/test_boundary_fixture.py).
   object_render.npz  the reference's UNCHANGED SceneGaussian.object_render (scene_gaussian.py:895-1044) driven over
                      this repo's CPU oracle registered as `diff_gaussian_rasterization` (BASELINE.json config 1,
                      "plumbing"): settings construction, output dict, disp post-processing, where .grad lands.
@@ -321,6 +326,48 @@ def main():
              table=np.stack([el[n] for n in el.dtype.names], axis=1),
              **{leaf: getattr(m2, leaf).detach().numpy() for leaf in
                 ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")})
+    # ---- what crosses the rasterizer boundary under the reference's own calls, fp32 (see the header)
+    from oracle import c_oracle as CO
+    orig = SG.GaussianRasterizer
+    leaves_all = [gm._xyz, gm._scaling, gm._rotation, gm._opacity, gm._features_dc, gm._features_rest] + \
+        [getattr(m, leaf) for m in models for leaf in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")]
+    cases = {}
+
+    def run_case(name, fn, seed):
+        random.seed(seed)
+        torch.manual_seed(seed)
+        rec = {}
+        SG.GaussianRasterizer = CO.make_rasterizer_module(rec)
+        for prm in leaves_all:
+            prm.grad = None
+        try:
+            out = fn()
+            gi_ = torch.tensor(np.random.default_rng(seed).normal(size=(3, 64, 64)).astype(np.float32))
+            gd_ = torch.tensor(np.random.default_rng(seed + 1).normal(size=(1, 64, 64)).astype(np.float32))
+            ga_ = torch.tensor(np.random.default_rng(seed + 2).normal(size=(1, 64, 64)).astype(np.float32))
+            loss = (out["image"] * gi_).sum() + (out["depth"] * gd_).sum() + (out["alpha"] * ga_).sum() + \
+                0.01 * torch.mean(out["scales"], dim=-1).mean()
+            loss.backward()
+        finally:
+            SG.GaussianRasterizer = orig
+        (call,) = rec["calls"]
+        cases[name] = call
+
+    run_case("object_test", lambda: sg.object_render(gm, cam, bg.clone(), test=True), 3)
+    run_case("object_train31", lambda: sg.object_render(gm, cam, bg.clone(), test=False), 31)
+    run_case("object_train7", lambda: sg.object_render(gm, cam, bg.clone(), test=False), 7)
+    run_case("scene_test", lambda: sg.scene_render(names, cam, bg.clone(), test=True), 5)
+    run_case("scene_train11", lambda: sg.scene_render(names, cam, bg.clone(), test=False), 11)
+    flat = {"cases": np.array(sorted(cases))}
+    for name, c in cases.items():
+        for k, v in c["settings"].items():
+            flat[f"{name}/settings/{k}"] = np.asarray(v)
+        for grp in ("inputs", "upstream", "grads"):
+            for k, v in c[grp].items():
+                flat[f"{name}/{grp}/{k}"] = np.asarray(v)
+        for k in ("image", "radii", "depth_alpha"):
+            flat[f"{name}/out/{k}"] = c[k]
+    np.savez_compressed(os.path.join(HERE, "raster_boundary.npz"), **flat)
     print("fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -1,0 +1,91 @@
+"""What crosses the rasterizer boundary when the REFERENCE's own object_render / scene_render run (fp32) -- recorded by
+tests/golden/make_golden.py from /root/reference over the scalar C oracle (tests/golden/raster_boundary.npz): the 12
+settings fields the reference constructed, the activated / noise-augmented tensors it handed over, the outputs, the
+upstream gradients autograd delivered (through the reference's disp post-processing) and the gradients returned.
+Cases: object_render test=True and test=False (two seeds: SH degree dropped / random background / SH + scale noise),
+scene_render (three models concatenated) test=True and test=False (scene_gaussian.py:673-893, 895-1044).
+CPU: the oracle replays the records. GPU: the HIP rasterizer, behind the drop-in module, replays them at 1e-5 with
+bit-exact radii -- reference-derived inputs through the product path at the north star's tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-5
+
+
+def _cases():
+    d = np.load(os.path.join(HERE, "golden", "raster_boundary.npz"))
+    out = {}
+    for name in d["cases"]:
+        name = str(name)
+        c = {"settings": {}, "inputs": {}, "upstream": {}, "grads": {}, "out": {}}
+        for k in d.files:
+            if k.startswith(name + "/"):
+                _, grp, key = k.split("/")
+                c[grp][key] = d[k]
+        out[name] = c
+    return out
+
+
+CASES = _cases()
+
+
+def _close(a, ref, what):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    e = float(np.abs(a - ref).max()) if a.size else 0.0
+    assert e <= TOL * max(1.0, float(np.abs(ref).max())), f"{what}: max abs err {e:.3e} (max|ref| {np.abs(ref).max():.3e})"
+
+
+def test_fixture_covers_the_reference_calls():
+    assert set(CASES) == {"object_test", "object_train31", "object_train7", "scene_test", "scene_train11"}
+    s = CASES["object_train31"]["settings"]
+    assert int(s["sh_degree"]) == 0                      # the sh_deg_aug branch of scene_gaussian.py:938-947 was taken
+    assert not np.array_equal(CASES["object_train31"]["inputs"]["scales"], CASES["object_test"]["inputs"]["scales"])
+    assert CASES["scene_test"]["inputs"]["means3D"].shape[0] == 300 + 517 + 130     # three models, torch.cat order
+    assert not np.array_equal(CASES["scene_train11"]["inputs"]["shs"], CASES["scene_test"]["inputs"]["shs"])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_replays_the_record(c_oracle, name):
+    c = CASES[name]
+    s, a = c["settings"], c["inputs"]
+    P, K = a["means3D"].shape[0], a["shs"].shape[1]
+    v = c_oracle.make_view(P, K, int(s["sh_degree"]), int(s["image_height"]), int(s["image_width"]), float(s["tanfovx"]),
+                           float(s["tanfovy"]), s["bg"], s["viewmatrix"], s["projmatrix"], s["campos"],
+                           scale_modifier=float(s["scale_modifier"]))
+    f = c_oracle.forward(v, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+    assert np.array_equal(f["radii"], c["out"]["radii"]) and np.array_equal(f["image"], c["out"]["image"])
+    b = c_oracle.backward(v, f, c["upstream"]["dL_dimage"], c["upstream"]["dL_ddepth_alpha"], a["means3D"], shs=a["shs"],
+                          scales=a["scales"], rotations=a["rotations"])
+    for k, ref in c["grads"].items():
+        assert np.array_equal(np.asarray(b[k]).reshape(ref.shape), ref), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hip_replays_the_record(built_lib, name):
+    from dreamscene_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    c = CASES[name]
+    s, a = c["settings"], c["inputs"]
+    t = lambda x: torch.tensor(np.asarray(x, np.float32), device=dev)
+    settings = GaussianRasterizationSettings(
+        image_height=int(s["image_height"]), image_width=int(s["image_width"]), tanfovx=float(s["tanfovx"]),
+        tanfovy=float(s["tanfovy"]), bg=t(s["bg"]), scale_modifier=float(s["scale_modifier"]), viewmatrix=t(s["viewmatrix"]),
+        projmatrix=t(s["projmatrix"]), sh_degree=int(s["sh_degree"]), campos=t(s["campos"]), prefiltered=False, score_flag=False)
+    p = {k: t(v).requires_grad_(True) for k, v in a.items()}
+    m2d = torch.zeros_like(p["means3D"], requires_grad=True)
+    img, radii, da = GaussianRasterizer(raster_settings=settings)(
+        means3D=p["means3D"], means2D=m2d, shs=p["shs"], colors_precomp=None, opacities=p["opacities"], scales=p["scales"],
+        rotations=p["rotations"], cov3D_precomp=None)
+    assert np.array_equal(radii.cpu().numpy(), c["out"]["radii"]), "radii"
+    _close(img.detach().cpu().numpy(), c["out"]["image"], "image")
+    _close(da.detach().cpu().numpy(), c["out"]["depth_alpha"], "depth_alpha")
+    torch.autograd.backward([img, da], [t(c["upstream"]["dL_dimage"]), t(c["upstream"]["dL_ddepth_alpha"])])
+    got = dict(dL_dmeans3D=p["means3D"].grad, dL_dmeans2D=m2d.grad, dL_dopacity=p["opacities"].grad, dL_dshs=p["shs"].grad,
+               dL_dscales=p["scales"].grad, dL_drotations=p["rotations"].grad)
+    for k, ref in c["grads"].items():
+        _close(got[k].cpu().numpy().reshape(ref.shape), ref, k)
