@@ -390,13 +390,11 @@ k_row_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ colst
       const uint32_t e = cb.base + (uint32_t)(wave * (64 * kPass2Items) + it * 64 + lane);
       kv[it] = e < cb.end ? keys[e] : 0xFFFFFFFFu;
     }
+    // (one LDS atomic per element: the rows of 64 consecutive pairs of a column are a few short runs of consecutive ty
+    //  of unrelated Gaussians -- little to aggregate, and the ballot rounds of a wave-aggregated count cost more)
 #pragma unroll
-    for (int it = 0; it < kPass2Items; ++it) {
-      const bool valid = kv[it] != 0xFFFFFFFFu;
-      const uint32_t d = valid ? kv[it] >> 24 : 0u;
-      const unsigned long long m = match_digit_n(d, valid, nbits);
-      if (valid && lane == __ffsll((long long)m) - 1) atomicAdd(&h[d], (uint32_t)__popcll(m));
-    }
+    for (int it = 0; it < kPass2Items; ++it)
+      if (kv[it] != 0xFFFFFFFFu) atomicAdd(&h[kv[it] >> 24], 1u);
   }
   __syncthreads();
   hist[(uint64_t)tid * nblk + blk] = h[tid];

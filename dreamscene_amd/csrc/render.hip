@@ -636,6 +636,9 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 //    8x8 blocks; NOT v_pk_* arithmetic: v_pk_fma_f32 issues at half the rate of v_fma_f32 on gfx950, tools/probe): 279 us
 //    against 238 -- what the shared reduction saves (37 of ~95 instructions per block) the three-way control flow and
 //    its register copies give back, and half as many waves hide less latency;
+//  * the four waves of a workgroup adding their sums of a splat into an LDS row (ds_add_f32, ten lanes) and the workgroup
+//    committing every staged entry once at the end (2.5x fewer global lane-atomics, 16x fewer atomic instructions):
+//    444 us against 238 -- float atomics on LDS are an order of magnitude slower than the global ones they replace;
 //  * the launch zero-filling the 142 MB of gradient buffers K8's sparse form otherwise clears itself ("K7 is VALU-bound,
 //    the stores are free"): K8 100 -> 86 us, K7 236 -> 274 us. The stores are not free: K7's atomics share the path.
 __device__ __forceinline__ void

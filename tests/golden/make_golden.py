@@ -342,9 +342,14 @@ def main():
             prm.grad = None
         try:
             out = fn()
-            gi_ = torch.tensor(np.random.default_rng(seed).normal(size=(3, 64, 64)).astype(np.float32))
-            gd_ = torch.tensor(np.random.default_rng(seed + 1).normal(size=(1, 64, 64)).astype(np.float32))
-            ga_ = torch.tensor(np.random.default_rng(seed + 2).normal(size=(1, 64, 64)).astype(np.float32))
+            # smooth weights (what a loss against a target image produces), not white noise: with noise the per-pixel terms
+            # of a splat cancel to a few percent of their magnitude and ANY fp32 summation order -- the lineage's
+            # per-thread atomics first of all -- is only good to ~1e-4 of the exact sum; that would test noise, not parity
+            yy, xx = np.mgrid[0:64, 0:64].astype(np.float32)
+            ph = 0.37 * seed
+            gi_ = torch.tensor(np.stack([np.sin(0.11 * xx + 0.07 * yy + ph + c) for c in range(3)]).astype(np.float32))
+            gd_ = torch.tensor(np.cos(0.09 * xx - 0.05 * yy + ph)[None].astype(np.float32))
+            ga_ = torch.tensor(np.sin(0.06 * xx + 0.13 * yy - ph)[None].astype(np.float32))
             loss = (out["image"] * gi_).sum() + (out["depth"] * gd_).sum() + (out["alpha"] * ga_).sum() + \
                 0.01 * torch.mean(out["scales"], dim=-1).mean()
             loss.backward()
