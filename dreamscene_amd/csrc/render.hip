@@ -639,6 +639,8 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 //  * the four waves of a workgroup adding their sums of a splat into an LDS row (ds_add_f32, ten lanes) and the workgroup
 //    committing every staged entry once at the end (2.5x fewer global lane-atomics, 16x fewer atomic instructions):
 //    444 us against 238 -- float atomics on LDS are an order of magnitude slower than the global ones they replace;
+//  * (and the control: the same kernel with the global atomic compiled out runs 236 us against 238 -- the atomics are
+//    free, the loop is bound by instruction issue);
 //  * the launch zero-filling the 142 MB of gradient buffers K8's sparse form otherwise clears itself ("K7 is VALU-bound,
 //    the stores are free"): K8 100 -> 86 us, K7 236 -> 274 us. The stores are not free: K7's atomics share the path.
 __device__ __forceinline__ void
@@ -739,8 +741,14 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       float qv = 0.f, wv = 0.f, gdl = 0.f;
       if (hit) {
         const float4 c = s2[j];
-        // v_rcp_f32 (1 ulp): T is only reconstructed for the gradient weights here, no gate depends on it
-        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
+        // v_rcp_f32 + one Newton step. T is only reconstructed for the gradient weights (no gate depends on it), but
+        // it is multiplied up through every layer behind the splat, and the raw v_rcp_f32 (1 ulp) errs the same way
+        // for the same argument: ~1e-5 of coherent drift over 100 layers, which a smooth upstream gradient whose
+        // lobes cancel across a screen-filling splat turns into 2e-4 on dL/dopacity (tests/test_boundary_fixture.py).
+        // The refined reciprocal is within half an ulp or so and unbiased, like the oracle's division: 2 FMAs.
+        const float om = 1.0f - alpha;
+        const float r0_ = __builtin_amdgcn_rcpf(om);
+        const float inv = __fmaf_rn(r0_, __fmaf_rn(-om, r0_, 1.0f), r0_);
         T = T * inv;
         const float w = alpha * T;
         // R = <(colour, depth, alpha) composited behind this splat, normalised to start here; upstream gradient>: the
