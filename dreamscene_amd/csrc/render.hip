@@ -741,14 +741,10 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       float qv = 0.f, wv = 0.f, gdl = 0.f;
       if (hit) {
         const float4 c = s2[j];
-        // v_rcp_f32 + one Newton step. T is only reconstructed for the gradient weights (no gate depends on it), but
-        // it is multiplied up through every layer behind the splat, and the raw v_rcp_f32 (1 ulp) errs the same way
-        // for the same argument: ~1e-5 of coherent drift over 100 layers, which a smooth upstream gradient whose
-        // lobes cancel across a screen-filling splat turns into 2e-4 on dL/dopacity (tests/test_boundary_fixture.py).
-        // The refined reciprocal is within half an ulp or so and unbiased, like the oracle's division: 2 FMAs.
-        const float om = 1.0f - alpha;
-        const float r0_ = __builtin_amdgcn_rcpf(om);
-        const float inv = __fmaf_rn(r0_, __fmaf_rn(-om, r0_, 1.0f), r0_);
+        // v_rcp_f32 (1 ulp): T is only reconstructed for the gradient weights here, no gate depends on it. (A Newton step
+        // on the reciprocal was tried against the reference-derived boundary records, where dL/dopacity sits at 2e-5 ..
+        // 9e-5: no change -- that error is the fp32 noise of the 7e4 upstream spike, tests/test_boundary_fixture.py.)
+        const float inv = __builtin_amdgcn_rcpf(1.0f - alpha);
         T = T * inv;
         const float w = alpha * T;
         // R = <(colour, depth, alpha) composited behind this splat, normalised to start here; upstream gradient>: the

@@ -449,12 +449,25 @@ static void bwd_pixel(const OrcView* v, int px, int py, const uint32_t* ranges, 
   const uint32_t a0 = ranges[2 * tile];
   const size_t pix = (size_t)py * W + px;
   const float pxf = (float)px, pyf = (float)py;
+  /* The GATES are the forward's: power, G = exp, alpha in fp32 with the fixed operator order (orc_power / orc_exp), so the
+   * backward walks exactly the contributors the forward composited. Everything downstream of the gates -- the transmittance
+   * multiplied back up, the colour / depth / alpha composited behind, dL/dalpha, the per-pixel terms of the sums -- is
+   * evaluated in rt_t: double in the scalar build (the checker holds an implementation to the exact gradient of the
+   * function the fp32 forward computed: the recurrences run over 100+ layers and (value - behind) cancels, so an fp32
+   * evaluation of THIS restatement is itself 1e-5 .. 2e-4 off on pixels with a large upstream gradient -- e.g. the pixel
+   * the reference's disp normalisation pins its (max - min) on --, measured against float64: tests/test_boundary_fixture.py),
+   * float in the OpenMP timing build. */
+#ifdef ORC_OMP
+  typedef float rt_t;
+#else
+  typedef double rt_t;
+#endif
   const float Tf = final_T[pix];
-  float T = Tf;
+  rt_t T = Tf;
   const float gC[3] = {dL_dimage[pix], dL_dimage[(size_t)H * W + pix], dL_dimage[(size_t)2 * H * W + pix]};
   const float gD = dL_ddepth_alpha[pix], gA = dL_ddepth_alpha[(size_t)H * W + pix];
-  const float bg_dot = (v->bg[0] * gC[0] + v->bg[1] * gC[1]) + v->bg[2] * gC[2];
-  float last_alpha = 0, last_c[3] = {0, 0, 0}, rec_c[3] = {0, 0, 0}, last_z = 0, rec_z = 0, rec_a = 0;
+  const rt_t bg_dot = ((rt_t)v->bg[0] * gC[0] + (rt_t)v->bg[1] * gC[1]) + (rt_t)v->bg[2] * gC[2];
+  rt_t last_alpha = 0, last_c[3] = {0, 0, 0}, rec_c[3] = {0, 0, 0}, last_z = 0, rec_z = 0, rec_a = 0;
   for (uint32_t k = n_contrib[pix]; k-- > 0;) {
     const uint32_t g = point_list[a0 + k];
     const size_t r = local ? (size_t)k : (size_t)g;
@@ -465,34 +478,33 @@ static void bwd_pixel(const OrcView* v, int px, int py, const uint32_t* ranges, 
     const float G = orc_exp(power);
     const float alpha = fminf(ALPHA_MAX, co[3] * G);
     if (alpha < ALPHA_MIN) continue;
-    T = T / (1.0f - alpha);
-    const float w = alpha * T;
-    float dL_dalpha = 0.0f;
+    T = T / ((rt_t)1 - alpha);
+    const rt_t w = alpha * T;
+    rt_t dL_dalpha = 0;
     for (int c = 0; c < 3; ++c) {
-      rec_c[c] = last_alpha * last_c[c] + (1.0f - last_alpha) * rec_c[c];
+      rec_c[c] = last_alpha * last_c[c] + ((rt_t)1 - last_alpha) * rec_c[c];
       last_c[c] = rgb[3 * g + c];
       dL_dalpha += (rgb[3 * g + c] - rec_c[c]) * gC[c];
       dL_drgb[3 * r + c] += w * gC[c];
     }
-    rec_z = last_alpha * last_z + (1.0f - last_alpha) * rec_z;
+    rec_z = last_alpha * last_z + ((rt_t)1 - last_alpha) * rec_z;
     last_z = depth[g];
     dL_dalpha += (depth[g] - rec_z) * gD;
     dL_ddepth[r] += w * gD;
-    rec_a = last_alpha + (1.0f - last_alpha) * rec_a;
-    dL_dalpha += (1.0f - rec_a) * gA;
+    rec_a = last_alpha + ((rt_t)1 - last_alpha) * rec_a;
+    dL_dalpha += ((rt_t)1 - rec_a) * gA;
     dL_dalpha *= T;
     last_alpha = alpha;
-    dL_dalpha += (-Tf / (1.0f - alpha)) * bg_dot;
+    dL_dalpha += (-(rt_t)Tf / ((rt_t)1 - alpha)) * bg_dot;
     /* With (u, v) = -Sigma^-1 d = -(A dx + B dy, C dy + B dx) and q = dL/dG G:  dG/dd = G (u, v), so q (u, v) is this
      * pixel's share of dL/d(pixel centre); and dL/dSigma = 1/2 sum q (Sigma^-1 d)(Sigma^-1 d)^T, so q (u^2, u v, v^2) is its
      * share of the gradient of the 2-D covariance ITSELF. Both are formed here, per pixel; the `dL_dconic` rows hold
      * (sum q u^2, sum q u v, sum q v^2) and orc_preprocess_bwd only scales them (SEMANTICS.md section 5). The lineage
      * sums dL/dconic = -1/2 q (dx^2, 2 dx dy, dy^2) and converts afterwards, which is the same in exact arithmetic and
-     * loses cond(Sigma)^2 digits in fp32 (needle-shaped splats: 1e-1 against float64 autograd).
-     * Expression tree of u, v: identical to render.hip (fma of the exact -A / -C with the rounded -B product). */
-    const float q = (co[3] * dL_dalpha) * G;
-    const float u = fmaf(-co[0], dx, (-co[1]) * dy), w2 = fmaf(-co[2], dy, (-co[1]) * dx);
-    const float m1 = q * u, m2 = q * w2;
+     * loses cond(Sigma)^2 digits in fp32 (needle-shaped splats: 1e-1 against float64 autograd). */
+    const rt_t q = ((rt_t)co[3] * dL_dalpha) * G;
+    const rt_t u = -((rt_t)co[0] * dx + (rt_t)co[1] * dy), w2 = -((rt_t)co[2] * dy + (rt_t)co[1] * dx);
+    const rt_t m1 = q * u, m2 = q * w2;
     dL_dxy_ndc[2 * r] += m1 * sx;
     dL_dxy_ndc[2 * r + 1] += m2 * sy;
     dL_dconic[3 * r] += m1 * u;
