@@ -14,7 +14,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE_OF = {"k_preprocess_bwd": "preprocess_bwd", "k_preprocess": "preprocess", "k_render_fwd": "render_fwd",
-            "k_render_bwd": "render_bwd", "k_radix": "sort", "k_row_hist": "sort", "k_row_scatter": "sort",
+            "k_render_bwd": "render_bwd", "k_radix": "sort", "k_os_": "sort", "k_gsr_zero_words": "sort",
+            "k_row_hist": "sort", "k_row_scatter": "sort",
             "k_depth": "sort", "k_emit_pairs": "duplicate",
             "k_emit_cols": "duplicate", "k_tile_ranges": "ranges", "k_sorted_block_sums": "scan", "k_scan_blocks": "scan",
             "k_col_hist": "scan", "k_col_plan": "scan", "k_work_order_fwd": "render_fwd", "k_work_order_bwd": "render_bwd"}
