@@ -140,3 +140,65 @@ def test_captured_step_overflow_falls_back_and_recaptures(built_lib):
             rast_cap_before = rast._cap.cap
     assert rast.stats["overflows"] == 1 and rast.stats["captures"] == 2, rast.stats
     assert rast._cap.cap > rast_cap_before
+
+
+def test_fresh_input_tensors_are_staged_not_recaptured(built_lib):
+    """The reference's trainers hand over ACTIVATIONS (a new tensor per step: gs_renderer.py:464-488), so a capture keyed
+    on input addresses never hits. After PTR_MISSES_TO_STAGE captures lost to new addresses alone the inputs are copied
+    into static buffers of the capture and the key is shapes only: no further captures, same results as the eager path."""
+    from dreamscene_amd import synth
+    from dreamscene_amd.graph import CapturedViews, PTR_MISSES_TO_STAGE, WARM_CALLS
+    V, P, H, W, K, D = 2, 2500, 96, 128, 16, 3
+    g, raw = _setup(P, H, W, K, seed=29)
+    cams = synth.object_cameras(8, H, W, radius=3.0)
+    gis = [torch.tensor(synth.upstream_grads(H, W, seed=k)[0], device=DEV) for k in range(V)]
+    gdas = [torch.tensor(synth.upstream_grads(H, W, seed=k)[1], device=DEV) for k in range(V)]
+    rast = CapturedViews()
+    keep = []                   # hold every step's inputs alive: the allocator must not hand the same block back
+    steps = WARM_CALLS + PTR_MISSES_TO_STAGE + 4
+    for step in range(steps):
+        # fresh tensors with values that move from step to step (what an optimizer + activations produce)
+        t = {k: (v.detach() * (1.0 + 0.01 * step) if k in ("scales", "opacities") else v.detach() + 0.0).requires_grad_(True)
+             for k, v in raw.items()}
+        keep.append(t)
+        sets = [settings_for(cams[(step + 3 * k) % 8], [1, 1, 1], D, DEV) for k in range(V)]
+        ref_outs, ref_grads = _eager(sets, t, gis, gdas)
+        leaves = [t[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+        m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+        outs = rast(sets, means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                    rotations=t["rotations"])
+        grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [m2d],
+                                    [y for k in range(V) for y in (gis[k], gdas[k])])
+        for (img, radii, da), (rimg, rradii, rda) in zip(outs, ref_outs):
+            assert torch.equal(radii, rradii) and torch.equal(img, rimg) and torch.equal(da, rda), step
+        for a, b in zip(grads, ref_grads):
+            assert tol_ok(a.reshape(b.shape).cpu().numpy(), b.cpu().numpy(), atol=2e-6), step
+    assert rast.stats["staged_inputs"] is True
+    assert rast.stats["captures"] == PTR_MISSES_TO_STAGE + 1, rast.stats      # by address, ..., then once on shapes
+    assert rast.stats["replays"] == steps - WARM_CALLS, rast.stats
+
+
+def test_backward_of_an_overwritten_replay_is_refused(built_lib):
+    """The static state of a capture belongs to its LATEST replay: backward of an earlier forward must raise, not
+    silently differentiate the later step (the eager path keeps per-call state and supports this pattern)."""
+    from dreamscene_amd import synth
+    from dreamscene_amd.graph import CapturedViews, WARM_CALLS
+    V, P, H, W, K, D = 2, 2000, 96, 128, 4, 1
+    g, t = _setup(P, H, W, K, seed=31)
+    cams = synth.object_cameras(4, H, W, radius=3.0)
+    rast = CapturedViews()
+
+    def fwd(step):
+        sets = [settings_for(cams[(step + k) % 4], [0, 0, 0], D, DEV) for k in range(V)]
+        m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+        return rast(sets, means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                    rotations=t["rotations"])
+    for step in range(WARM_CALLS + 1):          # warm-up calls + the capturing one, each with its own backward
+        sum(img.sum() for img, _, _ in fwd(step)).backward()
+    first = fwd(10)
+    loss_first = sum(img.sum() for img, _, _ in first)
+    second = fwd(11)                            # overwrites the static state `first` refers to
+    with pytest.raises(RuntimeError, match="overwritten by a later forward"):
+        loss_first.backward()
+    sum(img.sum() for img, _, _ in second).backward()       # the latest forward still differentiates
+    assert rast.stats["captures"] == 1
