@@ -76,7 +76,8 @@ class GsrGrads(C.Structure):
                 ("dL_dscales", _f), ("dL_drotations", _f), ("dL_dcov3D", _f), ("dL_dview", _f), ("dL_dproj", _f),
                 ("dL_dcampos", _f), ("partials", _f), ("accumulate", C.c_int32), ("reserved_", C.c_int32),
                 ("stat_max_radii2D", _f), ("stat_xyz_gradient_accum", _f), ("stat_denom", _f),
-                ("scene", C.POINTER(GsrSceneGrads)), ("reached_mask", C.c_void_p)]
+                ("scene", C.POINTER(GsrSceneGrads)), ("reached_mask", C.c_void_p),
+                ("reach", C.c_void_p), ("scratch_clean", C.c_int32), ("reserved2_", C.c_int32)]
 
 
 class GsrAdamGroup(C.Structure):

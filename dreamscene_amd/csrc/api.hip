@@ -26,6 +26,7 @@ int gsr_launch_render_bwd_views(int n, const GsrView* views, const GsrGeom* geom
                                 const GsrImages* imgs, const GsrImageGrads* igs, GsrGrads* outs, hipStream_t, GsrProfile*);
 int gsr_launch_work_order_fwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
 int gsr_launch_work_order_bwd(int n, const GsrView* views, const GsrBinning* bs, const GsrImages* imgs, hipStream_t);
+bool gsr_k8_form_restores(bool views_entry, const GsrView& v, const GsrGaussians& g, const GsrGrads& out);
 int gsr_launch_render_bwd(const GsrView&, const GsrGeom&, const GsrBinning&, const GsrImages&, const GsrImageGrads&,
                           GsrGrads&, hipStream_t, GsrProfile*);
 
@@ -372,6 +373,8 @@ static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom
   if (!ig->dL_dcolor || !ig->dL_ddepth_alpha || !img->final_T || !img->n_contrib || !b->ranges) return GSR_EINVAL;
   if (!b->tile_work || !img->tile_depth || !img->ckpt || !img->color || !img->depth_alpha) return GSR_EINVAL;
   if (!out->partials || !aligned16(out->partials)) return GSR_EINVAL;
+  if (out->scratch_clean && !out->reach) return GSR_EINVAL;
+  if (out->reach && (reinterpret_cast<uintptr_t>(out->reach) & 3u)) return GSR_EINVAL;
   {
     const int n_stat = (out->stat_max_radii2D != nullptr) + (out->stat_xyz_gradient_accum != nullptr) +
                        (out->stat_denom != nullptr);
@@ -393,10 +396,20 @@ static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom
   return GSR_OK;
 }
 
+// The scratch of one view (GsrGrads.partials + .reach) -> zeros
+static int clear_scratch(const GsrView* v, const GsrGrads* out, hipStream_t stream, bool partials = true) {
+  if (partials) GSR_HIP(gsr_zero_async(out->partials, (size_t)v->P * 12 * sizeof(float), stream));
+  if (out->reach) GSR_HIP(gsr_zero_async(out->reach, ((size_t)v->P + 3) / 4 * 4, stream));
+  return GSR_OK;
+}
+
 static int backward_render(const GsrView* v, const GsrGeom* geom, const GsrBinning* b, const GsrImages* img,
                            const GsrImageGrads* ig, GsrGrads* out, hipStream_t stream, GsrProfile* prof,
                            bool clear_partials = true) {
-  if (clear_partials) GSR_HIP(gsr_zero_async(out->partials, (size_t)v->P * 12 * sizeof(float), stream));
+  if (!out->scratch_clean) {
+    const int rc = clear_scratch(v, out, stream, clear_partials);
+    if (rc) return rc;
+  }
   return gsr_launch_render_bwd(*v, *geom, *b, *img, *ig, *out, stream, prof);
 }
 
@@ -416,6 +429,7 @@ int gsr_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom* geom, c
     rc = gsr_launch_preprocess_bwd(*v, *g, *geom, *out, stream);
     if (rc) return rc;
   }
+  if (out->scratch_clean && !gsr_k8_form_restores(false, *v, *g, *out)) return clear_scratch(v, out, stream);
   return GSR_OK;
 }
 
@@ -450,6 +464,11 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   bool contiguous = true;
   for (int k = 1; k < n_views; ++k)
     contiguous = contiguous && ((char*)outs[k].partials == (char*)outs[0].partials + (size_t)k * pbytes);
+  // GsrGrads.scratch_clean: the caller hands over zeroed scratch and gets it back zeroed -- nothing to clear (all views or none)
+  const bool clean = outs[0].scratch_clean != 0;
+  for (int k = 1; k < n_views; ++k)
+    if ((outs[k].scratch_clean != 0) != clean || (outs[k].reach != nullptr) != (outs[0].reach != nullptr)) return GSR_EINVAL;
+  if (clean) contiguous = false;
   if (contiguous) GSR_HIP(gsr_zero_async(outs[0].partials, pbytes * (size_t)n_views, stream));
   {
     const int rc = gsr_launch_work_order_bwd(n_views, views, bs, imgs, stream);   // all views' work lists in one launch
@@ -457,8 +476,11 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   }
   if (fused) {
     // K7 of all views in one launch
-    if (!contiguous)
-      for (int k = 0; k < n_views; ++k) GSR_HIP(gsr_zero_async(outs[k].partials, pbytes, stream));
+    if (!clean)
+      for (int k = 0; k < n_views; ++k) {
+        const int rc = clear_scratch(&views[k], &outs[k], stream, !contiguous);
+        if (rc) return rc;
+      }
     const int rc = gsr_launch_render_bwd_views(n_views, views, geoms, bs, imgs, igs, outs, stream, prof);
     if (rc) return rc;
   } else {
@@ -476,12 +498,23 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
       GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
       const int rc2 = gsr_launch_preprocess_bwd(views[k], gs[k], geoms[k], o, stream);
       if (rc2) return rc2;
+      if (clean && !gsr_k8_form_restores(false, views[k], gs[k], o)) {
+        const int rc3 = clear_scratch(&views[k], &outs[k], stream);
+        if (rc3) return rc3;
+      }
     }
   }
   if (fused) {
-    GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
-    const int rc = gsr_launch_preprocess_bwd_views(n_views, views, gs, geoms, outs, stream);
-    if (rc) return rc;
+    {
+      GsrStageTimer t(prof, stream, GSR_STAGE_PREPROCESS_BWD);
+      const int rc = gsr_launch_preprocess_bwd_views(n_views, views, gs, geoms, outs, stream);
+      if (rc) return rc;
+    }
+    if (clean && !gsr_k8_form_restores(true, views[0], *g, outs[0]))
+      for (int k = 0; k < n_views; ++k) {
+        const int rc = clear_scratch(&views[k], &outs[k], stream);
+        if (rc) return rc;
+      }
   }
   return GSR_OK;
 }

@@ -1282,7 +1282,10 @@ struct K8Views {
   int32_t sh_degree[GSR_MAX_BATCH_VIEWS];   // the active degree may differ per view (scene_render's sh_deg_aug)
   const float* dyn[GSR_MAX_BATCH_VIEWS];    // GsrView.dynamic of every view (NULL: the by-value entries above)
   const int32_t* radii[GSR_MAX_BATCH_VIEWS];
-  const float* partials[GSR_MAX_BATCH_VIEWS];
+  float* partials[GSR_MAX_BATCH_VIEWS];
+  // GsrGrads.reach of every view (all set or all NULL) and its contract: restore = zero the consumed sums and marks again
+  uint8_t* reach[GSR_MAX_BATCH_VIEWS];
+  int32_t restore;
   float* dL_dmeans2D[GSR_MAX_BATCH_VIEWS];
   // per-view scales (the trainers add fresh noise to the activated scales of every view, scene_gaussian.py:1004-1008):
   // then every view has its own scales tensor and its own scale gradient; the other parameters are shared
@@ -1377,7 +1380,10 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     bool reached = false;
     for (int vv = 0; vv < vb.nv; ++vv) {
       const int32_t r = ok ? vb.radii[vv][i] : 0;
-      if (r > 0) {
+      if (vb.reach[0]) {
+        // K7 marked the Gaussians it committed sums for: 1 byte instead of the 40-byte sums of every visible Gaussian
+        reached = reached || (r > 0 && vb.reach[vv][i] != 0);
+      } else if (r > 0) {
         const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
         const float4 pa = pp[0], pb = pp[1];
         const float2 pc = *reinterpret_cast<const float2*>(vb.partials[vv] + 12 * i + 8);
@@ -1481,8 +1487,15 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       const int D = vd.sh_degree;
       const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
       const float limx = 1.3f * tfx, limy = 1.3f * tfy;
-      const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
-      const float4 pa = pp[0], pb = pp[1], pc = pp[2];
+      float4* pp = reinterpret_cast<float4*>(vb.partials[vv] + 12 * i);
+      float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
+      if (!vb.reach[0] || vb.reach[vv][i] != 0) {       // (an unmarked Gaussian's sums are zero: not read)
+        pa = pp[0]; pb = pp[1]; pc = pp[2];
+        if (vb.restore) {                               // GsrGrads.scratch_clean: leave the scratch as it was found
+          pp[0] = make_float4(0.f, 0.f, 0.f, 0.f); pp[1] = pp[0]; pp[2] = pp[0];
+          vb.reach[vv][i] = (uint8_t)0;
+        }
+      }
       gop += pb.y;
       const float grgb[3] = {pb.z, pb.w, pc.x};
       // (1) colour -> SH coefficients, view direction
@@ -1901,6 +1914,15 @@ static void reached_mask_all(const GsrGrads& out, int32_t P, hipStream_t stream)
                      reinterpret_cast<unsigned long long*>(out.reached_mask), (int64_t)P);
 }
 
+// Does the form of K8 the launchers below pick honour GsrGrads.scratch_clean (zero the sums and marks it consumed)? The
+// views template does; the scene forms and the single-view kernel for colours / precomputed covariances / camera
+// gradients do not -- gsr_backward* then clears the scratch after them.
+bool gsr_k8_form_restores(bool views_entry, const GsrView& v, const GsrGaussians& g, const GsrGrads& out) {
+  if (!out.reach || !out.scratch_clean || g.scene) return false;
+  if (views_entry) return true;
+  return gsr_k8_sparse() && v.sh_stride >= 9 && !out.dL_dcolors && !out.dL_dcov3D && gsr_preprocess_bwd_views_supported(v, g, out);
+}
+
 int gsr_launch_preprocess_bwd(const GsrView& v, const GsrGaussians& g, const GsrGeom& geom, const GsrGrads& out,
                               hipStream_t stream) {
   // the trainers' case (SH rows, scales + rotations, no camera gradients): the sparse kernel with one view
@@ -1969,7 +1991,10 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
     vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy; vb.sh_degree[k] = views[k].sh_degree;
     vb.dyn[k] = views[k].dynamic;
     vb.radii[k] = geoms[k].radii; vb.partials[k] = outs[k].partials; vb.dL_dmeans2D[k] = outs[k].dL_dmeans2D;
+    vb.reach[k] = g.scene ? nullptr : outs[k].reach;
+    if ((outs[k].reach != nullptr) != (outs[0].reach != nullptr)) return GSR_EINVAL;
   }
+  vb.restore = (!g.scene && outs[0].reach && outs[0].scratch_clean) ? 1 : 0;
   // densification statistics: the views whose GsrGrads entry names the statistics tensors (all the same ones)
   GsrGrads out0 = outs[0];
   out0.stat_max_radii2D = nullptr; out0.stat_xyz_gradient_accum = nullptr; out0.stat_denom = nullptr;

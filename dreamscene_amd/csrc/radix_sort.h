@@ -233,7 +233,13 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
 //               tile by digit in LDS and writes runs of consecutive positions (coalesced; the old scatter stored
 //               element by element).
 // Look-back words: one u32 per (tile, digit) = tag << 28 | value, tag = 2 pass + 1 (this tile's count: "aggregate") or
-// 2 pass + 2 (count of this and all earlier tiles: "inclusive"), 0 = nothing yet. The table is zeroed ONCE per sort (tags
+// 2 pass + 2 (count of this and all earlier tiles: "inclusive"), 0 = nothing yet.
+// TWO LEVELS. A P-sized sort is a few hundred tiles that are all resident and start together, so nobody finds an inclusive
+// word early and a plain look-back walks ALL its predecessors: tiles^2 / 2 words per digit and pass (245 tiles per view:
+// 240 MB of L2 reads per pass against 16 MB of keys; measured 10 of the 28 us of a pass, and a wider window made it
+// slower). So the last tile of every group of kOsGroup consecutive tiles also publishes the GROUP's count (its own + the
+// group's earlier tiles') and, after a look-back over the group rows, the group's inclusive prefix; a tile then adds the
+// counts of the earlier tiles of its own group (< kOsGroup words) and looks back over GROUP rows only. The table is zeroed ONCE per sort (tags
 // tell the passes apart). Written and polled with relaxed agent-scope atomics ONLY -- a single aligned word is its own
 // flag, so no fence is needed (an agent-scope release fence writes the XCD's L2 back: measured 3.5x on K8 in round 2).
 // Values need 28 bits: sorts of 2^28 elements or more take the three-kernel passes.
@@ -251,7 +257,13 @@ __host__ __device__ inline uint32_t os_tiles(uint64_t n, int items) {
   return (uint32_t)((n + t - 1) / t);
 }
 // u32 words of the one-sweep state of a sort of up to n keys
-__host__ inline size_t os_state_words(uint64_t n, int items) { return (size_t)kOsTableOff + (size_t)kRadix * os_tiles(n, items); }
+// (tile words, then one row per GROUP of kOsGroup consecutive tiles)
+constexpr int kOsGroup = 16;
+__host__ __device__ inline uint32_t os_groups(uint32_t tiles) { return (tiles + kOsGroup - 1) / kOsGroup; }
+__host__ inline size_t os_state_words(uint64_t n, int items) {
+  const uint32_t t = os_tiles(n, items);
+  return (size_t)kOsTableOff + (size_t)kRadix * (t + os_groups(t));
+}
 
 template <bool DROP>
 __global__ void __launch_bounds__(kSortThreads)
@@ -338,6 +350,15 @@ __device__ __forceinline__ uint32_t os_look_back(gsr_gu32* table, uint32_t tile,
   }
 }
 
+// Phase stamps for tools/probe/sort_phases.hip (compiled out of the library)
+#ifdef GSR_OS_TRACE
+__device__ unsigned long long* g_os_trace = nullptr;      // [pass][tile][8] realtime stamps (100 MHz)
+#define GSR_OS_STAMP(k) do { if (threadIdx.x == 0 && g_os_trace) \
+    g_os_trace[(((size_t)pass * 4 + blockIdx.y) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define GSR_OS_STAMP(k) do { } while (0)
+#endif
+
 template <bool IOTA, int ITEMS, bool DROP>
 __global__ void __launch_bounds__(kSortThreads)
 k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
@@ -372,6 +393,7 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
       return;
     }
   }
+  GSR_OS_STAMP(0);
   if (tid == 0) s_tile = atomicAdd(&os[kOsMaxPasses * kRadix + pass], 1u);      // the ticket: tiles START in this order
 #pragma unroll
   for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
@@ -395,6 +417,10 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     dbase = woff + inc - x;
     if (DROP && n_out && tile == 0 && tid == kSortThreads - 1) *n_out = (uint64_t)(woff + inc);   // survivors
   }
+  GSR_OS_STAMP(1);
+#ifdef GSR_OS_TRACE
+  if (threadIdx.x == 0 && g_os_trace) g_os_trace[(((size_t)pass * 4 + blockIdx.y) * 4096 + blockIdx.x) * 8 + 7] = tile;
+#endif
   uint32_t* mywh = wh[wave];
   uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
   const unsigned long long lt = (1ull << lane) - 1ull;
@@ -425,6 +451,7 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     GSR_LDS_ORDER();
   }
   __syncthreads();
+  GSR_OS_STAMP(2);
   // thread d: this tile's count of digit d, the waves' offsets inside the run, the run's start inside the tile
   uint32_t cnt;
   {
@@ -437,17 +464,39 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     }
     cnt = run;
   }
-  // publish the count, then look back (thread d for digit d)
+  // publish the count, then look back (thread d for digit d): earlier tiles of the own group, then the group rows
   gsr_gu32* table = gsr_global(os + kOsTableOff);
+  gsr_gu32* gtable = table + (size_t)gridDim.x * kRadix;
   const uint32_t tagA = (uint32_t)(2 * pass + 1) << 28, tagI = (uint32_t)(2 * pass + 2) << 28;
+  const uint32_t grp = tile / kOsGroup;
+  const int gpos = (int)(tile % kOsGroup);
+  __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagA | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t excl = 0;
-  if (tile == 0) {
-    __hip_atomic_store(table + tid, tagI | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagA | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    excl = os_look_back(table, tile, tid, tagA, tagI);
-    __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagI | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (gpos) {                                  // (workgroup-uniform)
+    for (;;) {
+      uint32_t sum = 0;
+      bool ok = true;
+#pragma unroll
+      for (int j = 1; j < kOsGroup; ++j)
+        if (j <= gpos) {
+          const uint32_t w = __hip_atomic_load(table + (size_t)(tile - j) * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && ((w & 0xF0000000u) == tagA);
+          sum += w & 0x0FFFFFFFu;
+        }
+      if (ok) { excl = sum; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
   }
+  if (gpos == kOsGroup - 1) {
+    // the group's last tile: the group's count, then (after the look-back over the earlier groups) its inclusive prefix
+    if (grp) __hip_atomic_store(gtable + (size_t)grp * kRadix + tid, tagA | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t before = grp ? os_look_back(gtable, grp, tid, tagA, tagI) : 0u;
+    __hip_atomic_store(gtable + (size_t)grp * kRadix + tid, tagI | (before + excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    excl += before;
+  } else if (grp) {
+    excl += os_look_back(gtable, grp, tid, tagA, tagI);
+  }
+  GSR_OS_STAMP(3);
   // start of digit d's run inside the tile: exclusive scan of cnt over the digits
   uint32_t lstart;
   {
@@ -479,6 +528,7 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     }
   }
   __syncthreads();
+  GSR_OS_STAMP(4);
   const uint32_t ntile = s_ntile;
   for (uint32_t i = tid; i < ntile; i += kSortThreads) {
     const uint32_t k = skey[i];
@@ -486,6 +536,7 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     keys_out[pos] = k;
     vals_out[pos] = sval[i];
   }
+  GSR_OS_STAMP(5);
 }
 
 __host__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }

@@ -236,9 +236,9 @@ k_work_order_bwd(const uint32_t n_tiles, const WorkBwdViews wv) {
 // Double-buffered staging of 256 list entries. The reach mask of an entry rides in the unused fourth component of its
 // third splat row (s2[..].w): 24 KB instead of 29 KB per workgroup = one more workgroup per CU; the Gaussian ids are only
 // staged by the score variant.
-template <bool SCORE>
+template <bool SCORE, int PAD = 0>
 struct Stage {
-  float4 s0[2][kBatch], s1[2][kBatch], s2[2][kBatch];
+  float4 s0[2][kBatch + PAD], s1[2][kBatch + PAD], s2[2][kBatch + PAD];
   uint32_t sid[SCORE ? 2 : 1][SCORE ? kBatch : 1];
 };
 __device__ __forceinline__ uint32_t stage_mask(const float4& s2row) { return __float_as_uint(s2row.w); }
@@ -263,8 +263,15 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
              float* __restrict__ out_color, float* __restrict__ out_da, float* __restrict__ final_T,
              uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_depth, float* __restrict__ score,
              const int score_mode) {
-  __shared__ Stage<SCORE> st;
-  __shared__ uint8_t cand[4][kBatch];   // per wave: the batch's candidates for its 4x4 block, in list order
+  // Row kBatch of every staged array is a candidate no pixel takes (opacity 0 -> alpha 0 < 1/255): the per-wave candidate
+  // lists are padded with it to a multiple of four, so the compositing loop has no partial step.
+  __shared__ Stage<SCORE, 1> st;
+  __shared__ uint16_t cand[4][kBatch + 4];   // per wave: the batch's candidates for its 4x4 block, in list order
+  if (threadIdx.x < 2) {
+    st.s0[threadIdx.x][kBatch] = make_float4(0.f, 0.f, 0.f, 0.f);
+    st.s1[threadIdx.x][kBatch] = make_float4(0.f, 0.f, 0.f, 0.f);
+    st.s2[threadIdx.x][kBatch] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int slot = lane & 3, pl = lane >> 2;
@@ -354,22 +361,20 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
         if (m) cand[wave][cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint8_t)(k * 64 + lane);
         cnt += (int)__popcll(bal);
       }
+      if (lane < 3) cand[wave][cnt + lane] = (uint16_t)kBatch;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       {
         for (int i = 0; i < cnt; i += 4) {
           if (donem == ~0ull) break;
-          const int nv = min(4, cnt - i);
-          const int j = (int)cand[wave][min(i + slot, cnt - 1)];
+          const int j = (int)cand[wave][i + slot];
           const float4 a = st.s0[buf][j];
           const float4 b = st.s1[buf][j];
           const float2 c = *reinterpret_cast<const float2*>(&st.s2[buf][j]);
           const float dx = a.x - pxf, dy = a.y - pyf;
           const float power = gsr_power(a.z, a.w, b.x, dx, dy);
           const float alpha = fminf(GSR_ALPHA_MAX, gsr_mul(b.y, gsr_exp(power)));
-          // lanes whose slot holds a candidate: the low nv lanes of every quad
-          const unsigned long long nvm = 0x1111111111111111ull * (unsigned long long)((1u << nv) - 1u);
-          const unsigned long long gm = nvm & ~donem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
+          const unsigned long long gm = ~donem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                         __builtin_amdgcn_ballot_w64(alpha >= GSR_ALPHA_MIN);
           const bool g = __builtin_amdgcn_inverse_ballot_w64(gm);
           // transmittance after this slot, multiplied up in LIST ORDER -- ((T f0) f1) f2 ... with f = 1 - alpha of a
@@ -387,11 +392,11 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
           }
           const float Tprev = gsr_dpp<0x90>(test_T);
           const float T_before = (slot >= 1) ? Tprev : T;
-          // the first slot (in list order) whose own contribution would drop T below the threshold stops the pixel:
-          // inclusive OR over the slots <= mine, formed on the scalar unit from the wave's 64-bit flag mask
-          unsigned long long stopm = gm & __builtin_amdgcn_ballot_w64(test_T < GSR_T_MIN);
-          stopm |= (stopm << 1) & 0xEEEEEEEEEEEEEEEEull;
-          stopm |= (stopm << 2) & 0xCCCCCCCCCCCCCCCCull;
+          // The first slot (in list order) whose own contribution would drop T below the threshold stops the pixel, it
+          // and everything behind it. A pixel still in play holds T >= 1e-4 and the slots' test_T only decrease along the
+          // list (factors <= 1, one rounding each), so "a gated slot <= mine fell below the threshold" IS "my test_T is
+          // below it": no scan over the quad, and the quad's stop flag is slot 3's comparison.
+          const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < GSR_T_MIN);
           const bool hit = __builtin_amdgcn_inverse_ballot_w64(gm & ~stopm);
           const float w = hit ? alpha * T_before : 0.0f;
           C0 = fmaf(b.w, w, C0); C1 = fmaf(c.x, w, C1); C2 = fmaf(c.y, w, C2);
@@ -406,15 +411,15 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
               // independent of the order -- and k_score_finalize multiplies by the opacity once (mode 0) or the caller does
               // (mode 2: raw counts, summed over many views first). A float sum of thousands of EQUAL increments rounds the
               // same way every time (measured 6e-5 relative on the sum over 48 views).
-              if (hm != 0ull && lane == slot && slot < nv)
-                atomicAdd(reinterpret_cast<uint32_t*>(score) + st.sid[buf][j], (uint32_t)__popcll(hm));
+              if (hm != 0ull && lane == slot)
+                atomicAdd(reinterpret_cast<uint32_t*>(score) + st.sid[buf][j & (kBatch - 1)], (uint32_t)__popcll(hm));
             } else {
               float ws = w;                               // sum over the lanes sharing the slot: xor 4,8,16,32
               ws += gsr_dpp<0x124>(ws);                   // row_ror:4
               ws += gsr_dpp<0x128>(ws);                   // row_ror:8
               ws += __shfl_xor(ws, 16, 64);
               ws += __shfl_xor(ws, 32, 64);
-              if (hm != 0ull && lane == slot && slot < nv) unsafeAtomicAdd(score + st.sid[buf][j], ws);
+              if (hm != 0ull && lane == slot) unsafeAtomicAdd(score + st.sid[buf][j & (kBatch - 1)], ws);
             }
           }
           // T after the quad: the survivors' T(1-alpha) only decrease along the list -> quad minimum (T >= 1e-4 > 0:
@@ -423,7 +428,10 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
           tn = min(tn, (uint32_t)gsr_dpp_i<0xB1>((int)tn));   // quad_perm [1,0,3,2]
           tn = min(tn, (uint32_t)gsr_dpp_i<0x4E>((int)tn));   // quad_perm [2,3,0,1]
           T = __uint_as_float(tn);
-          unsigned long long quad_stop = (stopm >> 3) & 0x1111111111111111ull;   // slot 3 holds the OR over the quad
+          // slot 3's flag -> all four lanes of its quad. On the SCALAR unit: its instructions issue beside the vector
+          // instructions of the other waves (removing 22 of them from this loop changed nothing: A/B in one gpurun call,
+          // 44.0 vs 45.0 us per view -- the loop is bound by its ~50 vector instructions), so mask arithmetic belongs there
+          unsigned long long quad_stop = (stopm >> 3) & 0x1111111111111111ull;
           quad_stop |= quad_stop << 1;
           quad_stop |= quad_stop << 2;
           donem |= quad_stop;
@@ -650,9 +658,10 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
              const float4* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ color,
              const float* __restrict__ depth_alpha, const float* __restrict__ final_T,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-             const float* __restrict__ dL_dda, float* __restrict__ partials) {
+             const float* __restrict__ dL_dda, float* __restrict__ partials, uint8_t* __restrict__ reach) {
   __shared__ float4 s0[kBatch], s1[kBatch], s2[kBatch];
   __shared__ uint32_t sid[kBatch], smask[kBatch];
+  __shared__ unsigned long long hitw[kBatch / 64];    // staged entries some wave committed sums for (-> GsrGrads.reach)
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (item >= items[0]) return;
@@ -683,6 +692,7 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
     s2[tid] = n2;
     sid[tid] = nid;
     smask[tid] = (tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u;
+    if (tid < kBatch / 64) hitw[tid] = 0ull;
   }
 
   const float Tf = p.inside ? final_T[pix] : 0.f;
@@ -720,8 +730,10 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   for (int k = 0; k < kBatch / 64; ++k) {
     if (k * 64 >= n) break;
     unsigned long long bits = __ballot((smask[k * 64 + lane] >> wave) & 1u);
+    unsigned long long hitk = 0ull;       // (scalar unit: free next to the vector instructions of the other waves)
     while (bits) {
-      const int j = k * 64 + __builtin_ctzll(bits);
+      const int jb = __builtin_ctzll(bits);
+      const int j = k * 64 + jb;
       bits &= bits - 1ull;
       const uint32_t pos = hi - 1u - (uint32_t)j;      // 0-based list position
       const unsigned long long livem = __builtin_amdgcn_ballot_w64(pos < last);
@@ -736,6 +748,7 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       const unsigned long long hitm = livem & __builtin_amdgcn_ballot_w64(power <= 0.0f) &
                                       __builtin_amdgcn_ballot_w64(alpha >= GSR_ALPHA_MIN);
       if (hitm == 0ull) continue;
+      hitk |= 1ull << jb;
       const bool hit = __builtin_amdgcn_inverse_ballot_w64(hitm);
       // per-lane factors of the 10 sums; lanes without a hit contribute zeros (only these three are cleared)
       float qv = 0.f, wv = 0.f, gdl = 0.f;
@@ -774,6 +787,13 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       const float sred = reduce10(v, lane);
       if (commit) unsafeAtomicAdd(partials + 12 * (size_t)sid[j] + comp, sred);
     }
+    if (reach && hitk && lane == 0) atomicOr(&hitw[k], hitk);
+  }
+  if (reach) {
+    // the Gaussians this item committed sums for: one byte each, written (not added: any number of items may mark the
+    // same Gaussian) by the thread that staged the entry
+    __syncthreads();
+    if (tid < n && ((hitw[tid >> 6] >> (tid & 63)) & 1ull)) reach[sid[tid]] = (uint8_t)1;
   }
  }
 }
@@ -828,6 +848,7 @@ struct BwdViews {
   const float* dL_dcolor[GSR_MAX_BATCH_VIEWS];
   const float* dL_dda[GSR_MAX_BATCH_VIEWS];
   float* partials[GSR_MAX_BATCH_VIEWS];
+  uint8_t* reach[GSR_MAX_BATCH_VIEWS];
 };
 
 template <bool SCORE>
@@ -856,7 +877,7 @@ k_render_bwd(const int W, const int H, const BwdViews bv, const uint32_t n_views
   const int y = (int)(per_view ? blockIdx.x / per_view : blockIdx.x - item * n_views);
   render_bwd_body(item, W, H, bv.items[y], bv.tile_depth[y], bv.ckpt[y], bv.ranges[y], bv.point_list[y], bv.splat[y], bv.bg[y],
                   bv.color[y], bv.depth_alpha[y], bv.final_T[y], bv.n_contrib[y], bv.dL_dcolor[y], bv.dL_dda[y],
-                  bv.partials[y]);
+                  bv.partials[y], bv.reach[y]);
 }
 
 // The stage timers (GSR_STAGE_RENDER_FWD / _BWD) bracket the compositing kernel alone (not the work-list kernel), so
@@ -954,6 +975,7 @@ int gsr_launch_render_bwd_views(int n, const GsrView* views, const GsrGeom* geom
     bv.splat[k] = reinterpret_cast<const float4*>(geoms[k].splat); bv.bg[k] = views[k].bg; bv.color[k] = imgs[k].color;
     bv.depth_alpha[k] = imgs[k].depth_alpha; bv.final_T[k] = imgs[k].final_T; bv.n_contrib[k] = imgs[k].n_contrib;
     bv.dL_dcolor[k] = igs[k].dL_dcolor; bv.dL_dda[k] = igs[k].dL_ddepth_alpha; bv.partials[k] = outs[k].partials;
+    bv.reach[k] = outs[k].reach;
     items_cap = bs[k].bwd_items_cap > items_cap ? bs[k].bwd_items_cap : items_cap;
   }
   GsrStageTimer timer(prof, stream, GSR_STAGE_RENDER_BWD);

@@ -15,8 +15,10 @@ PyTorch is used for device memory, streams and autograd plumbing only; all arith
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import dataclasses
+import threading
 import time
 from typing import NamedTuple, Optional, Sequence
 
@@ -503,6 +505,49 @@ def _model_grad_rows(sc_struct, leaves_of, model_grads, accumulate, K, dev):
     return outs
 
 
+
+class _Scratch:
+    """K7 -> K8 scratch of V views of P Gaussians, kept between calls under GsrGrads.scratch_clean: `partials` [V,P,12] (the
+    per-Gaussian sums K7 adds to) and `reach` [V, (P+3)//4*4] (the Gaussians K7 marked) are ALL ZERO whenever no backward is
+    in flight -- K8 zeroes what it consumed -- so a step launches no clear (96 MB of stores + as many of loads at 500 k
+    Gaussians x 4 views). `dirty` guards the invariant: set while a call is being enqueued, cleared when it returned OK."""
+    __slots__ = ("partials", "reach", "dirty")
+
+    def __init__(self, V, P, dev):
+        self.partials = torch.zeros((V, max(P, 1), 12), dtype=torch.float32, device=dev)
+        self.reach = torch.zeros((V, (max(P, 1) + 3) // 4 * 4), dtype=torch.uint8, device=dev)
+        self.dirty = False
+
+
+_SCRATCH: "collections.OrderedDict" = collections.OrderedDict()
+_SCRATCH_LOCK = threading.Lock()
+_SCRATCH_MAX = 4
+
+
+def _scratch_acquire(dev, V: int, P: int) -> _Scratch:
+    """The scratch of (device, current stream, V, P): calls on one stream are ordered, so they can share it; another
+    stream gets its own. Allocated (zeroed) on first use, re-zeroed if a previous call failed half-way."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream, V, P)
+    with _SCRATCH_LOCK:
+        s = _SCRATCH.get(key)
+        if s is None:
+            s = _SCRATCH[key] = _Scratch(V, P, dev)
+            while len(_SCRATCH) > _SCRATCH_MAX:
+                _SCRATCH.popitem(last=False)
+        else:
+            _SCRATCH.move_to_end(key)
+            if s.dirty:
+                s.partials.zero_()
+                s.reach.zero_()
+        s.dirty = True
+    return s
+
+
+def _bind_scratch(gr, sc: _Scratch, k: int = 0):
+    gr.partials = sc.partials[k].data_ptr()
+    gr.reach = sc.reach[k].data_ptr()
+    gr.scratch_clean = 1
+
 def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, model_grads, accumulate: bool,
                     dL_dscales_out=None, stats=None, profile=None) -> dict:
     """Backward of a scene forward: the parameter gradients are written (or, with accumulate, ADDED) straight into
@@ -521,11 +566,11 @@ def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, mod
              dL_dview=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
              dL_dproj=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
              dL_dcampos=torch.zeros(3, dtype=f32, device=dev) if cam_grads else None)
-    partials = torch.empty((max(P, 1), 12), dtype=f32, device=dev)
+    scratch = _scratch_acquire(dev, 1, P)
     gr = L.GsrGrads()
     gr.dL_dmeans2D = o["dL_dmeans2D"].data_ptr()
     gr.dL_dview, gr.dL_dproj, gr.dL_dcampos = _ptr(o["dL_dview"]), _ptr(o["dL_dproj"]), _ptr(o["dL_dcampos"])
-    gr.partials = partials.data_ptr()
+    _bind_scratch(gr, scratch)
     gr.accumulate = int(bool(accumulate))
     dL_dscales_out = _prep(dL_dscales_out, "dL_dscales_out", dev)
     sg.dL_dscales_out = _ptr(dL_dscales_out)
@@ -538,7 +583,7 @@ def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, mod
     with torch.cuda.device(dev):
         L.check(lib.gsr_backward(C.byref(st.view), C.byref(st.gauss), C.byref(st.geom), C.byref(st.binning),
                                  C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
-    o["partials"] = partials
+    scratch.dirty = False
     return o
 
 
@@ -572,11 +617,11 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
              dL_dview=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
              dL_dproj=torch.zeros(16, dtype=f32, device=dev) if cam_grads else None,
              dL_dcampos=torch.zeros(3, dtype=f32, device=dev) if cam_grads else None)
-    partials = new(max(P, 1), 12)
+    scratch = _scratch_acquire(dev, 1, P)
     gr = L.GsrGrads()
     for k, t in o.items():
         setattr(gr, k, _ptr(t))
-    gr.partials = partials.data_ptr()
+    _bind_scratch(gr, scratch)
     gr.accumulate = int(bool(accumulate and arena is not None))
     if arena is not None and getattr(arena, "reached", None) is not None:
         gr.reached_mask = arena.reached.data_ptr()      # K8 marks the rows an exchange has to move (GradArena.reached_rows)
@@ -589,7 +634,7 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
     with torch.cuda.device(dev):
         L.check(lib.gsr_backward(C.byref(st.view), C.byref(g), C.byref(st.geom), C.byref(st.binning),
                                  C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
-    o["partials"] = partials
+    scratch.dirty = False
     return o
 
 
@@ -609,7 +654,7 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
     sc0, keep0 = st0.scene
     outs = _model_grad_rows(sc0, keep0, model_grads, accumulate, K, dev)
     m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
-    partials = torch.empty((V, max(P, 1), 12), dtype=f32, device=dev)
+    scratch = _scratch_acquire(dev, V, P)
     views = (L.GsrView * V)(*[st.view for st in states])
     gauss = (L.GsrGaussians * V)(*[st.gauss for st in states])
     geoms = (L.GsrGeom * V)(*[st.geom for st in states])
@@ -632,7 +677,7 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
         sgs[k].dL_dscales_out = _ptr(gso)
         grs[k].scene = C.pointer(sgs[k])
         grs[k].dL_dmeans2D = m2d[k].data_ptr()
-        grs[k].partials = partials[k].data_ptr()
+        _bind_scratch(grs[k], scratch, k)
         grs[k].accumulate = int(bool(accumulate))
         if k in counted:
             _bind_stats(grs[k], stats, P, dev)
@@ -640,6 +685,7 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
     prof = profile.handle if profile is not None else None
     with torch.cuda.device(dev):
         L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof), "gsr_backward_views")
+    scratch.dirty = False
     return dict(dL_dmeans2D=m2d[:, :P], model_grads=outs)
 
 
@@ -673,7 +719,7 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         per_view_scales = any(st.gauss.scales != g.scales for st in states)
     if reuse is not None:
         o = {k: reuse[k] for k in names}
-        m2d, partials = reuse["_m2d"], reuse["_partials"]
+        m2d, scratch = reuse["_m2d"], reuse["_scratch"]
     else:
         o = dict(dL_dmeans3D=new(P, 3, name="means3D"), dL_dopacities=new(P, 1, name="opacities"),
                  dL_dshs=new(P, K, 3, name="shs") if g.shs else None, dL_dcolors=new(P, 3) if g.colors_precomp else None,
@@ -683,7 +729,9 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         if per_view_scales:        # every view has its own scales tensor -> its own scale gradient
             o["dL_dscales"] = torch.empty((V, P, 3), dtype=f32, device=dev)
         m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
-        partials = torch.empty((V, max(P, 1), 12), dtype=f32, device=dev)
+        # (a reused dict -- graph capture -- keeps the scratch of the call that made it: static addresses, and the
+        #  captured K7 / K8 pair maintains the all-zero invariant like an eager one)
+        scratch = _scratch_acquire(dev, V, P)
     views = (L.GsrView * V)(*[st.view for st in states])
     gauss = (L.GsrGaussians * V)(*[st.gauss for st in states])
     geoms = (L.GsrGeom * V)(*[st.geom for st in states])
@@ -704,7 +752,7 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         if per_view_scales:
             grs[k].dL_dscales = o["dL_dscales"][k].data_ptr()
         grs[k].dL_dmeans2D = m2d[k].data_ptr()
-        grs[k].partials = partials[k].data_ptr()
+        _bind_scratch(grs[k], scratch, k)
         grs[k].accumulate = int(bool(accumulate and arena is not None))
         if arena is not None and getattr(arena, "reached", None) is not None:
             grs[k].reached_mask = arena.reached.data_ptr()
@@ -716,8 +764,9 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
     with torch.cuda.device(dev):
         L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof),
                 "gsr_backward_views")
+    scratch.dirty = False
     o["dL_dmeans2D"] = m2d[:, :P]
-    o["_m2d"], o["_partials"] = m2d, partials
+    o["_m2d"], o["_scratch"] = m2d, scratch
     return o
 
 
