@@ -233,17 +233,21 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
 //               tile by digit in LDS and writes runs of consecutive positions (coalesced; the old scatter stored
 //               element by element).
 // Look-back words: one u32 per (tile, digit) = tag << 28 | value, tag = 2 pass + 1 (this tile's count: "aggregate") or
-// 2 pass + 2 (count of this and all earlier tiles: "inclusive"), 0 = nothing yet.
-// TWO LEVELS. A P-sized sort is a few hundred tiles that are all resident and start together, so nobody finds an inclusive
-// word early and a plain look-back walks ALL its predecessors: tiles^2 / 2 words per digit and pass (245 tiles per view:
-// 240 MB of L2 reads per pass against 16 MB of keys; measured 10 of the 28 us of a pass, and a wider window made it
-// slower). So the last tile of every group of kOsGroup consecutive tiles also publishes the GROUP's count (its own + the
-// group's earlier tiles') and, after a look-back over the group rows, the group's inclusive prefix; a tile then adds the
-// counts of the earlier tiles of its own group (< kOsGroup words) and looks back over GROUP rows only. The table is zeroed ONCE per sort (tags
+// 2 pass + 2 (count of this and all earlier tiles: "inclusive"), 0 = nothing yet. The table is zeroed ONCE per sort (tags
 // tell the passes apart). Written and polled with relaxed agent-scope atomics ONLY -- a single aligned word is its own
 // flag, so no fence is needed (an agent-scope release fence writes the XCD's L2 back: measured 3.5x on K8 in round 2).
 // Values need 28 bits: sorts of 2^28 elements or more take the three-kernel passes.
-constexpr int kOsItemsSmall = 8;      // keys per thread, P-sized sorts (2048-key tiles)
+// Where a pass spends its time (tools/probe/sort_phases.hip, 4 views x 500 k depth keys, 2048-key tiles: 245 tiles per view,
+// all resident and starting together; us, mean per tile): ticket + digit-base scan 2.7, load + rank 5.0, publish + look-back
+// 10 (tile 1: 0.5, tile 15: 5, the last quarter of the list: 12.6), LDS sort 1.7, write 1.4; launch span 28. The look-back is
+// the wait for the predecessors' words to become VISIBLE across XCDs plus the walk: a window of 32 or 64 instead of 16 is
+// slower (144 / 197 vs 131 us per sort: the walk is bandwidth, ~1 KB per predecessor and tile), and a two-level scheme
+// (group rows of 16 tiles: 31 words per digit instead of up to 245) needs one more publish -> visible hop and takes the same
+// 10 us. What helps is fewer tiles: 4096-key tiles halve the chain (look-back 6 us, pass 21 us, sort 132 -> 112 us).
+#ifndef GSR_OS_ITEMS_SMALL
+#define GSR_OS_ITEMS_SMALL 16
+#endif
+constexpr int kOsItemsSmall = GSR_OS_ITEMS_SMALL;     // keys per thread, P-sized sorts (4096-key tiles: see the phase timings below)
 constexpr int kOsMaxPasses = 4;
 constexpr uint32_t kOsHistTile = 2048;  // keys per workgroup of k_os_hist
 constexpr uint32_t kOsTableOff = kOsMaxPasses * kRadix + 16;   // u32 words: [passes][256] histograms | 4 tickets (+ pad) | table
@@ -257,13 +261,7 @@ __host__ __device__ inline uint32_t os_tiles(uint64_t n, int items) {
   return (uint32_t)((n + t - 1) / t);
 }
 // u32 words of the one-sweep state of a sort of up to n keys
-// (tile words, then one row per GROUP of kOsGroup consecutive tiles)
-constexpr int kOsGroup = 16;
-__host__ __device__ inline uint32_t os_groups(uint32_t tiles) { return (tiles + kOsGroup - 1) / kOsGroup; }
-__host__ inline size_t os_state_words(uint64_t n, int items) {
-  const uint32_t t = os_tiles(n, items);
-  return (size_t)kOsTableOff + (size_t)kRadix * (t + os_groups(t));
-}
+__host__ inline size_t os_state_words(uint64_t n, int items) { return (size_t)kOsTableOff + (size_t)kRadix * os_tiles(n, items); }
 
 template <bool DROP>
 __global__ void __launch_bounds__(kSortThreads)
@@ -352,7 +350,7 @@ __device__ __forceinline__ uint32_t os_look_back(gsr_gu32* table, uint32_t tile,
 
 // Phase stamps for tools/probe/sort_phases.hip (compiled out of the library)
 #ifdef GSR_OS_TRACE
-__device__ unsigned long long* g_os_trace = nullptr;      // [pass][tile][8] realtime stamps (100 MHz)
+__device__ unsigned long long* g_os_trace = nullptr;      // [pass][view][block][8] realtime stamps (100 MHz)
 #define GSR_OS_STAMP(k) do { if (threadIdx.x == 0 && g_os_trace) \
     g_os_trace[(((size_t)pass * 4 + blockIdx.y) * 4096 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
 #else
@@ -464,37 +462,16 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     }
     cnt = run;
   }
-  // publish the count, then look back (thread d for digit d): earlier tiles of the own group, then the group rows
+  // publish the count, then look back (thread d for digit d)
   gsr_gu32* table = gsr_global(os + kOsTableOff);
-  gsr_gu32* gtable = table + (size_t)gridDim.x * kRadix;
   const uint32_t tagA = (uint32_t)(2 * pass + 1) << 28, tagI = (uint32_t)(2 * pass + 2) << 28;
-  const uint32_t grp = tile / kOsGroup;
-  const int gpos = (int)(tile % kOsGroup);
-  __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagA | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t excl = 0;
-  if (gpos) {                                  // (workgroup-uniform)
-    for (;;) {
-      uint32_t sum = 0;
-      bool ok = true;
-#pragma unroll
-      for (int j = 1; j < kOsGroup; ++j)
-        if (j <= gpos) {
-          const uint32_t w = __hip_atomic_load(table + (size_t)(tile - j) * kRadix + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && ((w & 0xF0000000u) == tagA);
-          sum += w & 0x0FFFFFFFu;
-        }
-      if (ok) { excl = sum; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  if (gpos == kOsGroup - 1) {
-    // the group's last tile: the group's count, then (after the look-back over the earlier groups) its inclusive prefix
-    if (grp) __hip_atomic_store(gtable + (size_t)grp * kRadix + tid, tagA | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t before = grp ? os_look_back(gtable, grp, tid, tagA, tagI) : 0u;
-    __hip_atomic_store(gtable + (size_t)grp * kRadix + tid, tagI | (before + excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    excl += before;
-  } else if (grp) {
-    excl += os_look_back(gtable, grp, tid, tagA, tagI);
+  if (tile == 0) {
+    __hip_atomic_store(table + tid, tagI | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagA | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    excl = os_look_back(table, tile, tid, tagA, tagI);
+    __hip_atomic_store(table + (size_t)tile * kRadix + tid, tagI | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   GSR_OS_STAMP(3);
   // start of digit d's run inside the tile: exclusive scan of cnt over the digits
