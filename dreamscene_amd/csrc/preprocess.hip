@@ -31,6 +31,23 @@ __device__ __forceinline__ void load_view(const GsrView& v, ViewConst& c) {
   for (int i = 0; i < 3; ++i) c.cam[i] = v.campos[i];
 }
 
+// The constants of view vv inside a loop over the views of a batched launch: read through the CONSTANT address space, i.e.
+// with scalar loads (s_load, counted by lgkmcnt). As ordinary global loads (the address is uniform but the compiler cannot
+// prove that the kernel's own stores leave it alone) they are vector-memory operations, and on gfx9 those return IN ORDER
+// with the vector-memory stores: the first load of view vv + 1 waited for the write acknowledgement of everything view vv
+// had just stored -- one HBM write latency per view and wave in K1 and K8.
+typedef const __attribute__((address_space(4))) float gsr_cfloat;
+__device__ __forceinline__ gsr_cfloat* gsr_const(const float* p) { return (gsr_cfloat*)(uintptr_t)p; }
+__device__ __forceinline__ void load_view_const(const float* viewmatrix, const float* projmatrix, const float* campos, ViewConst& c) {
+  gsr_cfloat* V = gsr_const(viewmatrix);
+  gsr_cfloat* PV = gsr_const(projmatrix);
+  gsr_cfloat* cam = gsr_const(campos);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { c.V[i] = V[i]; c.PV[i] = PV[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c.cam[i] = cam[i];
+}
+
 // ---- multi-model ("scene") input: GsrScene flattened for the kernels (passed by value in the kernel arguments).
 // A workgroup never straddles two models: model m owns the workgroups [fblk[m], fblk[m+1]) and its Gaussians keep
 // their place first[m] + row in the concatenated index space every other kernel works in.
@@ -432,7 +449,10 @@ struct ViewDyn {
 __device__ __forceinline__ ViewDyn view_dyn(const float* __restrict__ dyn, float tfx, float tfy, int D) {
   ViewDyn d;
   d.tanfovx = tfx; d.tanfovy = tfy; d.sh_degree = D;
-  if (dyn) { d.tanfovx = dyn[0]; d.tanfovy = dyn[1]; d.sh_degree = (int)dyn[2]; }
+  if (dyn) {
+    gsr_cfloat* c = gsr_const(dyn);     // (scalar loads: see load_view_const)
+    d.tanfovx = c[0]; d.tanfovy = c[1]; d.sh_degree = (int)c[2];
+  }
   return d;
 }
 
@@ -662,10 +682,7 @@ k_preprocess_views(const GsrView v, const GsrGaussians g, const K1Views vb) {
   float opac = 0.f, tau = -1.f;
   for (int vv = 0; vv < vb.nv; ++vv) {
     ViewConst vc;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
+    load_view_const(vb.viewmatrix[vv], vb.projmatrix[vv], vb.campos[vv], vc);
     const ViewDyn vd = view_dyn(vb.dyn[vv], vb.tanfovx[vv], vb.tanfovy[vv], vb.sh_degree[vv]);
     const float tfx = vd.tanfovx, tfy = vd.tanfovy;
     const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
@@ -748,10 +765,7 @@ k_preprocess_views_scene(const GsrView v, const SceneTab sc, const K1Views vb) {
       so[3 * i] = sa[0]; so[3 * i + 1] = sa[1]; so[3 * i + 2] = sa[2];
     }
     ViewConst vc;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
+    load_view_const(vb.viewmatrix[vv], vb.projmatrix[vv], vb.campos[vv], vc);
     const ViewDyn vd = view_dyn(vb.dyn[vv], vb.tanfovx[vv], vb.tanfovy[vv], vb.sh_degree[vv]);
     const float tfx = vd.tanfovx, tfy = vd.tanfovy;
     const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
@@ -1307,29 +1321,42 @@ struct K8Views {
 // zero contributes exactly zero to every output of K8 -- every term of the chain rule is a product with one of them --
 // so the ~1 200 instructions per pair, and the 236 B parameter row, are only worth touching for the Gaussians some
 // view reached. Those are scattered (nearly every wave holds one), so the REACHED form of the kernel below compacts
-// them inside the workgroup:
-//   A. thread = Gaussian: radii + K7 sums of every view -> "reached by some view?", counted over the workgroup. More
-//      than kK8SparseMax of its 256: the workgroup carries on as the dense kernel (the sums are read a second time, from
-//      the cache). Otherwise it clears the gradient rows of its 256 Gaussians with coalesced stores (unless
-//      accumulating); a Gaussian nothing reached gets its per-view zeros and visibility statistics here and is done;
-//   B. the reached ones are listed in LDS (ballot / popcount prefix, ascending); wave c of the workgroup (rotated by the
-//      block index so that the work does not pile up on one SIMD) takes entries [64 c, 64 c + 64) and runs the dense
-//      chain rule on them -- same arithmetic, same summation order over the views, bit-identical rows -- writing each
-//      row itself over the cleared one; waves without entries leave.
-// At C3 a workgroup lists ~40 of its 256 Gaussians: one wave instead of four runs the chain rule and 84 % of the
-// parameter rows are never read. Measured (us per view, dense -> this): C3 27.6 -> 27.0 (the dense kernel is
-// not bound by its instruction count there after all), 2 M Gaussians @512^2 94.5 -> 76, single-view calls 2 360 -> 2 530
-// views/s. Forms that were measured and dropped: (i) chunks of (Gaussian, view) pairs dealt to the waves with the results
+// them inside the workgroup, which owns kK8Block = 1 024 consecutive Gaussians:
+//   A. every thread classifies four Gaussians (radii + K7's marks, GsrGrads.reach, of every view; without marks: the K7
+//      sums themselves) -> "reached by some view?". The workgroup clears the gradient rows (and the per-view rows) of its
+//      1 024 Gaussians with coalesced stores (unless accumulating); a Gaussian nothing reached gets its visibility
+//      statistics here and is done;
+//   B. the reached ones are listed in LDS (ballot / popcount prefix, ascending) and the four waves walk the list in rounds
+//      of 256 (wave slots rotated by the block index so that partial rounds do not pile up on one SIMD), running the dense
+//      chain rule on them -- same arithmetic, same summation order over the views, bit-identical rows -- and writing each
+//      row over the cleared one.
+// Where a workgroup spends its time (tools/k8_stamps.py: realtime stamps inside the kernel; C3, 4 views, 489 workgroups of
+// 1 024 Gaussians, 161 of them reached on average, all resident at once; us since the workgroup's entry, mean):
+//   classified 14.5 | parameters + SH row in 27.6 | rows cleared 47.9 | views done 54.0 58.4 62.5 66.6 | rows stored 69.2
+// and the launch takes 93 (the workgroups with two rounds). What the numbers say:
+//  * the chain rule is ~1 400 instructions per view and lane and runs at ~7 cycles per instruction -- one wave per SIMD,
+//    every instruction dependent on the last: 4.3 us per view whatever the occupancy of the lanes;
+//  * every memory round trip on the critical path costs 3-10 us while all workgroups are in the same phase, so requests
+//    are issued in batches (all slices and views of the classification at once; parameters, SH row and the first view's
+//    sums at once; the next view's sums before the current view's arithmetic) and the per-view constants come through
+//    scalar loads (load_view_const): on gfx9 a vector load issued behind a vector store waits for the store's
+//    acknowledgement, which is how the per-view stores used to serialise the views;
+//  * the 142 MB of zeros are 20 us of HBM writes during which nothing else progresses (all workgroups clear at the same
+//    time). Next lead: clear from the idle wave(s) only, skipping the reached rows, so that it overlaps the chain rule;
+//  * 230 -> 260 registers (the prefetch) halved the occupancy and cost 88 -> 121 us: amdgpu_waves_per_eu(2) pins it.
+// Round 2 gave a workgroup 256 Gaussians and ONE wave of it the ~40 reached ones (three shifts of workgroups, 101 us);
+// C3 in the opacity-0.1 initial state (67 % reached: three or four rounds per workgroup) is slower in this form than
+// with the old dense fallback (151 vs 124 us per launch) -- 3 % of that step.
+// Forms that were measured and dropped: (i) chunks of (Gaussian, view) pairs dealt to the waves with the results
 // summed by ds_add_f32 into a 256-row LDS tile (0.5 ns per pair: slower than dense once 5 % are active); (ii) a separate
 // classify launch appending to global lists kept in spare words of the K7 sums, then the dense kernel over the lists
 // (one list: 31 000 same-address atomics at 2 M Gaussians; one list per 8 192 Gaussians: the live workgroups of the
 // second launch all land on three of the eight XCDs); (iii) lane j of every wave holding the j-th reached Gaussian,
-// wave w running view w, results added to an LDS tile view after view between barriers: slower than this form
-// everywhere except at 2 M (72).
-#ifndef GSR_K8_SPARSE_MAX
-#define GSR_K8_SPARSE_MAX 128
+// wave w running view w, results added to an LDS tile view after view between barriers.
+#ifndef GSR_K8_BLOCK
+#define GSR_K8_BLOCK 1024
 #endif
-constexpr int kK8SparseMax = GSR_K8_SPARSE_MAX;
+constexpr int kK8Block = GSR_K8_BLOCK;       // Gaussians per workgroup of the REACHED form (a multiple of 256)
 
 // one lane's row of F floats -> global memory (dword-aligned 16-byte pieces)
 template <int F>
@@ -1362,107 +1389,198 @@ __device__ __forceinline__ void block_zero(float* __restrict__ dst, int n) {
 }
 
 template <int KT, bool PVS, bool REACHED = false>   // PVS: per-view scales; REACHED: the sparse form described above
-__global__ void __launch_bounds__(256)
+// (two waves per SIMD = two workgroups per CU: one resident wave of workgroups at 500 k Gaussians. Without the attribute the
+//  allocator took 260 registers, one workgroup per CU, and the kernel ran its workgroups in two shifts: 88 -> 121 us)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, const GsrGrads out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ uint32_t wcnt[4];
-  __shared__ uint8_t reached_list[256];
+  constexpr int kPer = REACHED ? kK8Block / 256 : 1;        // Gaussians classified per thread
+  __shared__ uint32_t wcnt[REACHED ? 4 * kPer : 1];
+  __shared__ uint16_t reached_list[REACHED ? kK8Block : 1];
   constexpr int F = 3 * KT;
   const int W = v.image_width, H = v.image_height;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t P = v.P;
-  const int64_t first = (int64_t)blockIdx.x * 256;
+  // REACHED: the workgroup's kPer slices of 256 consecutive Gaussians lie gridDim.x * 256 apart -- how many Gaussians the
+  // views reached varies along the index (C3: 161 of 1 024 on average, 566 in the densest contiguous block, and the kernel
+  // ends with the workgroup that has the most rounds); slices from four places average it
+  const auto slice_base = [&](int t) { return ((int64_t)t * gridDim.x + blockIdx.x) * 256; };
+  const int64_t first = REACHED ? slice_base(0) : (int64_t)blockIdx.x * 256;
   int64_t i = first + tid;
   bool ok = i < P;
-  bool sparse = false;   // uniform over the workgroup
+  constexpr bool sparse = REACHED;
+  int cnt = 0;           // REACHED: entries of reached_list
+#ifdef GSR_K8_STAMPS
+  unsigned long long ts[12];
+  int nts = 0;
+#define GSR_K8_STAMP() do { if (nts < 12) ts[nts++] = wall_clock64(); } while (0)
+#else
+#define GSR_K8_STAMP() do { } while (0)
+#endif
+  GSR_K8_STAMP();   // 0: entry
+  // phase A's verdicts, kept for the epilogue of round 0 (slice t = Gaussians slice_base(t) + tid)
+  bool reached[kPer];
+  unsigned long long rmask[kPer];
   if constexpr (REACHED) {
     // ---- A: which of the workgroup's Gaussians did some view reach?
-    bool reached = false;
-    for (int vv = 0; vv < vb.nv; ++vv) {
-      const int32_t r = ok ? vb.radii[vv][i] : 0;
-      if (vb.reach[0]) {
-        // K7 marked the Gaussians it committed sums for: 1 byte instead of the 40-byte sums of every visible Gaussian
-        reached = reached || (r > 0 && vb.reach[vv][i] != 0);
-      } else if (r > 0) {
-        const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
-        const float4 pa = pp[0], pb = pp[1];
-        const float2 pc = *reinterpret_cast<const float2*>(vb.partials[vv] + 12 * i + 8);
-        reached = reached || (pa.x != 0.f) || (pa.y != 0.f) || (pa.z != 0.f) || (pa.w != 0.f) || (pb.x != 0.f) ||
-                  (pb.y != 0.f) || (pb.z != 0.f) || (pb.w != 0.f) || (pc.x != 0.f) || (pc.y != 0.f);
+    // The loads of all slices of a view are issued together (every one of them is a memory latency if it is consumed
+    // where it is issued: 2 x 4 x 4 dependent round trips were 17 of this kernel's 95 us).
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) reached[t] = false;
+    for (int v0 = 0; v0 < vb.nv; v0 += 4) {
+      int32_t r[4][kPer];
+      uint32_t mk[4][kPer];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int t = 0; t < kPer; ++t) {
+          const int64_t it = slice_base(t) + tid;
+          const bool in = (v0 + u < vb.nv) && (it < P);
+          r[u][t] = in ? vb.radii[v0 + u][it] : 0;
+          // K7 marked the Gaussians it committed sums for: 1 byte instead of the 40-byte sums of every visible Gaussian
+          mk[u][t] = (vb.reach[0] && in) ? (uint32_t)vb.reach[v0 + u][it] : 0u;
+        }
       }
-    }
-    const unsigned long long m = __ballot(reached);
-    if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
-    if (lane == 0 && out.reached_mask && first + wave * 64 < P) {
-      // the rows a gradient exchange has to move (GsrGrads.reached_mask): one word per wave, owned by this wave alone
-      unsigned long long* w = reinterpret_cast<unsigned long long*>(out.reached_mask) + (first >> 6) + wave;
-      *w = out.accumulate ? (*w | m) : m;
-    }
-    __syncthreads();
-    const int cnt = (int)((wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]));
-    sparse = cnt <= kK8SparseMax;
-    if (sparse) {
-      if (!out.accumulate) {
-        const int nblk = (int)min((int64_t)256, P - first);
-        block_zero<true>(out.dL_dshs + first * F, nblk * F);
-        block_zero<false>(out.dL_dmeans3D + first * 3, nblk * 3);
-        block_zero<false>(out.dL_dopacities + first, nblk);
-        if constexpr (!PVS) block_zero<false>(out.dL_dscales + first * 3, nblk * 3);
-        block_zero<true>(out.dL_drotations + first * 4, nblk * 4);
-      }
-      if (ok && !reached) {   // what the chain rule below would produce from zeros
-        for (int vv = 0; vv < vb.nv; ++vv) {
-          float* m2 = vb.dL_dmeans2D[vv];
-          m2[3 * i] = 0.f; m2[3 * i + 1] = 0.f; m2[3 * i + 2] = 0.f;
-          if constexpr (PVS) {
-            float* o = vb.dL_dscales[vv];
-            o[3 * i] = 0.f; o[3 * i + 1] = 0.f; o[3 * i + 2] = 0.f;
-          }
-          if (out.stat_denom && ((vb.stat_mask >> vv) & 1u)) {
-            const int32_t r = vb.radii[vv][i];
-            if (r > 0) {
-              out.stat_denom[i] += 1.0f;
-              out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)r);
-            }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int t = 0; t < kPer; ++t) {
+          if (vb.reach[0]) {
+            reached[t] = reached[t] || ((r[u][t] > 0) & (mk[u][t] != 0u));
+          } else if (r[u][t] > 0) {      // without marks: the sums themselves
+            const float4* pp = reinterpret_cast<const float4*>(vb.partials[v0 + u] + 12 * (slice_base(t) + tid));
+            const float4 pa = pp[0], pb = pp[1];
+            const float2 pc = *reinterpret_cast<const float2*>(vb.partials[v0 + u] + 12 * (slice_base(t) + tid) + 8);
+            reached[t] = reached[t] || (pa.x != 0.f) || (pa.y != 0.f) || (pa.z != 0.f) || (pa.w != 0.f) || (pb.x != 0.f) ||
+                         (pb.y != 0.f) || (pb.z != 0.f) || (pb.w != 0.f) || (pc.x != 0.f) || (pc.y != 0.f);
           }
         }
       }
-      // ---- B: the reached ones, ascending
-      if (reached) {
-        uint32_t off = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) off += wcnt[w];
-        reached_list[off] = (uint8_t)tid;
-      }
-      __syncthreads();   // (also orders the cleared rows before a lane of this workgroup rewrites one: same CU, same L2)
-      const int chunk = ((wave + 4 - (int)(blockIdx.x & 3u)) & 3) * 64;
-      if (chunk >= cnt) return;
-      ok = chunk + lane < cnt;
-      i = first + (ok ? (int)reached_list[chunk + lane] : 0);
     }
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) {
+      rmask[t] = __ballot(reached[t]);
+      if (lane == 0) wcnt[t * 4 + wave] = (uint32_t)__popcll(rmask[t]);
+    }
+    GSR_K8_STAMP();   // 1: classified
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) {
+      uint32_t off = 0;
+      for (int q = 0; q < t * 4 + wave; ++q) off += wcnt[q];
+      if (reached[t]) reached_list[off + (uint32_t)__popcll(rmask[t] & ((1ull << lane) - 1ull))] = (uint16_t)(t * 256 + tid);
+    }
+    for (int q = 0; q < 4 * kPer; ++q) cnt += (int)wcnt[q];
+    __syncthreads();
+    // (everything this phase STORES comes after the first loads of phase B, in the epilogue of round 0: vector-memory
+    //  operations return in order on gfx9, so a load issued behind a store waits for the store's write acknowledgement)
   }
-  const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;
-  const int n_valid = (int)min((int64_t)64, max((int64_t)0, P - wave_first));
   const float mod = v.scale_modifier;
   constexpr int stride = F | 1;
   float* lw = lds + wave * (64 * stride);
   float* sh = lw + lane * stride;
+  // ---- B (REACHED): rounds of 256 list entries, wave slot rotated by the block index; otherwise one pass, thread = Gaussian
+  for (int round = 0;; round += 256) {
+  bool active = true;    // REACHED: this wave has entries in this round (uniform over the wave)
+  if constexpr (REACHED) {
+    const int chunk = round + ((wave + 4 - (int)(blockIdx.x & 3u)) & 3) * 64;
+    active = chunk < cnt;
+    if (!active && round > 0) break;
+    ok = active && (chunk + lane < cnt);
+    {
+      const int e = ok ? (int)reached_list[chunk + lane] : 0;
+      i = slice_base(e >> 8) + (e & 255);
+    }
+  }
+  const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;      // (the dense form's coalesced write-back)
+  const int n_valid = (int)min((int64_t)64, max((int64_t)0, P - wave_first));
 
-  bool any = false;
-  for (int vv = 0; vv < vb.nv; ++vv) any = any || (ok && vb.radii[vv][i] > 0);
+  bool any = ok;         // REACHED: a listed Gaussian is visible in the view that reached it
+  if constexpr (!REACHED) {
+    any = false;
+    for (int vv = 0; vv < vb.nv; ++vv) any = any || (ok && vb.radii[vv][i] > 0);
+  }
   const unsigned long long amask = __ballot(any);
 
+  // one view ahead: radius, K7's mark and (REACHED: unconditionally -- an unmarked row is zero or ignored) the K7 sums of
+  // the next view are requested before the current view's arithmetic and before its stores
+  int32_t r_nx = 0;
+  uint32_t mk_nx = 1u;
+  float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f), b_nx = a_nx, c_nx = a_nx;
+  const auto prefetch_view = [&](int vv) {
+    r_nx = ok ? vb.radii[vv][i] : 0;
+    mk_nx = (ok && vb.reach[0]) ? (uint32_t)vb.reach[vv][i] : 1u;
+    if constexpr (REACHED) {
+      if (ok) {
+        const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
+        a_nx = pp[0]; b_nx = pp[1]; c_nx = pp[2];
+      }
+    }
+  };
+  // every request of the round goes out before anything is consumed: one memory latency, not four
   float px = 0, py = 0, pz = 0;
   float R[9], c6[6], s3[3] = {0.f, 0.f, 0.f};
   float4 q = make_float4(1, 0, 0, 0);
   if (any) {
     px = g.means3D[3 * i]; py = g.means3D[3 * i + 1]; pz = g.means3D[3 * i + 2];
     q = *reinterpret_cast<const float4*>(g.rotations + 4 * i);
+    if constexpr (!PVS) { s3[0] = g.scales[3 * i]; s3[1] = g.scales[3 * i + 1]; s3[2] = g.scales[3 * i + 2]; }
+  }
+  prefetch_view(0);
+  if (any) {
+    load_row<F>(g.shs + (size_t)i * F, sh);      // the lane's own SH row, kept (read only) in its LDS row
     quat_to_R(q, R);
     if constexpr (!PVS) {
-      s3[0] = mod * g.scales[3 * i]; s3[1] = mod * g.scales[3 * i + 1]; s3[2] = mod * g.scales[3 * i + 2];
+      s3[0] = mod * s3[0]; s3[1] = mod * s3[1]; s3[2] = mod * s3[2];
       cov3d_from(s3[0], s3[1], s3[2], R, c6);
     }
-    load_row<F>(g.shs + (size_t)i * F, sh);      // the lane's own SH row, kept (read only) in its LDS row
+  }
+  GSR_K8_STAMP();   // 2: parameters + SH row in, view 0 requested
+  if constexpr (REACHED) {
+    if (round == 0) {
+      // ---- the rows of the workgroup's Gaussians nothing reached: zeros, and their visibility statistics
+#pragma unroll
+      for (int t = 0; t < kPer; ++t) {
+        const int64_t base = slice_base(t), it = base + tid;
+        if (lane == 0 && out.reached_mask && base + wave * 64 < P) {
+          // the rows a gradient exchange has to move (GsrGrads.reached_mask): one word per wave and slice, owned by this wave
+          unsigned long long* w = reinterpret_cast<unsigned long long*>(out.reached_mask) + (base >> 6) + wave;
+          if (out.accumulate) *w |= rmask[t]; else *w = rmask[t];
+        }
+        if (!reached[t] && it < P && out.stat_denom) {   // visibility statistics (the reached ones: in the chain rule below)
+          float n = 0.f, rmax = 0.f;
+          for (int vv = 0; vv < vb.nv; ++vv)
+            if ((vb.stat_mask >> vv) & 1u) {
+              const int32_t r = vb.radii[vv][it];
+              if (r > 0) { n += 1.0f; rmax = fmaxf(rmax, (float)r); }
+            }
+          if (n > 0.f) {
+            out.stat_denom[it] += n;
+            out.stat_max_radii2D[it] = fmaxf(out.stat_max_radii2D[it], rmax);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < kPer; ++t) {
+        const int64_t base = slice_base(t);
+        const int nblk = (int)max((int64_t)0, min((int64_t)256, P - base));
+        if (nblk == 0) continue;
+        if (!out.accumulate) {
+          block_zero<true>(out.dL_dshs + base * F, nblk * F);
+          block_zero<false>(out.dL_dmeans3D + base * 3, nblk * 3);
+          block_zero<false>(out.dL_dopacities + base, nblk);
+          if constexpr (!PVS) block_zero<false>(out.dL_dscales + base * 3, nblk * 3);
+          block_zero<true>(out.dL_drotations + base * 4, nblk * 4);
+        }
+        for (int vv = 0; vv < vb.nv; ++vv) {      // the per-view rows: what the chain rule below would produce from zeros
+          block_zero<false>(vb.dL_dmeans2D[vv] + base * 3, nblk * 3);
+          if constexpr (PVS) block_zero<false>(vb.dL_dscales[vv] + base * 3, nblk * 3);
+        }
+      }
+      __syncthreads();   // (orders the cleared rows before a lane of this workgroup rewrites one: same CU, same L2)
+    }
+    GSR_K8_STAMP();   // 3: zero fill issued, barrier passed
+    if (!active) break;
   }
   float drot[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -1474,27 +1592,28 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   for (int k = 0; k < 9; ++k) dS[k] = 0.f;
 
   for (int vv = 0; vv < vb.nv; ++vv) {
-    const bool vis = ok && (vb.radii[vv][i] > 0);
+    const int32_t rad_v = r_nx;
+    const bool take = mk_nx != 0u;                      // (an unmarked Gaussian's sums are zero: not used)
+    float4 pa = a_nx, pb = b_nx, pc = c_nx;
+    if (vv + 1 < vb.nv) prefetch_view(vv + 1);
+    const bool vis = ok && (rad_v > 0);
     float gndx = 0.f, gndy = 0.f;
     if (vis) {
       ViewConst vc;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
+      load_view_const(vb.viewmatrix[vv], vb.projmatrix[vv], vb.campos[vv], vc);
       const ViewDyn vd = view_dyn(vb.dyn[vv], vb.tanfovx[vv], vb.tanfovy[vv], vb.sh_degree[vv]);
       const float tfx = vd.tanfovx, tfy = vd.tanfovy;
       const int D = vd.sh_degree;
       const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
       const float limx = 1.3f * tfx, limy = 1.3f * tfy;
       float4* pp = reinterpret_cast<float4*>(vb.partials[vv] + 12 * i);
-      float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
-      if (!vb.reach[0] || vb.reach[vv][i] != 0) {       // (an unmarked Gaussian's sums are zero: not read)
-        pa = pp[0]; pb = pp[1]; pc = pp[2];
-        if (vb.restore) {                               // GsrGrads.scratch_clean: leave the scratch as it was found
-          pp[0] = make_float4(0.f, 0.f, 0.f, 0.f); pp[1] = pp[0]; pp[2] = pp[0];
-          vb.reach[vv][i] = (uint8_t)0;
-        }
+      if constexpr (!REACHED) {
+        if (take) { pa = pp[0]; pb = pp[1]; pc = pp[2]; }
+      }
+      if (!take) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; pc = pa; }
+      if (take && vb.restore) {                         // GsrGrads.scratch_clean: leave the scratch as it was found
+        pp[0] = make_float4(0.f, 0.f, 0.f, 0.f); pp[1] = pp[0]; pp[2] = pp[0];
+        vb.reach[vv][i] = (uint8_t)0;
       }
       gop += pb.y;
       const float grgb[3] = {pb.z, pb.w, pc.x};
@@ -1563,7 +1682,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       if (out.stat_denom && ((vb.stat_mask >> vv) & 1u)) {
         out.stat_xyz_gradient_accum[i] += sqrtf(gndx * gndx + gndy * gndy);
         out.stat_denom[i] += 1.0f;
-        out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)vb.radii[vv][i]);
+        out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)rad_v);
       }
     }
     if (ok) {
@@ -1574,6 +1693,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
         o[3 * i] = 0.f; o[3 * i + 1] = 0.f; o[3 * i + 2] = 0.f;
       }
     }
+    GSR_K8_STAMP();   // 4..: a view done
   }
 
   float dscale[3] = {0.f, 0.f, 0.f};
@@ -1611,6 +1731,23 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     }
     *reinterpret_cast<float4*>(out.dL_drotations + 4 * i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
   }
+#ifdef GSR_K8_STAMPS
+  GSR_K8_STAMP();     // rows stored (issued)
+  if constexpr (REACHED) {
+    // timing experiment only (results are destroyed): wave slot 0 of every workgroup leaves its stamps, as 10 ns ticks since
+    // entry, in the first floats of view 0's dL_dmeans2D rows of this workgroup
+    if (round == 0 && lane == 0 && ((wave + 4 - (int)(blockIdx.x & 3u)) & 3) == 0) {
+      __builtin_amdgcn_s_waitcnt(0);
+      const unsigned long long tend = wall_clock64();
+      float* o = vb.dL_dmeans2D[0] + first * 3;
+      for (int k = 0; k < nts; ++k) o[k] = (float)(ts[k] - ts[0]);
+      o[nts] = (float)(tend - ts[0]);
+      o[14] = (float)cnt; o[15] = (float)nts;
+    }
+  }
+#endif
+  if constexpr (!REACHED) break;
+  }   // rounds
 }
 
 
@@ -1685,10 +1822,7 @@ k_preprocess_bwd_views_scene(const GsrView v, const SceneTab sc, const SceneGrad
     }
     if (vis) {
       ViewConst vc;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) { vc.V[k] = vb.viewmatrix[vv][k]; vc.PV[k] = vb.projmatrix[vv][k]; }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) vc.cam[k] = vb.campos[vv][k];
+      load_view_const(vb.viewmatrix[vv], vb.projmatrix[vv], vb.campos[vv], vc);
       const ViewDyn vd = view_dyn(vb.dyn[vv], vb.tanfovx[vv], vb.tanfovy[vv], vb.sh_degree[vv]);
       const float tfx = vd.tanfovx, tfy = vd.tanfovy;
       const int D = vd.sh_degree;
@@ -2030,11 +2164,12 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
   // (rows of 12 floats or fewer, K <= 4: skipping them saves less than the classification costs -- the 2 M indoor scene
   //  at K = 4 measured 36 us per view sparse, 33 dense -- so those keep the dense kernel)
   if (gsr_k8_sparse() && v.sh_stride >= 9) {
-#define GSR_LAUNCH_K8SP(KT)                                                                                         \
-  if (vb.per_view_scales)                                                                                           \
-    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, out0); \
-  else                                                                                                              \
-    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, false, true>), dim3(nb), dim3(256), lds, stream, v, g, vb, out0)
+    const uint32_t nbr = (uint32_t)(((int64_t)v.P + kK8Block - 1) / kK8Block);
+#define GSR_LAUNCH_K8SP(KT)                                                                                          \
+  if (vb.per_view_scales)                                                                                            \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true, true>), dim3(nbr), dim3(256), lds, stream, v, g, vb, out0); \
+  else                                                                                                               \
+    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, false, true>), dim3(nbr), dim3(256), lds, stream, v, g, vb, out0)
     switch (v.sh_stride) {
       case 16: GSR_LAUNCH_K8SP(16); break;
       case 9: GSR_LAUNCH_K8SP(9); break;
