@@ -374,7 +374,7 @@ static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom
   if (!b->tile_work || !img->tile_depth || !img->ckpt || !img->color || !img->depth_alpha) return GSR_EINVAL;
   if (!out->partials || !aligned16(out->partials)) return GSR_EINVAL;
   if (out->scratch_clean && !out->reach) return GSR_EINVAL;
-  if (out->reach && (reinterpret_cast<uintptr_t>(out->reach) & 3u)) return GSR_EINVAL;
+  if (out->reach && (reinterpret_cast<uintptr_t>(out->reach) & 7u)) return GSR_EINVAL;
   {
     const int n_stat = (out->stat_max_radii2D != nullptr) + (out->stat_xyz_gradient_accum != nullptr) +
                        (out->stat_denom != nullptr);
@@ -399,7 +399,7 @@ static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom
 // The scratch of one view (GsrGrads.partials + .reach) -> zeros
 static int clear_scratch(const GsrView* v, const GsrGrads* out, hipStream_t stream, bool partials = true) {
   if (partials) GSR_HIP(gsr_zero_async(out->partials, (size_t)v->P * 12 * sizeof(float), stream));
-  if (out->reach) GSR_HIP(gsr_zero_async(out->reach, ((size_t)v->P + 3) / 4 * 4, stream));
+  if (out->reach) GSR_HIP(gsr_zero_async(out->reach, ((size_t)v->P + 63) / 64 * 8, stream));
   return GSR_OK;
 }
 

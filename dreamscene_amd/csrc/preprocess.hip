@@ -1298,7 +1298,7 @@ struct K8Views {
   const int32_t* radii[GSR_MAX_BATCH_VIEWS];
   float* partials[GSR_MAX_BATCH_VIEWS];
   // GsrGrads.reach of every view (all set or all NULL) and its contract: restore = zero the consumed sums and marks again
-  uint8_t* reach[GSR_MAX_BATCH_VIEWS];
+  unsigned long long* reach[GSR_MAX_BATCH_VIEWS];
   int32_t restore;
   float* dL_dmeans2D[GSR_MAX_BATCH_VIEWS];
   // per-view scales (the trainers add fresh noise to the activated scales of every view, scene_gaussian.py:1004-1008):
@@ -1388,6 +1388,21 @@ __device__ __forceinline__ void block_zero(float* __restrict__ dst, int n) {
   }
 }
 
+// zeros over the rows of F floats [0, n) at dst (n <= 64) whose bit in `skip` is clear, one wave; rows stay whole: a
+// 16-byte store never straddles into a skipped row (F % 4 == 0 and dst 16-byte aligned, or 4-byte stores)
+template <int F>
+__device__ __forceinline__ void wave_zero_rows(float* __restrict__ dst, int n, unsigned long long skip, int lane) {
+  if constexpr (F % 4 == 0) {
+    constexpr int Q = F / 4;
+    float4* d = reinterpret_cast<float4*>(dst);
+    for (int q = lane; q < n * Q; q += 64)
+      if (!((skip >> (q / Q)) & 1ull)) d[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (int f = lane; f < n * F; f += 64)
+      if (!((skip >> (f / F)) & 1ull)) dst[f] = 0.f;
+  }
+}
+
 template <int KT, bool PVS, bool REACHED = false>   // PVS: per-view scales; REACHED: the sparse form described above
 // (two waves per SIMD = two workgroups per CU: one resident wave of workgroups at 500 k Gaussians. Without the attribute the
 //  allocator took 260 registers, one workgroup per CU, and the kernel ran its workgroups in two shifts: 88 -> 121 us)
@@ -1397,15 +1412,19 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   constexpr int kPer = REACHED ? kK8Block / 256 : 1;        // Gaussians classified per thread
   __shared__ uint32_t wcnt[REACHED ? 4 * kPer : 1];
   __shared__ uint16_t reached_list[REACHED ? kK8Block : 1];
+  __shared__ unsigned long long lmask[REACHED ? 4 * kPer : 1];   // reached Gaussians of the 64-row chunk (slice, wave)
+  __shared__ unsigned long long vmask[REACHED ? GSR_MAX_BATCH_VIEWS : 1][REACHED ? 4 * kPer : 1];   // ... per view (K7's marks)
+  __shared__ uint32_t zero_next;                                  // next chunk nobody has cleared yet
   constexpr int F = 3 * KT;
   const int W = v.image_width, H = v.image_height;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t P = v.P;
-  // REACHED: the workgroup's kPer slices of 256 consecutive Gaussians lie gridDim.x * 256 apart -- how many Gaussians the
-  // views reached varies along the index (C3: 161 of 1 024 on average, 566 in the densest contiguous block, and the kernel
-  // ends with the workgroup that has the most rounds); slices from four places average it
-  const auto slice_base = [&](int t) { return ((int64_t)t * gridDim.x + blockIdx.x) * 256; };
-  const int64_t first = REACHED ? slice_base(0) : (int64_t)blockIdx.x * 256;
+  // REACHED: the workgroup's 4 kPer chunks of 64 consecutive Gaussians lie gridDim.x * 64 apart -- how many Gaussians the
+  // views reached varies along the index (C3: 161 of 1 024 on average, 566 in the densest contiguous block, 455 with four
+  // slices of 256, and the kernel ends with the workgroup that has the most rounds); chunks from sixteen places average it.
+  // Chunk c = 4 t + wave belongs to the lanes of `wave` in slice t of phase A.
+  const auto chunk_base = [&](int c) { return ((int64_t)c * gridDim.x + blockIdx.x) * 64; };
+  const int64_t first = REACHED ? chunk_base(0) : (int64_t)blockIdx.x * 256;
   int64_t i = first + tid;
   bool ok = i < P;
   constexpr bool sparse = REACHED;
@@ -1418,7 +1437,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
 #define GSR_K8_STAMP() do { } while (0)
 #endif
   GSR_K8_STAMP();   // 0: entry
-  // phase A's verdicts, kept for the epilogue of round 0 (slice t = Gaussians slice_base(t) + tid)
+  // phase A's verdicts (slice t of a thread = Gaussian chunk_base(4 t + wave) + lane)
   bool reached[kPer];
   unsigned long long rmask[kPer];
   if constexpr (REACHED) {
@@ -1426,42 +1445,55 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     // The loads of all slices of a view are issued together (every one of them is a memory latency if it is consumed
     // where it is issued: 2 x 4 x 4 dependent round trips were 17 of this kernel's 95 us).
 #pragma unroll
-    for (int t = 0; t < kPer; ++t) reached[t] = false;
-    for (int v0 = 0; v0 < vb.nv; v0 += 4) {
-      int32_t r[4][kPer];
-      uint32_t mk[4][kPer];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (int t = 0; t < kPer; ++t) {
-          const int64_t it = slice_base(t) + tid;
-          const bool in = (v0 + u < vb.nv) && (it < P);
-          r[u][t] = in ? vb.radii[v0 + u][it] : 0;
-          // K7 marked the Gaussians it committed sums for: 1 byte instead of the 40-byte sums of every visible Gaussian
-          mk[u][t] = (vb.reach[0] && in) ? (uint32_t)vb.reach[v0 + u][it] : 0u;
-        }
+    for (int t = 0; t < kPer; ++t) { reached[t] = false; rmask[t] = 0ull; }
+    if (vb.reach[0]) {
+      // K7 marked the Gaussians it committed sums for (GsrGrads.reach: one bit per Gaussian and view): one 8-byte word per
+      // (view, chunk) -- thread 4 kPer vv + c fetches it -- instead of the 40-byte sums of every visible Gaussian
+      static_assert(GSR_MAX_BATCH_VIEWS * 4 * kPer <= 256, "one thread per (view, chunk) word");
+      if (tid < vb.nv * 4 * kPer) {
+        const int vv = tid / (4 * kPer), c = tid % (4 * kPer);
+        const int64_t r0 = chunk_base(c);
+        vmask[vv][c] = r0 < P ? vb.reach[vv][r0 >> 6] : 0ull;
       }
+      __syncthreads();
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int t = 0; t < kPer; ++t) {
+        for (int vv = 0; vv < vb.nv; ++vv) rmask[t] |= vmask[vv][4 * t + wave];
+        reached[t] = (rmask[t] >> lane) & 1ull;
+      }
+    } else {
+      // without marks: the sums themselves (the loads of all slices of four views are issued together)
+      for (int v0 = 0; v0 < vb.nv; v0 += 4) {
+        int32_t r[4][kPer];
 #pragma unroll
-        for (int t = 0; t < kPer; ++t) {
-          if (vb.reach[0]) {
-            reached[t] = reached[t] || ((r[u][t] > 0) & (mk[u][t] != 0u));
-          } else if (r[u][t] > 0) {      // without marks: the sums themselves
-            const float4* pp = reinterpret_cast<const float4*>(vb.partials[v0 + u] + 12 * (slice_base(t) + tid));
-            const float4 pa = pp[0], pb = pp[1];
-            const float2 pc = *reinterpret_cast<const float2*>(vb.partials[v0 + u] + 12 * (slice_base(t) + tid) + 8);
-            reached[t] = reached[t] || (pa.x != 0.f) || (pa.y != 0.f) || (pa.z != 0.f) || (pa.w != 0.f) || (pb.x != 0.f) ||
-                         (pb.y != 0.f) || (pb.z != 0.f) || (pb.w != 0.f) || (pc.x != 0.f) || (pc.y != 0.f);
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int t = 0; t < kPer; ++t) {
+            const int64_t it = chunk_base(4 * t + wave) + lane;
+            r[u][t] = ((v0 + u < vb.nv) && (it < P)) ? vb.radii[v0 + u][it] : 0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int t = 0; t < kPer; ++t) {
+            if (r[u][t] > 0) {
+              const float4* pp = reinterpret_cast<const float4*>(vb.partials[v0 + u] + 12 * (chunk_base(4 * t + wave) + lane));
+              const float4 pa = pp[0], pb = pp[1];
+              const float2 pc = *reinterpret_cast<const float2*>(vb.partials[v0 + u] + 12 * (chunk_base(4 * t + wave) + lane) + 8);
+              reached[t] = reached[t] || (pa.x != 0.f) || (pa.y != 0.f) || (pa.z != 0.f) || (pa.w != 0.f) || (pb.x != 0.f) ||
+                           (pb.y != 0.f) || (pb.z != 0.f) || (pb.w != 0.f) || (pc.x != 0.f) || (pc.y != 0.f);
+            }
           }
         }
       }
+#pragma unroll
+      for (int t = 0; t < kPer; ++t) rmask[t] = __ballot(reached[t]);
     }
 #pragma unroll
-    for (int t = 0; t < kPer; ++t) {
-      rmask[t] = __ballot(reached[t]);
-      if (lane == 0) wcnt[t * 4 + wave] = (uint32_t)__popcll(rmask[t]);
-    }
+    for (int t = 0; t < kPer; ++t)
+      if (lane == 0) { wcnt[t * 4 + wave] = (uint32_t)__popcll(rmask[t]); lmask[t * 4 + wave] = rmask[t]; }
+    if (tid == 0) zero_next = 0u;
     GSR_K8_STAMP();   // 1: classified
     __syncthreads();
 #pragma unroll
@@ -1482,15 +1514,13 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   // ---- B (REACHED): rounds of 256 list entries, wave slot rotated by the block index; otherwise one pass, thread = Gaussian
   for (int round = 0;; round += 256) {
   bool active = true;    // REACHED: this wave has entries in this round (uniform over the wave)
+  int entry = 0;         // REACHED: the lane's list entry
   if constexpr (REACHED) {
     const int chunk = round + ((wave + 4 - (int)(blockIdx.x & 3u)) & 3) * 64;
     active = chunk < cnt;
-    if (!active && round > 0) break;
     ok = active && (chunk + lane < cnt);
-    {
-      const int e = ok ? (int)reached_list[chunk + lane] : 0;
-      i = slice_base(e >> 8) + (e & 255);
-    }
+    entry = ok ? (int)reached_list[chunk + lane] : 0;
+    i = chunk_base(entry >> 6) + (entry & 63);      // (entry = 256 t + tid = 64 (4 t + wave) + lane)
   }
   const int64_t wave_first = (int64_t)blockIdx.x * 256 + wave * 64;      // (the dense form's coalesced write-back)
   const int n_valid = (int)min((int64_t)64, max((int64_t)0, P - wave_first));
@@ -1509,7 +1539,9 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f), b_nx = a_nx, c_nx = a_nx;
   const auto prefetch_view = [&](int vv) {
     r_nx = ok ? vb.radii[vv][i] : 0;
-    mk_nx = (ok && vb.reach[0]) ? (uint32_t)vb.reach[vv][i] : 1u;
+    if (!vb.reach[0]) mk_nx = 1u;
+    else if constexpr (REACHED) mk_nx = (uint32_t)((vmask[vv][entry >> 6] >> (entry & 63)) & 1ull);
+    else mk_nx = ok ? (uint32_t)((vb.reach[vv][i >> 6] >> (i & 63)) & 1ull) : 0u;
     if constexpr (REACHED) {
       if (ok) {
         const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
@@ -1536,51 +1568,65 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     }
   }
   GSR_K8_STAMP();   // 2: parameters + SH row in, view 0 requested
-  if constexpr (REACHED) {
-    if (round == 0) {
-      // ---- the rows of the workgroup's Gaussians nothing reached: zeros, and their visibility statistics
-#pragma unroll
-      for (int t = 0; t < kPer; ++t) {
-        const int64_t base = slice_base(t), it = base + tid;
-        if (lane == 0 && out.reached_mask && base + wave * 64 < P) {
-          // the rows a gradient exchange has to move (GsrGrads.reached_mask): one word per wave and slice, owned by this wave
-          unsigned long long* w = reinterpret_cast<unsigned long long*>(out.reached_mask) + (base >> 6) + wave;
-          if (out.accumulate) *w |= rmask[t]; else *w = rmask[t];
-        }
-        if (!reached[t] && it < P && out.stat_denom) {   // visibility statistics (the reached ones: in the chain rule below)
-          float n = 0.f, rmax = 0.f;
-          for (int vv = 0; vv < vb.nv; ++vv)
-            if ((vb.stat_mask >> vv) & 1u) {
-              const int32_t r = vb.radii[vv][it];
-              if (r > 0) { n += 1.0f; rmax = fmaxf(rmax, (float)r); }
-            }
-          if (n > 0.f) {
-            out.stat_denom[it] += n;
-            out.stat_max_radii2D[it] = fmaxf(out.stat_max_radii2D[it], rmax);
-          }
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < kPer; ++t) {
-        const int64_t base = slice_base(t);
-        const int nblk = (int)max((int64_t)0, min((int64_t)256, P - base));
-        if (nblk == 0) continue;
-        if (!out.accumulate) {
-          block_zero<true>(out.dL_dshs + base * F, nblk * F);
-          block_zero<false>(out.dL_dmeans3D + base * 3, nblk * 3);
-          block_zero<false>(out.dL_dopacities + base, nblk);
-          if constexpr (!PVS) block_zero<false>(out.dL_dscales + base * 3, nblk * 3);
-          block_zero<true>(out.dL_drotations + base * 4, nblk * 4);
-        }
-        for (int vv = 0; vv < vb.nv; ++vv) {      // the per-view rows: what the chain rule below would produce from zeros
-          block_zero<false>(vb.dL_dmeans2D[vv] + base * 3, nblk * 3);
-          if constexpr (PVS) block_zero<false>(vb.dL_dscales[vv] + base * 3, nblk * 3);
-        }
-      }
-      __syncthreads();   // (orders the cleared rows before a lane of this workgroup rewrites one: same CU, same L2)
+  // ---- what a wave does when it has no (more) list entries: the words of the exchange mask and the visibility statistics
+  // of its lanes' Gaussians, then zeros over the rows nothing reached -- 64-row chunks claimed from a counter, so the
+  // waves that are idle from the start clear while the others run the chain rule, and nothing the chain rule loads
+  // queues behind those stores (the reached rows are written by the chain rule alone: the two never touch the same row)
+  const auto wave_exit = [&]() {
+    if (vb.restore && vb.reach[0] && tid < vb.nv * 4 * kPer) {      // GsrGrads.scratch_clean: K7's marks back to zero
+      const int64_t r0 = chunk_base(tid % (4 * kPer));
+      if (r0 < P) vb.reach[tid / (4 * kPer)][r0 >> 6] = 0ull;
     }
-    GSR_K8_STAMP();   // 3: zero fill issued, barrier passed
-    if (!active) break;
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) {
+      const int64_t base = chunk_base(4 * t + wave), it = base + lane;
+      const unsigned long long rm = lmask[t * 4 + wave];      // (from LDS: nothing of phase A stays in registers)
+      if (lane == 0 && out.reached_mask && base < P) {
+        // the rows a gradient exchange has to move (GsrGrads.reached_mask): one word per wave and slice, owned by this wave
+        unsigned long long* w = reinterpret_cast<unsigned long long*>(out.reached_mask) + (base >> 6);
+        if (out.accumulate) *w |= rm; else *w = rm;
+      }
+      if (!((rm >> lane) & 1ull) && it < P && out.stat_denom) {   // visibility statistics (the reached ones: in the chain rule)
+        float n = 0.f, rmax = 0.f;
+        for (int vv = 0; vv < vb.nv; ++vv)
+          if ((vb.stat_mask >> vv) & 1u) {
+            const int32_t r = vb.radii[vv][it];
+            if (r > 0) { n += 1.0f; rmax = fmaxf(rmax, (float)r); }
+          }
+        if (n > 0.f) {
+          out.stat_denom[it] += n;
+          out.stat_max_radii2D[it] = fmaxf(out.stat_max_radii2D[it], rmax);
+        }
+      }
+    }
+    for (;;) {
+      uint32_t c = 0;
+      if (lane == 0) c = atomicAdd(&zero_next, 1u);
+      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+      if (c >= (uint32_t)(4 * kPer)) break;
+      const int64_t r0 = chunk_base((int)c);
+      const int n = (int)max((int64_t)0, min((int64_t)64, P - r0));
+      if (n == 0) continue;
+      const unsigned long long skip = lmask[c];
+      if (!out.accumulate) {
+        wave_zero_rows<F>(out.dL_dshs + r0 * F, n, skip, lane);
+        wave_zero_rows<3>(out.dL_dmeans3D + r0 * 3, n, skip, lane);
+        wave_zero_rows<1>(out.dL_dopacities + r0, n, skip, lane);
+        if constexpr (!PVS) wave_zero_rows<3>(out.dL_dscales + r0 * 3, n, skip, lane);
+        wave_zero_rows<4>(out.dL_drotations + r0 * 4, n, skip, lane);
+      }
+      for (int vv = 0; vv < vb.nv; ++vv) {      // the per-view rows: what the chain rule would produce from zeros
+#ifdef GSR_K8_STAMPS
+        if (c == 0 && vv == 0) continue;        // (the stamps are left there)
+#endif
+        wave_zero_rows<3>(vb.dL_dmeans2D[vv] + r0 * 3, n, skip, lane);
+        if constexpr (PVS) wave_zero_rows<3>(vb.dL_dscales[vv] + r0 * 3, n, skip, lane);
+      }
+    }
+  };
+  GSR_K8_STAMP();   // 3
+  if constexpr (REACHED) {
+    if (!active) { wave_exit(); break; }
   }
   float drot[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -1596,6 +1642,9 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     const bool take = mk_nx != 0u;                      // (an unmarked Gaussian's sums are zero: not used)
     float4 pa = a_nx, pb = b_nx, pc = c_nx;
     if (vv + 1 < vb.nv) prefetch_view(vv + 1);
+    if constexpr (!REACHED) {     // (the wave owns the mark word of its 64 Gaussians; the REACHED form: wave_exit)
+      if (vb.restore && vb.reach[0] && ok && (i & 63) == 0) vb.reach[vv][i >> 6] = 0ull;
+    }
     const bool vis = ok && (rad_v > 0);
     float gndx = 0.f, gndy = 0.f;
     if (vis) {
@@ -1613,7 +1662,6 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       if (!take) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; pc = pa; }
       if (take && vb.restore) {                         // GsrGrads.scratch_clean: leave the scratch as it was found
         pp[0] = make_float4(0.f, 0.f, 0.f, 0.f); pp[1] = pp[0]; pp[2] = pp[0];
-        vb.reach[vv][i] = (uint8_t)0;
       }
       gop += pb.y;
       const float grgb[3] = {pb.z, pb.w, pc.x};
@@ -1747,6 +1795,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   }
 #endif
   if constexpr (!REACHED) break;
+  else if (round + 256 + ((wave + 4 - (int)(blockIdx.x & 3u)) & 3) * 64 >= cnt) { wave_exit(); break; }
   }   // rounds
 }
 
@@ -2125,7 +2174,7 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
     vb.tanfovx[k] = views[k].tanfovx; vb.tanfovy[k] = views[k].tanfovy; vb.sh_degree[k] = views[k].sh_degree;
     vb.dyn[k] = views[k].dynamic;
     vb.radii[k] = geoms[k].radii; vb.partials[k] = outs[k].partials; vb.dL_dmeans2D[k] = outs[k].dL_dmeans2D;
-    vb.reach[k] = g.scene ? nullptr : outs[k].reach;
+    vb.reach[k] = g.scene ? nullptr : reinterpret_cast<unsigned long long*>(outs[k].reach);
     if ((outs[k].reach != nullptr) != (outs[0].reach != nullptr)) return GSR_EINVAL;
   }
   vb.restore = (!g.scene && outs[0].reach && outs[0].scratch_clean) ? 1 : 0;

@@ -658,7 +658,7 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
              const float4* __restrict__ splat, const float* __restrict__ bg, const float* __restrict__ color,
              const float* __restrict__ depth_alpha, const float* __restrict__ final_T,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-             const float* __restrict__ dL_dda, float* __restrict__ partials, uint8_t* __restrict__ reach) {
+             const float* __restrict__ dL_dda, float* __restrict__ partials, unsigned long long* __restrict__ reach) {
   __shared__ float4 s0[kBatch], s1[kBatch], s2[kBatch];
   __shared__ uint32_t sid[kBatch], smask[kBatch];
   __shared__ unsigned long long hitw[kBatch / 64];    // staged entries some wave committed sums for (-> GsrGrads.reach)
@@ -790,10 +790,10 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
     if (reach && hitk && lane == 0) atomicOr(&hitw[k], hitk);
   }
   if (reach) {
-    // the Gaussians this item committed sums for: one byte each, written (not added: any number of items may mark the
-    // same Gaussian) by the thread that staged the entry
+    // the Gaussians this item committed sums for: one bit each, set by the thread that staged the entry (outside the loop:
+    // a handful of 64-bit atomics per item)
     __syncthreads();
-    if (tid < n && ((hitw[tid >> 6] >> (tid & 63)) & 1ull)) reach[sid[tid]] = (uint8_t)1;
+    if (tid < n && ((hitw[tid >> 6] >> (tid & 63)) & 1ull)) atomicOr(reach + (sid[tid] >> 6), 1ull << (sid[tid] & 63u));
   }
  }
 }
@@ -848,7 +848,7 @@ struct BwdViews {
   const float* dL_dcolor[GSR_MAX_BATCH_VIEWS];
   const float* dL_dda[GSR_MAX_BATCH_VIEWS];
   float* partials[GSR_MAX_BATCH_VIEWS];
-  uint8_t* reach[GSR_MAX_BATCH_VIEWS];
+  unsigned long long* reach[GSR_MAX_BATCH_VIEWS];
 };
 
 template <bool SCORE>
@@ -975,7 +975,7 @@ int gsr_launch_render_bwd_views(int n, const GsrView* views, const GsrGeom* geom
     bv.splat[k] = reinterpret_cast<const float4*>(geoms[k].splat); bv.bg[k] = views[k].bg; bv.color[k] = imgs[k].color;
     bv.depth_alpha[k] = imgs[k].depth_alpha; bv.final_T[k] = imgs[k].final_T; bv.n_contrib[k] = imgs[k].n_contrib;
     bv.dL_dcolor[k] = igs[k].dL_dcolor; bv.dL_dda[k] = igs[k].dL_ddepth_alpha; bv.partials[k] = outs[k].partials;
-    bv.reach[k] = outs[k].reach;
+    bv.reach[k] = reinterpret_cast<unsigned long long*>(outs[k].reach);
     items_cap = bs[k].bwd_items_cap > items_cap ? bs[k].bwd_items_cap : items_cap;
   }
   GsrStageTimer timer(prof, stream, GSR_STAGE_RENDER_BWD);

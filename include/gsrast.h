@@ -217,9 +217,10 @@ typedef struct GsrGrads {
                                  an object is exactly zero). K8 classifies the Gaussians K7 reached anyway (its sparse form);
                                  forms of K8 that do not classify set every bit. accumulate = 0: the words are overwritten;
                                  accumulate = 1: OR-ed into (the union over the views added to the gradient buffers) */
-  uint8_t* reach;             /* NULL or device scratch of (P + 3) / 4 * 4 bytes (u8[P], padded) next to `partials`: K7 marks the Gaussians it composited into
-                                 this view (1 byte each), so that K8 finds them without reading the [P,12] sums of every
-                                 visible Gaussian (96 MB of the 4-view step at 500 k Gaussians, of which 15 MB are non-zero) */
+  uint64_t* reach;            /* NULL or device scratch u64[(P + 63) / 64] next to `partials`: K7 sets bit i % 64 of word
+                                 i / 64 for the Gaussians it composited into this view, so that K8 finds them without
+                                 reading the [P,12] sums of every visible Gaussian (96 MB of the 4-view step at 500 k
+                                 Gaussians, of which 15 MB are non-zero): one word per 64 Gaussians and view */
   int32_t scratch_clean;      /* 0: `partials` (and `reach`) hold anything on entry -- the library clears them first -- and
                                  anything on return. 1 (needs `reach`): the caller keeps both buffers between calls and
                                  guarantees they are ALL ZERO on entry; the library leaves them all zero on return (K8 zeroes

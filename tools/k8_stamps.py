@@ -1,5 +1,8 @@
-"""Timing experiment (GSR_LIB=dreamscene_amd/libgsrast_stamps.so, built with -DGSR_K8_STAMPS): where does a workgroup of K8
-spend its time? One 4-view step at C3; the stamps come back in view 0's dL_dmeans2D (the results of that tensor are destroyed)."""
+"""Timing experiment: where does a workgroup of K8 spend its time? One 4-view step at C3 with a library built with
+-DGSR_K8_STAMPS; the realtime stamps come back in view 0's dL_dmeans2D (the results of that tensor are destroyed).
+    python -c "from dreamscene_amd import build as B; B.build(extra_flags=['-DGSR_K8_STAMPS'], \
+               out='dreamscene_amd/libgsrast_stamps.so', objdir='dreamscene_amd/_obj_stamps')"
+    GSR_LIB=$PWD/dreamscene_amd/libgsrast_stamps.so python tools/k8_stamps.py"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +27,7 @@ for rep in range(4):
     torch.autograd.backward([x for (img, _, da) in outs for x in (img, da)], [y for k in range(V) for y in (gi[k], gd[k])])
     torch.cuda.synchronize()
 nwg = (P + 1023) // 1024
-st = m2d.grad[0].reshape(-1)[: nwg * 768].reshape(-1, 768)[:, :16].cpu().numpy()   # slice 0 of workgroup b = Gaussians [256 b, 256 b + 256)
+st = m2d.grad[0].reshape(-1)[: nwg * 192].reshape(-1, 192)[:, :16].cpu().numpy()   # chunk 0 of workgroup b = Gaussians [64 b, 64 b + 64)
 n = int(st[0, 15])
 print("workgroups", st.shape[0], "stamps", n, "reached per workgroup: mean %.0f max %.0f" % (st[:, 14].mean(), st[:, 14].max()))
 names = ["entry", "classified", "params+SH in, view 0 requested", "zero fill issued + barrier"] + [f"view {k} done" for k in range(n - 5)] + ["rows stored (issued)", "all memory ops complete"]
