@@ -263,6 +263,16 @@ k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restr
   }
 }
 
+// Workgroup b of a 1-D grid runs on XCD b % 8 (each XCD has its own L2). Neighbouring blocks -- runs of one column here,
+// runs of 64 depth-ordered Gaussians in k_emit_cols -- write neighbouring list positions, i.e. they share the cache lines at
+// their seams; on different XCDs each L2 holds its part of such a line and writes it back partially (a read-modify-write
+// at the memory: k_emit_cols moved 177 MB for 49 MB of pairs). So logical block ids are dealt in CONTIGUOUS ranges per XCD:
+// raw index b -> (b % 8) * ceil(n / 8) + b / 8 for the n blocks in use (the grid is rounded up to a multiple of 8).
+__device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n) {
+  const uint32_t per = (n + 7u) / 8u, j = b >> 3, id = (b & 7u) * per + j;
+  return (j < per && id < n) ? id : 0xFFFFFFFFu;
+}
+
 // One wave per run of 64 depth-ordered Gaussians. Lanes enumerate the run's PAIRS (Gaussian-major, then row-major
 // inside the rectangle) 64 at a time; a pair's position in the "sorted by tx" list is the running counter of its
 // column (start: colstart + scanned hist1) plus its rank among the round's pairs of the same column -- the stable
@@ -277,10 +287,10 @@ k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x,
   __shared__ uint32_t col_run[256];
   __shared__ uint32_t pbase[65];
   __shared__ uint32_t rs[64], ids[64], mg[64];
-  const uint32_t run_id = blockIdx.x;
-  const int64_t s0 = (int64_t)run_id * kColRun;
   const int64_t nv = (int64_t)*n_vis;
-  if (s0 >= nv) return;
+  const uint32_t run_id = xcd_chunked(blockIdx.x, (uint32_t)((nv + kColRun - 1) / kColRun));   // (see col_blocks)
+  if (run_id == 0xFFFFFFFFu) return;
+  const int64_t s0 = (int64_t)run_id * kColRun;
   const int lane = threadIdx.x;
   for (int tx = lane; tx < gx; tx += 64) col_run[tx] = colstart[tx] + hist1[(uint64_t)tx * nrun + run_id];
   const bool in = s0 + lane < nv;
@@ -331,12 +341,14 @@ k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x,
 
 // ---- second pass: stable by ty over column-aligned workgroups
 struct ColBlocks {
-  uint32_t col, base, end;   // this workgroup's column and element range [base, end)
+  uint32_t blk;              // this workgroup's logical block (0xFFFFFFFF: none)
+  uint32_t col, base, end;   // its column and element range [base, end)
+  uint32_t total;            // logical blocks in use
 };
 
 // Every workgroup derives the block table from colstart: column tx owns max(1, ceil(cnt/4096)) workgroups.
 __device__ __forceinline__ ColBlocks col_blocks(const uint32_t* __restrict__ colstart, int gx, uint32_t cap,
-                                                uint32_t blk, uint32_t* sh_fb /*[257]*/, uint32_t* sh_tmp /*[8]*/) {
+                                                uint32_t raw_b, uint32_t* sh_fb /*[257]*/, uint32_t* sh_tmp /*[8]*/) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t cs = 0, ce = 0;
   if (tid < gx) {
@@ -358,14 +370,17 @@ __device__ __forceinline__ ColBlocks col_blocks(const uint32_t* __restrict__ col
   const uint32_t fb = woff + inc - nb;
   sh_fb[tid] = fb;
   if (tid == 255) sh_fb[256] = fb + nb;
-  if (nb && blk >= fb && blk < fb + nb) {
+  __syncthreads();
+  ColBlocks cb;
+  cb.total = sh_fb[256];
+  cb.blk = xcd_chunked(raw_b, cb.total);
+  if (nb && cb.blk >= fb && cb.blk < fb + nb) {       // (0xFFFFFFFF matches nobody)
     sh_tmp[4] = (uint32_t)tid;
-    sh_tmp[5] = cs + (blk - fb) * kPass2Block;
+    sh_tmp[5] = cs + (cb.blk - fb) * kPass2Block;
     sh_tmp[6] = ce;
   }
   __syncthreads();
-  ColBlocks cb;
-  const bool any = blk < sh_fb[256];
+  const bool any = cb.blk != 0xFFFFFFFFu;
   cb.col = any ? sh_tmp[4] : 0xFFFFFFFFu;
   cb.base = any ? sh_tmp[5] : 0u;
   cb.end = any ? min(sh_tmp[6], cb.base + kPass2Block) : 0u;
@@ -380,9 +395,11 @@ k_row_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ colst
   __shared__ uint32_t sh_fb[257];
   __shared__ uint32_t sh_tmp[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t blk = blockIdx.x;
   h[tid] = 0;
-  const ColBlocks cb = col_blocks(colstart, gx, cap, blk, sh_fb, sh_tmp);
+  const ColBlocks cb = col_blocks(colstart, gx, cap, blockIdx.x, sh_fb, sh_tmp);
+  // (the scan runs over all nblk columns of the table: the ones past the blocks in use are zeroed by their raw index)
+  if (blockIdx.x >= cb.total && blockIdx.x < nblk) hist[(uint64_t)tid * nblk + blockIdx.x] = 0u;
+  if (cb.blk == 0xFFFFFFFFu) return;
   if (cb.base < cb.end) {
     uint32_t kv[kPass2Items];
 #pragma unroll
@@ -397,7 +414,7 @@ k_row_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ colst
       if (kv[it] != 0xFFFFFFFFu) atomicAdd(&h[kv[it] >> 24], 1u);
   }
   __syncthreads();
-  hist[(uint64_t)tid * nblk + blk] = h[tid];
+  hist[(uint64_t)tid * nblk + cb.blk] = h[tid];
 }
 
 // per-view outputs of the ty pass (they live in separately allocated per-view state buffers)
@@ -421,9 +438,9 @@ k_row_scatter(const uint32_t* __restrict__ vals_in, const RowOut ro, const uint3
   __shared__ uint32_t sh_fb[257];
   __shared__ uint32_t sh_tmp[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t blk = blockIdx.x;
-  const ColBlocks cb = col_blocks(colstart, gx, cap, blk, sh_fb, sh_tmp);
+  const ColBlocks cb = col_blocks(colstart, gx, cap, blockIdx.x, sh_fb, sh_tmp);
   if (cb.col == 0xFFFFFFFFu) return;
+  const uint32_t blk = cb.blk;
 #pragma unroll
   for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
   {
@@ -630,7 +647,7 @@ static int launch_binning_columns(int n, const GsrView& v, const GsrGeom* geoms,
     GsrStageTimer t(prof, stream, GSR_STAGE_DUPLICATE);
     int nbits_x = 1;
     while ((1 << nbits_x) < gx) ++nbits_x;
-    hipLaunchKernelGGL(k_emit_cols, dim3(nrun, ny), dim3(64), 0, stream, n_dev_vis, gx, nbits_x, rect_sorted,
+    hipLaunchKernelGGL(k_emit_cols, dim3((nrun + 7u) / 8u * 8u, ny), dim3(64), 0, stream, n_dev_vis, gx, nbits_x, rect_sorted,
                        geom.sorted_idx, s.hist1, nrun, s.colstart, cap, vals1, ps, ss);
     GSR_HIP(hipGetLastError());
   }
@@ -639,11 +656,11 @@ static int launch_binning_columns(int n, const GsrView& v, const GsrGeom* geoms,
     //  per-row totals left by k_col_hist: bit-identical lists, 87 us per 4-view launch against 84 for these three -- the
     //  816 blocks of a view are all resident at once, so the look-back chain, not the data, sets the time; not kept)
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    hipLaunchKernelGGL(k_row_hist, dim3(nblk, ny), dim3(kSortThreads), 0, stream, vals1, s.colstart, gx, cap, nbits, nblk,
+    hipLaunchKernelGGL(k_row_hist, dim3((nblk + 7u) / 8u * 8u, ny), dim3(kSortThreads), 0, stream, vals1, s.colstart, gx, cap, nbits, nblk,
                        hist, ps, ss);
     hipLaunchKernelGGL(k_radix_scan, dim3(kRadix, ny), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr,
                        1u, ss);
-    hipLaunchKernelGGL(k_row_scatter, dim3(nblk, ny), dim3(kSortThreads), 0, stream, vals1, ro, s.colstart, gx, gy, cap,
+    hipLaunchKernelGGL(k_row_scatter, dim3((nblk + 7u) / 8u * 8u, ny), dim3(kSortThreads), 0, stream, vals1, ro, s.colstart, gx, gy, cap,
                        nbits, nblk, hist, totals, ps, ss);
     GSR_HIP(hipGetLastError());
   }
