@@ -442,10 +442,12 @@ def main():
                                 n_salu = sq.get("SQ_INSTS_SALU", 0.0)
                                 mix = VALU_MIX.get(dominant, {"plain": 0.5, "other": 0.5, "trans": 0.0})
                                 ns_valu = sum(mix[c] * ISSUE_NS[c] for c in mix)
-                                busy_ns = n_valu * ns_valu + n_salu * ISSUE_NS["salu"]
+                                # (scalar instructions issue beside the vector instructions of the other waves: removing 22 of
+                                #  them per step from K6's loop changed nothing, tools/ab_lib.sh A/B -- they are not priced)
+                                busy_ns = n_valu * ns_valu
                                 valu = {"insts_per_launch": int(n_valu), "salu_per_launch": int(n_salu),
                                         "issue_ns": ISSUE_NS, "valu_mix": mix, "simds": SIMDS,
-                                        # modelled share of the SIMDs' issue time the launch's instructions need
+                                        # modelled share of the SIMDs' time the launch's VECTOR instructions need to issue
                                         "issue_frac": round(busy_ns * 1e-9 / (SIMDS * avg_s), 4),
                                         # VALU instructions per second against the best the part issues (plain class)
                                         "inst_rate_frac_of_peak": round(n_valu * ISSUE_NS["plain"] * 1e-9 / (SIMDS * avg_s), 4),
