@@ -1,6 +1,6 @@
 #!/bin/bash
-# kernel-trace timing of K1 / K8 (and K7 as the yardstick of the box) for the product library and variants of it
-# usage: tools/k8_variants.sh <tag> [variant names: dreamscene_amd/libgsrast_<name>.so ...]
+# kernel-trace timing of K1 / K8 (and K7 as the yardstick of the box) for the product library and variants of it:
+# usage: tools/kernel_times.sh <tag> [variant names: dreamscene_amd/libgsrast_<name>.so ...]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/$1; mkdir -p $O; shift
 cd /tmp && export TMPDIR=/tmp
 for v in new "$@"; do
