@@ -11,7 +11,7 @@
 //    block into a byte list in LDS; K7's waves walk a 64-bit ballot with scalar code. Splats that cannot touch a wave's
 //    pixels cost it no vector instructions; the per-pixel gates (power > 0, alpha < 1/255, T < 1e-4) are evaluated
 //    unchanged on the survivors, as 64-bit lane masks on the scalar unit.
-//  * K7 reduces the 10 per-splat gradient sums over the wave's 64 pixels with a transposed butterfly (25 VALU ops,
+//  * K7 reduces the 10 per-splat gradient sums over the wave's 64 pixels with a transposed butterfly (24 VALU ops,
 //    reduce10) that leaves them in 10 different lanes: ONE global_atomic_add_f32 instruction commits a splat.
 //  * Load balance: tiles differ in cost by orders of magnitude (empty / silhouette / deep). The work lists are ordered
 //    heaviest-first on the device (k_work_order_fwd / _bwd) and workgroup b simply takes item b: the hardware
@@ -573,13 +573,16 @@ render_fwd_tile_body(const uint32_t item, const int W, const int H, const uint32
 }
 
 // --------------------------------------------------------------------------------------------------------- K7
-// Transposed butterfly over the 64 lanes for 10 values (see file header): at every step a lane keeps one register of
-// a pair and hands the other one to its partner, so the number of live registers halves while the sums grow
-// (10 -> 5 by permlane32 swap, -> 3 by permlane16 swap, -> 2 by row_ror:8 = lane ^ 8, -> 1 by row_half_mirror =
-// lane ^ 7, then quad_perm xor 2 and xor 1: 8, 7, 2, 1 span the 16 lanes of a row). 23 VALU ops. On return lane L of
-// row r = L >> 4 holds the wave total of component 4 w + ((r & 1) << 1 | (r >> 1)), where w = 2 if L & 4, else
-// 1 if L & 8, else 0:
-//   w = 0: rows -> v0 v2 v1 v3     w = 1: rows -> v4 v6 v5 v7     w = 2: rows -> v8 (pad) v9 (pad)
+// Transposed butterfly over the 64 lanes for 10 values (see file header): at every step a lane keeps one register of a
+// pair and hands the other one to its partner, so the number of live registers halves while the sums grow:
+//   10 -> 5 over lane bit 3 (row_ror:8 = lane ^ 8), -> 3 over bit 2 (row_half_mirror = lane ^ 7), -> 2 over bit 5
+//   (permlane32 swap), -> 1 over bit 4 (permlane16 swap), then quad_perm xor 2 and xor 1 complete the sums.
+// The steps with the most pairs use the cheapest primitive (issue costs): bits 3 and 2 are also BANKS of a
+// DPP row (lanes 4i..4i+3), so "select, then add the partner's other register" is two DPP adds with complementary bank
+// masks (a bank-masked DPP write leaves the other lanes' destination alone: 2 x 1.85 ns per pair); a permlane swap +
+// add is 4.7 ns per pair and is left for the two steps with 2 and 1 pairs. Round 3 had the order bit 5, 4, 3, 2
+// (5 + 3 swaps): 50.5 ns of issue per splat, this order 47.4.
+// On return lane L holds the wave total of component  c = b3 + 2 b2 + 4 b5 + 8 b4  (b_k = bit k of L; c < 10 valid).
 __device__ __forceinline__ float add_swap32(float a, float b) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -589,33 +592,37 @@ __device__ __forceinline__ float add_swap16(float a, float b) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float reduce10(const float v[10], int lane) {
-  const float c01 = add_swap32(v[0], v[1]);
-  const float c23 = add_swap32(v[2], v[3]);
-  const float c45 = add_swap32(v[4], v[5]);
-  const float c67 = add_swap32(v[6], v[7]);
-  const float c89 = add_swap32(v[8], v[9]);
-  const float A = add_swap16(c01, c23), B = add_swap16(c45, c67), C = add_swap16(c89, 0.f);
-  // 3 -> 2 -> 1 registers inside the 16-lane rows. Which register a lane keeps depends on a lane bit that is also a
-  // BANK of the row (lanes 4i..4i+3), so the "select, then add the partner's other register" of each step is two DPP adds
-  // with complementary bank masks (a bank-masked DPP write leaves the other lanes' destination alone) instead of two
-  // v_cndmask + one DPP add:   lanes 0-7 of a row: AB = A + A[lane ^ 8];  lanes 8-15: AB = B + B[lane ^ 8]
-  //                            lanes with bit 2 clear: R = AB + AB[lane ^ 7];  set: R = Cp + Cp[lane ^ 7]
-  // (s_nop 1: the inputs come straight from VALU instructions and a DPP operand needs two wait states after its producer;
+  // (s_nop: the inputs come straight from VALU instructions and a DPP operand needs two wait states after its producer;
   //  the hazard recognizer does not look inside an asm block)
-  float AB, Cp, R;
+  float p0, p1, p2, p3, p4, q0, q1, q2;
   asm("s_nop 1\n\t"
-      "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-      "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-      "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_add_f32_dpp %2, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-      "v_add_f32_dpp %2, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %1, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %2, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %2, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %3, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %4, %16, %16 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %4, %17, %17 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
       "s_nop 1\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %6, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %6, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %7, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf"
+      : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(q0), "=&v"(q1), "=&v"(q2)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]));
+  // q0: components b3 + 2 b2, q1: 4 + b3 + 2 b2, q2: 8 + b3 (in all lanes: its pair partner is the pad)
+  const float r0 = add_swap32(q0, q1);      // lanes 0-31: q0 (components b3 + 2 b2), lanes 32-63: q1 (4 + ...)
+  const float r1 = add_swap32(q2, 0.f);     // lanes 0-31: q2 (8 + b3 [+ 2 b2: pad]), lanes 32-63: zeros (pad)
+  float R = add_swap16(r0, r1);             // rows 0, 2: r0, rows 1, 3: r1
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-      : "=&v"(AB), "=&v"(Cp), "=&v"(R)
-      : "v"(A), "v"(B), "v"(C));
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "+v"(R));
   (void)lane;
   return R;
 }
@@ -721,10 +728,9 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
     R = rc0 * gC0 + rc1 * gC1 + rc2 * gC2 + rec_z * gD + rec_a * gA;
   }
 
-  // lane -> (component slot, scale) of the single atomic that commits a splat's 10 sums (see reduce10)
-  const int l16 = lane & 15, rr = lane >> 4;
-  const int comp = 4 * ((l16 & 4) ? 2 : ((l16 & 8) ? 1 : 0)) + (((rr & 1) << 1) | (rr >> 1));
-  const bool commit = (l16 == 0 || l16 == 4 || l16 == 8) && (comp < 10);
+  // one lane per quad commits with the single atomic of a splat's 10 sums; its component: bit 3 -> 1, bit 2 -> 2, bit 5 -> 4, bit 4 -> 8 (see reduce10)
+  const int comp = ((lane >> 3) & 1) | (((lane >> 2) & 1) << 1) | (((lane >> 5) & 1) << 2) | (((lane >> 4) & 1) << 3);
+  const bool commit = ((lane & 3) == 0) && (comp < 10);
   __syncthreads();
 
   for (int k = 0; k < kBatch / 64; ++k) {
