@@ -615,6 +615,9 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
       : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(q0), "=&v"(q1), "=&v"(q2)
       : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]));
   // q0: components b3 + 2 b2, q1: 4 + b3 + 2 b2, q2: 8 + b3 (in all lanes: its pair partner is the pad)
+  // (q2 has no partner register; letting it skip the bit-5 step and committing components 8 and 9 from BOTH halves of the
+  //  wave -- two lanes of the one atomic instruction adding to the same address -- doubled the kernel's time: 55 -> 102 us
+  //  per view. Same-address lanes inside one atomic instruction serialise; every lane of the commit has its own address.)
   const float r0 = add_swap32(q0, q1);      // lanes 0-31: q0 (components b3 + 2 b2), lanes 32-63: q1 (4 + ...)
   const float r1 = add_swap32(q2, 0.f);     // lanes 0-31: q2 (8 + b3 [+ 2 b2: pad]), lanes 32-63: zeros (pad)
   float R = add_swap16(r0, r1);             // rows 0, 2: r0, rows 1, 3: r1
