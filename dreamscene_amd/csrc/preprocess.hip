@@ -990,6 +990,7 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
     px = p_xyz[3 * row]; py = p_xyz[3 * row + 1]; pz = p_xyz[3 * row + 2];
     const float4* pp = reinterpret_cast<const float4*>(partials + 12 * i);
     pa = pp[0]; pb = pp[1]; pc = pp[2];
+    pc.x += pc.z; pc.y += pc.w;      // (K7 commits the last two sums from the two halves of a wave: render.hip, reduce10)
   }
   const float S1 = pa.x, S2 = pa.y, S3 = pa.z, S4 = pa.w, S5 = pb.x, gop = pb.y;
   float gndx = 0.f, gndy = 0.f;
@@ -1480,9 +1481,10 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
             if (r[u][t] > 0) {
               const float4* pp = reinterpret_cast<const float4*>(vb.partials[v0 + u] + 12 * (chunk_base(4 * t + wave) + lane));
               const float4 pa = pp[0], pb = pp[1];
-              const float2 pc = *reinterpret_cast<const float2*>(vb.partials[v0 + u] + 12 * (chunk_base(4 * t + wave) + lane) + 8);
+              const float4 pc = pp[2];
               reached[t] = reached[t] || (pa.x != 0.f) || (pa.y != 0.f) || (pa.z != 0.f) || (pa.w != 0.f) || (pb.x != 0.f) ||
-                           (pb.y != 0.f) || (pb.z != 0.f) || (pb.w != 0.f) || (pc.x != 0.f) || (pc.y != 0.f);
+                           (pb.y != 0.f) || (pb.z != 0.f) || (pb.w != 0.f) || (pc.x != 0.f) || (pc.y != 0.f) ||
+                           (pc.z != 0.f) || (pc.w != 0.f);
             }
           }
         }
@@ -1660,6 +1662,7 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
         if (take) { pa = pp[0]; pb = pp[1]; pc = pp[2]; }
       }
       if (!take) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; pc = pa; }
+      pc.x += pc.z; pc.y += pc.w;      // (K7 commits the last two sums from the two halves of a wave: render.hip, reduce10)
       if (take && vb.restore) {                         // GsrGrads.scratch_clean: leave the scratch as it was found
         pp[0] = make_float4(0.f, 0.f, 0.f, 0.f); pp[1] = pp[0]; pp[2] = pp[0];
       }
@@ -1877,7 +1880,9 @@ k_preprocess_bwd_views_scene(const GsrView v, const SceneTab sc, const SceneGrad
       const int D = vd.sh_degree;
       const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
       const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
-      const float4 pa = pp[0], pb = pp[1], pc = pp[2];
+      const float4 pa = pp[0], pb = pp[1];
+      float4 pc = pp[2];
+      pc.x += pc.z; pc.y += pc.w;      // (see k_preprocess_bwd)
       gop += pb.y;
       const float grgb[3] = {pb.z, pb.w, pc.x};
       // (1) colour -> SH coefficients (through this view's noise), view direction

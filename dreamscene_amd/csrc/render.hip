@@ -582,7 +582,8 @@ render_fwd_tile_body(const uint32_t item, const int W, const int H, const uint32
 // masks (a bank-masked DPP write leaves the other lanes' destination alone: 2 x 1.85 ns per pair); a permlane swap +
 // add is 4.7 ns per pair and is left for the two steps with 2 and 1 pairs. Round 3 had the order bit 5, 4, 3, 2
 // (5 + 3 swaps): 50.5 ns of issue per splat, this order 47.4.
-// On return lane L holds the wave total of component  c = b3 + 2 b2 + 4 b5 + 8 b4  (b_k = bit k of L; c < 10 valid).
+// On return lane L (b_k = bit k of L) holds, in rows 0 and 2 (b4 = 0), the wave total of component b3 + 2 b2 + 4 b5; in row 1
+// the total over lanes 0-31 of component 8 + b3 and in row 3 the total over lanes 32-63 of the same (word 10 + b3).
 __device__ __forceinline__ float add_swap32(float a, float b) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -615,12 +616,12 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
       : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(q0), "=&v"(q1), "=&v"(q2)
       : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]));
   // q0: components b3 + 2 b2, q1: 4 + b3 + 2 b2, q2: 8 + b3 (in all lanes: its pair partner is the pad)
-  // (q2 has no partner register; letting it skip the bit-5 step and committing components 8 and 9 from BOTH halves of the
-  //  wave -- two lanes of the one atomic instruction adding to the same address -- doubled the kernel's time: 55 -> 102 us
-  //  per view. Same-address lanes inside one atomic instruction serialise; every lane of the commit has its own address.)
   const float r0 = add_swap32(q0, q1);      // lanes 0-31: q0 (components b3 + 2 b2), lanes 32-63: q1 (4 + ...)
-  const float r1 = add_swap32(q2, 0.f);     // lanes 0-31: q2 (8 + b3 [+ 2 b2: pad]), lanes 32-63: zeros (pad)
-  float R = add_swap16(r0, r1);             // rows 0, 2: r0, rows 1, 3: r1
+  // q2 has no partner register: it skips the bit-5 step (a swap with a zero register, an add) and is committed from BOTH
+  // halves of the wave into DIFFERENT words of the 12-float row -- row 1 adds its half's sums of components 8, 9 to words
+  // 8, 9, row 3 to words 10, 11, K8 adds the two. (Into the same words it would be two lanes of one atomic instruction on
+  // one address, and those serialise: 55 -> 102 us per view.)
+  float R = add_swap16(r0, q2);             // rows 0, 2: r0 (complete), rows 1, 3: q2 summed over rows {0,1} / {2,3}
   asm("s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\t"
@@ -632,7 +633,8 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 
 // Accumulates into partials [P,12], with q = dL/dG * G per (pixel, splat), d = centre - pixel and (u, v) = -Sigma^-1 d =
 // (-(A dx + B dy), -(C dy + B dx)) (Sigma^-1 = the conic):
-//   (sum q u, sum q v, sum q u^2, sum q u v, sum q v^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -)
+//   (sum q u, sum q v, sum q u^2, sum q u v, sum q v^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, dL/db', dL/ddepth')
+// (the last two pairs: the sums over the lower / upper half of a wave, added by K8 -- see reduce10)
 // dG/dd = G (u, v), so the first two sums are dL/d(pixel centre), and dL/dSigma = 1/2 sum q (Sigma^-1 d)(Sigma^-1 d)^T, so
 // the other three are the gradient of the 2-D covariance itself (K8 only scales them) -- both formed PER PIXEL, as the
 // scalar oracle does (gsr_oracle.c, orc_pixel_bwd; SEMANTICS.md section 5). Rounds 1-2 summed the raw moments of d
@@ -732,8 +734,9 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   }
 
   // one lane per quad commits with the single atomic of a splat's 10 sums; its component: bit 3 -> 1, bit 2 -> 2, bit 5 -> 4, bit 4 -> 8 (see reduce10)
-  const int comp = ((lane >> 3) & 1) | (((lane >> 2) & 1) << 1) | (((lane >> 5) & 1) << 2) | (((lane >> 4) & 1) << 3);
-  const bool commit = ((lane & 3) == 0) && (comp < 10);
+  const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+  const int comp = b4 ? 8 + 2 * b5 + b3 : (b3 | (b2 << 1) | (b5 << 2));      // word of the 12-float row (see reduce10)
+  const bool commit = ((lane & 3) == 0) && !(b4 && b2);                      // 8 + 4 lanes, twelve different words
   __syncthreads();
 
   for (int k = 0; k < kBatch / 64; ++k) {
