@@ -99,8 +99,11 @@ def test_hip_replays_the_record(built_lib, c_oracle, name):
     _close(img, c["out"]["image"], "image")
     _close(da, c["out"]["depth_alpha"], "depth_alpha")
     assert float(np.abs(up_da).max()) > 1e4            # the spike of the disp normalisation is in the record
+    # With the upstream as recorded the disp normalisation puts |dL/d(depth, alpha)| = 7e4 on two pixels (<= 1 elsewhere): an
+    # fp32 backward carries eps x 7e4 of absolute noise on every Gaussian those pixels composite, and the ORDER of K7's
+    # atomics moves it from run to run (observed 1e-5 .. 1.02e-4 of max|ref| on dL/dopacity over the rounds' runs): 3e-4.
     for k, ref in c["grads"].items():
-        _close(got[k].reshape(ref.shape), ref, k + " (upstream as recorded)", tol=1e-4)
+        _close(got[k].reshape(ref.shape), ref, k + " (upstream as recorded)", tol=3e-4)
     # the same record with the spike pixels clipped: the usual bar
     cl_img, cl_da = np.clip(up_img, -50.0, 50.0), np.clip(up_da, -50.0, 50.0)
     _, _, _, got = _hip_replay(c, cl_img, cl_da)
