@@ -247,11 +247,11 @@ __device__ __forceinline__ uint32_t stage_mask(const float4& s2row) { return __f
 // Forward compositing, "list-parallel lanes": FOUR lanes share a pixel and take four consecutive candidates of
 // the list per step:
 //   * work item = one 8x8 pixel quarter of a 16x16 tile, handled by a 256-thread workgroup; wave = 4x4 pixels;
-//     lane = (pixel = lane>>2, slot = lane&3);
+//     lane = 16 (pixel row) + 4 slot + pixel column;
 //   * each lane evaluates alpha of "its" candidate; the transmittance in front of it is T * (exclusive product
-//     of the earlier slots' (1-alpha)) -- a 2-step quad scan on DPP quad_perm, no LDS; the T < 1e-4 stop is an
-//     OR-scan over the quad; the new T is the quad-min of the survivors' T(1-alpha);
-//   * colour / depth / alpha partial sums stay per lane and are folded over the quad once, at the end.
+//     of the earlier slots' (1-alpha)) -- three bank-masked DPP multiplies (row_shr:4), no LDS; the T < 1e-4 stop is one
+//     comparison per lane; the new T is the minimum over the slots of the survivors' T(1-alpha) (row_ror:4, :8);
+//   * colour / depth / alpha partial sums stay per lane and are folded over the slots once, at the end.
 // 4x more (and 4x finer) work items, tighter 4x4 culling; same gates in the same list order on the same bits (the
 // transmittance is multiplied up in list order inside the quad; only the colour / depth / alpha SUMS associate
 // differently from a sequential loop, at the 1e-7 level).
@@ -274,7 +274,10 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   }
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int slot = lane & 3, pl = lane >> 2;
+  // lane = 16 (pixel row) + 4 slot + (pixel column): the slots of a pixel are the four BANKS of a DPP row, so a step of the
+  // transmittance scan is one bank-masked v_mul_f32_dpp row_shr:4 (lanes of the other banks keep their value) instead of a
+  // quad_perm multiply plus a select
+  const int slot = (lane >> 2) & 3, pcol = lane & 3, prow = lane >> 4;
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
   {
     // Workgroup b takes item b of the heaviest-first work list: the hardware dispatcher hands workgroups out in
@@ -283,7 +286,7 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
     const int quarter = (int)(item & 3u);
     const int ty = (int)tile / gx, tx = (int)tile - ty * gx;
     const int q_x0 = tx * GSR_TILE + (quarter & 1) * 8, q_y0 = ty * GSR_TILE + (quarter >> 1) * 8;
-    const int px = q_x0 + (wave & 1) * 4 + (pl & 3), py = q_y0 + (wave >> 1) * 4 + (pl >> 2);
+    const int px = q_x0 + (wave & 1) * 4 + pcol, py = q_y0 + (wave >> 1) * 4 + prow;
     const bool inside = (px < W) && (py < H);
     const float pxf = (float)px, pyf = (float)py;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
@@ -329,12 +332,12 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       if (base != r0) {
         // checkpoint of the per-pixel prefix state at this batch boundary: lets the backward start a traversal
         // at any multiple of 256 list entries (k_render_bwd splits deep tiles into independent segments)
-        float f0 = C0, f1 = C1, f2 = C2, f3 = Dp, f4 = Wt;       // quad folds: all lanes take part
-        f0 += gsr_dpp<0xB1>(f0); f0 += gsr_dpp<0x4E>(f0);
-        f1 += gsr_dpp<0xB1>(f1); f1 += gsr_dpp<0x4E>(f1);
-        f2 += gsr_dpp<0xB1>(f2); f2 += gsr_dpp<0x4E>(f2);
-        f3 += gsr_dpp<0xB1>(f3); f3 += gsr_dpp<0x4E>(f3);
-        f4 += gsr_dpp<0xB1>(f4); f4 += gsr_dpp<0x4E>(f4);
+        float f0 = C0, f1 = C1, f2 = C2, f3 = Dp, f4 = Wt;       // folds over the slots (row_ror:4, :8): all lanes take part
+        f0 += gsr_dpp<0x124>(f0); f0 += gsr_dpp<0x128>(f0);
+        f1 += gsr_dpp<0x124>(f1); f1 += gsr_dpp<0x128>(f1);
+        f2 += gsr_dpp<0x124>(f2); f2 += gsr_dpp<0x128>(f2);
+        f3 += gsr_dpp<0x124>(f3); f3 += gsr_dpp<0x128>(f3);
+        f4 += gsr_dpp<0x124>(f4); f4 += gsr_dpp<0x128>(f4);
         if (slot == 0 && inside) {
           // slot = absolute list position / 256: boundaries of one list are 256 apart and the first boundary of
           // a tile lies >= 256 entries after the end of the previous tile's list, so slots never collide
@@ -382,72 +385,76 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
           // T < 1e-4 stop is a hard gate: SEMANTICS.md section 4). Three dependent quad steps: after step k slot k is final.
           const float fgate = g ? gsr_sub(1.0f, alpha) : 1.0f;
           float test_T = gsr_mul(T, fgate);
-          {
-            const float t1 = gsr_dpp<0x90>(test_T);      // quad_perm [0,0,1,2]: value of slot-1
-            test_T = (slot >= 1) ? gsr_mul(t1, fgate) : test_T;
-            const float t2 = gsr_dpp<0x90>(test_T);
-            test_T = (slot >= 2) ? gsr_mul(t2, fgate) : test_T;
-            const float t3 = gsr_dpp<0x90>(test_T);
-            test_T = (slot >= 3) ? gsr_mul(t3, fgate) : test_T;
-          }
-          const float Tprev = gsr_dpp<0x90>(test_T);
-          const float T_before = (slot >= 1) ? Tprev : T;
+          // (each step: the lanes of slots >= k take test_T of slot - 1 times their own factor; s_nop: a DPP operand needs two
+          //  wait states after its producer and the hazard recognizer does not look inside an asm block)
+          asm("s_nop 1\n\t"
+              "v_mul_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+              "s_nop 1\n\t"
+              "v_mul_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xc\n\t"
+              "s_nop 1\n\t"
+              "v_mul_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0x8"
+              : "+v"(test_T) : "v"(fgate));
+          // alpha times the transmittance in FRONT of the slot: T for slot 0, test_T of slot - 1 for the others
+          float w_all = alpha * T;
+          asm("s_nop 1\n\t"
+              "v_mul_f32_dpp %0, %1, %2 row_shr:4 row_mask:0xf bank_mask:0xe"
+              : "+v"(w_all) : "v"(test_T), "v"(alpha));
           // The first slot (in list order) whose own contribution would drop T below the threshold stops the pixel, it
           // and everything behind it. A pixel still in play holds T >= 1e-4 and the slots' test_T only decrease along the
           // list (factors <= 1, one rounding each), so "a gated slot <= mine fell below the threshold" IS "my test_T is
           // below it": no scan over the quad, and the quad's stop flag is slot 3's comparison.
           const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < GSR_T_MIN);
           const bool hit = __builtin_amdgcn_inverse_ballot_w64(gm & ~stopm);
-          const float w = hit ? alpha * T_before : 0.0f;
+          const float w = hit ? w_all : 0.0f;
           C0 = fmaf(b.w, w, C0); C1 = fmaf(c.x, w, C1); C2 = fmaf(c.y, w, C2);
           Dp = fmaf(b.z, w, Dp);
           Wt += w;
           last = hit ? ((base - r0) + (uint32_t)j + 1u) : last;
           if constexpr (SCORE) {
             // the pixels of the wave that composite slot s's splat: the 16 lanes holding this slot
-            const unsigned long long hm = __ballot(hit) & (0x1111111111111111ull << slot);
+            const unsigned long long hm = __ballot(hit) & (0x000F000F000F000Full << (4 * slot));
             if (score_mode != 1) {
               // weight = opacity per contributing (pixel, splat): the kernel counts the pixels -- integer atomics, exact and
               // independent of the order -- and k_score_finalize multiplies by the opacity once (mode 0) or the caller does
               // (mode 2: raw counts, summed over many views first). A float sum of thousands of EQUAL increments rounds the
               // same way every time (measured 6e-5 relative on the sum over 48 views).
-              if (hm != 0ull && lane == slot)
+              if (hm != 0ull && lane == 4 * slot)
                 atomicAdd(reinterpret_cast<uint32_t*>(score) + st.sid[buf][j & (kBatch - 1)], (uint32_t)__popcll(hm));
             } else {
-              float ws = w;                               // sum over the lanes sharing the slot: xor 4,8,16,32
-              ws += gsr_dpp<0x124>(ws);                   // row_ror:4
-              ws += gsr_dpp<0x128>(ws);                   // row_ror:8
+              float ws = w;                               // sum over the lanes sharing the slot: xor 1, 2, 16, 32
+              ws += gsr_dpp<0xB1>(ws);                    // quad_perm [1,0,3,2]
+              ws += gsr_dpp<0x4E>(ws);                    // quad_perm [2,3,0,1]
               ws += __shfl_xor(ws, 16, 64);
               ws += __shfl_xor(ws, 32, 64);
-              if (hm != 0ull && lane == slot) unsafeAtomicAdd(score + st.sid[buf][j & (kBatch - 1)], ws);
+              if (hm != 0ull && lane == 4 * slot) unsafeAtomicAdd(score + st.sid[buf][j & (kBatch - 1)], ws);
             }
           }
           // T after the quad: the survivors' T(1-alpha) only decrease along the list -> quad minimum (T >= 1e-4 > 0:
           // the order of positive floats is the order of their bit patterns, and v_min_u32 takes a DPP operand)
           uint32_t tn = __float_as_uint(hit ? test_T : T);
-          tn = min(tn, (uint32_t)gsr_dpp_i<0xB1>((int)tn));   // quad_perm [1,0,3,2]
-          tn = min(tn, (uint32_t)gsr_dpp_i<0x4E>((int)tn));   // quad_perm [2,3,0,1]
+          tn = min(tn, (uint32_t)gsr_dpp_i<0x124>((int)tn));   // row_ror:4
+          tn = min(tn, (uint32_t)gsr_dpp_i<0x128>((int)tn));   // row_ror:8
           T = __uint_as_float(tn);
           // slot 3's flag -> all four lanes of its quad. On the SCALAR unit: its instructions issue beside the vector
           // instructions of the other waves (removing 22 of them from this loop changed nothing: A/B in one gpurun call,
           // 44.0 vs 45.0 us per view -- the loop is bound by its ~50 vector instructions), so mask arithmetic belongs there
-          unsigned long long quad_stop = (stopm >> 3) & 0x1111111111111111ull;
-          quad_stop |= quad_stop << 1;
-          quad_stop |= quad_stop << 2;
+          unsigned long long quad_stop = (stopm >> 12) & 0x000F000F000F000Full;
+          quad_stop |= quad_stop << 4;
+          quad_stop |= quad_stop << 8;
           donem |= quad_stop;
         }
       }
     }
     // fold the four slots of each pixel
-    C0 += gsr_dpp<0xB1>(C0); C0 += gsr_dpp<0x4E>(C0);
-    C1 += gsr_dpp<0xB1>(C1); C1 += gsr_dpp<0x4E>(C1);
-    C2 += gsr_dpp<0xB1>(C2); C2 += gsr_dpp<0x4E>(C2);
-    Dp += gsr_dpp<0xB1>(Dp); Dp += gsr_dpp<0x4E>(Dp);
-    Wt += gsr_dpp<0xB1>(Wt); Wt += gsr_dpp<0x4E>(Wt);
+    C0 += gsr_dpp<0x124>(C0); C0 += gsr_dpp<0x128>(C0);
+    C1 += gsr_dpp<0x124>(C1); C1 += gsr_dpp<0x128>(C1);
+    C2 += gsr_dpp<0x124>(C2); C2 += gsr_dpp<0x128>(C2);
+    Dp += gsr_dpp<0x124>(Dp); Dp += gsr_dpp<0x128>(Dp);
+    Wt += gsr_dpp<0x124>(Wt); Wt += gsr_dpp<0x128>(Wt);
     {
       int l = (int)last;
-      l = max(l, gsr_dpp_i<0xB1>(l));
-      l = max(l, gsr_dpp_i<0x4E>(l));
+      l = max(l, gsr_dpp_i<0x124>(l));
+      l = max(l, gsr_dpp_i<0x128>(l));
       last = (uint32_t)l;
     }
     if (inside && slot == 0) {
