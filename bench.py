@@ -43,8 +43,10 @@ SIMDS = 1024            # 256 CUs x 4 SIMDs
 # every DPP or SGPR-operand form 1.85; v_exp / v_rcp / v_permlane*_swap 3.5; an SALU instruction 0.8 (it shares the issue port)
 ISSUE_NS = {"plain": 1.22, "other": 1.85, "trans": 3.5, "salu": 0.8}
 # static mix of the VALU instructions of the compositing loops (by class, from the ISA of render.hip's hot loops)
-VALU_MIX = {"render_bwd": {"plain": 0.67, "other": 0.23, "trans": 0.10},
-            "render_fwd": {"plain": 0.49, "other": 0.51, "trans": 0.0}}
+# (K7 per (8x8 block, splat): ~86 instructions, of which 18 DPP adds, 3 compares, min, rndne, cvt, ldexp = "other", the
+#  reciprocal and 2 permlane swaps = "trans"; K6 per step: ~49, of which 6 DPP, 4 compares, 4 selects, min, rndne, cvt, ldexp)
+VALU_MIX = {"render_bwd": {"plain": 0.665, "other": 0.30, "trans": 0.035},
+            "render_fwd": {"plain": 0.61, "other": 0.39, "trans": 0.0}}
 # stage -> the kernel whose launches the stage timer brackets (for the counters in profiles/traffic.json)
 STAGE_KERNEL = {"preprocess": "k_preprocess", "preprocess_bwd": "k_preprocess_bwd", "render_fwd": "k_render_fwd",
                 "render_bwd": "k_render_bwd", "duplicate": "k_emit"}
