@@ -192,6 +192,16 @@ __device__ __forceinline__ uint32_t rect_y0(uint32_t r) { return (r >> 8) & 255u
 __device__ __forceinline__ uint32_t rect_w(uint32_t r) { return ((r >> 16) & 255u) + 1u; }
 __device__ __forceinline__ uint32_t rect_h(uint32_t r) { return (r >> 24) + 1u; }
 
+// Workgroup b of a 1-D grid runs on XCD b % 8 (each XCD has its own L2). Neighbouring blocks -- runs of one column here,
+// runs of 64 depth-ordered Gaussians in k_emit_cols -- write neighbouring list positions, i.e. they share the cache lines at
+// their seams; on different XCDs each L2 holds its part of such a line and writes it back partially (a read-modify-write
+// at the memory: k_emit_cols moved 177 MB for 49 MB of pairs). So logical block ids are dealt in CONTIGUOUS ranges per XCD:
+// raw index b -> (b % 8) * ceil(n / 8) + b / 8 for the n blocks in use (the grid is rounded up to a multiple of 8).
+__device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n) {
+  const uint32_t per = (n + 7u) / 8u, j = b >> 3, id = (b & 7u) * per + j;
+  return (j < per && id < n) ? id : 0xFFFFFFFFu;
+}
+
 // Per run of 64 depth-ordered Gaussians (one wave): pairs per tile column -> hist1[tx][run]; also the rectangles in
 // depth order.
 __global__ void __launch_bounds__(256)
@@ -206,8 +216,13 @@ k_col_hist(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sort
   for (int w = 0; w < 4; ++w) bins[w][tid] = 0;
   __syncthreads();
   uint32_t* mybins = bins[wave];
-  const int64_t s = (int64_t)blockIdx.x * 256 + tid;
-  const bool in = s < (int64_t)*n_vis;
+  // (blocks dealt to the XCDs in contiguous ranges, see xcd_chunked: the four runs of a block are 16 bytes of every column's
+  //  row of hist1, neighbouring blocks share those lines)
+  const int64_t nv = (int64_t)*n_vis;
+  const uint32_t blk = xcd_chunked(blockIdx.x, (uint32_t)((nv + 255) / 256));
+  if (blk == 0xFFFFFFFFu) return;
+  const int64_t s = (int64_t)blk * 256 + tid;
+  const bool in = s < nv;
   uint32_t r = 0, w = 0, h = 0, x0 = 0;
   if (in) {
     r = rects[sorted_idx[s]];
@@ -229,8 +244,8 @@ k_col_hist(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sort
   if (tid < gx) {
 #pragma unroll
     for (int w2 = 0; w2 < 4; ++w2) {
-      const uint32_t run = blockIdx.x * 4 + w2;
-      if (run < nrun && (int64_t)run * kColRun < (int64_t)*n_vis) hist1[(uint64_t)tid * nrun + run] = bins[w2][tid];
+      const uint32_t run = blk * 4 + w2;
+      if (run < nrun && (int64_t)run * kColRun < nv) hist1[(uint64_t)tid * nrun + run] = bins[w2][tid];
     }
   }
 }
@@ -261,16 +276,6 @@ k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restr
     *n_pairs = n;
     if (n_pairs_all) n_pairs_all[blockIdx.y] = n;   // batched: the counts of all views side by side (one copy to the host)
   }
-}
-
-// Workgroup b of a 1-D grid runs on XCD b % 8 (each XCD has its own L2). Neighbouring blocks -- runs of one column here,
-// runs of 64 depth-ordered Gaussians in k_emit_cols -- write neighbouring list positions, i.e. they share the cache lines at
-// their seams; on different XCDs each L2 holds its part of such a line and writes it back partially (a read-modify-write
-// at the memory: k_emit_cols moved 177 MB for 49 MB of pairs). So logical block ids are dealt in CONTIGUOUS ranges per XCD:
-// raw index b -> (b % 8) * ceil(n / 8) + b / 8 for the n blocks in use (the grid is rounded up to a multiple of 8).
-__device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n) {
-  const uint32_t per = (n + 7u) / 8u, j = b >> 3, id = (b & 7u) * per + j;
-  return (j < per && id < n) ? id : 0xFFFFFFFFu;
 }
 
 // One wave per run of 64 depth-ordered Gaussians. Lanes enumerate the run's PAIRS (Gaussian-major, then row-major
@@ -606,7 +611,7 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
       uint32_t* rect_sorted = where ? s.k0 : s.k1;   // the key buffer the sort result is NOT in
       const uint32_t nrun = col_runs(P);
       const uint32_t nby = (uint32_t)batch;
-      hipLaunchKernelGGL(k_col_hist, dim3(nb, nby), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx, s.rects, rect_sorted,
+      hipLaunchKernelGGL(k_col_hist, dim3((nb + 7u) / 8u * 8u, nby), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx, s.rects, rect_sorted,
                          gx, nrun, s.hist1, bstride);
       hipLaunchKernelGGL(k_radix_scan, dim3(gx, nby), dim3(256), 0, stream, s.hist1, nrun, s.totals1,
                          (const uint64_t*)n_vis_dev, (uint32_t)kColRun, bstride);
