@@ -1404,15 +1404,16 @@ __device__ __forceinline__ void wave_zero_rows(float* __restrict__ dst, int n, u
   }
 }
 
-template <int KT, bool PVS, bool REACHED = false>   // PVS: per-view scales; REACHED: the sparse form described above
+template <int KT, bool PVS, bool REACHED = false, int KPER = 4>   // PVS: per-view scales; REACHED: the sparse form described above;
+// KPER: 256-Gaussian slices per workgroup of the REACHED form (4: 1 024 Gaussians, for grids that fill the chip once; 1: small P)
 // (two waves per SIMD = two workgroups per CU: one resident wave of workgroups at 500 k Gaussians. Without the attribute the
 //  allocator took 260 registers, one workgroup per CU, and the kernel ran its workgroups in two shifts: 88 -> 121 us)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, const GsrGrads out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int kPer = REACHED ? kK8Block / 256 : 1;        // Gaussians classified per thread
+  constexpr int kPer = REACHED ? KPER : 1;                  // Gaussians classified per thread
   __shared__ uint32_t wcnt[REACHED ? 4 * kPer : 1];
-  __shared__ uint16_t reached_list[REACHED ? kK8Block : 1];
+  __shared__ uint16_t reached_list[REACHED ? 256 * KPER : 1];
   __shared__ unsigned long long lmask[REACHED ? 4 * kPer : 1];   // reached Gaussians of the 64-row chunk (slice, wave)
   __shared__ unsigned long long vmask[REACHED ? GSR_MAX_BATCH_VIEWS : 1][REACHED ? 4 * kPer : 1];   // ... per view (K7's marks)
   __shared__ uint32_t zero_next;                                  // next chunk nobody has cleared yet
@@ -2218,17 +2219,23 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
   // (rows of 12 floats or fewer, K <= 4: skipping them saves less than the classification costs -- the 2 M indoor scene
   //  at K = 4 measured 36 us per view sparse, 33 dense -- so those keep the dense kernel)
   if (gsr_k8_sparse() && v.sh_stride >= 9) {
-    const uint32_t nbr = (uint32_t)(((int64_t)v.P + kK8Block - 1) / kK8Block);
-#define GSR_LAUNCH_K8SP(KT)                                                                                          \
-  if (vb.per_view_scales)                                                                                            \
-    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, true, true>), dim3(nbr), dim3(256), lds, stream, v, g, vb, out0); \
-  else                                                                                                               \
-    hipLaunchKernelGGL((k_preprocess_bwd_views<KT, false, true>), dim3(nbr), dim3(256), lds, stream, v, g, vb, out0)
+    // 1 024 Gaussians per workgroup when that still gives every CU its two workgroups (the form's occupancy), 256 otherwise
+    // (100 k Gaussians: 98 workgroups of 1 024 on 256 CUs took 51 us against 28 for 391 of 256)
+    const bool big = (int64_t)v.P >= (int64_t)400 * kK8Block;
+    const int64_t per_wg = big ? kK8Block : 256;
+    const uint32_t nbr = (uint32_t)(((int64_t)v.P + per_wg - 1) / per_wg);
+#define GSR_LAUNCH_K8SP1(KT, PVS_)                                                                                         \
+  if (big) hipLaunchKernelGGL((k_preprocess_bwd_views<KT, PVS_, true, kK8Block / 256>), dim3(nbr), dim3(256), lds, stream, v, g, vb, out0); \
+  else hipLaunchKernelGGL((k_preprocess_bwd_views<KT, PVS_, true, 1>), dim3(nbr), dim3(256), lds, stream, v, g, vb, out0)
+#define GSR_LAUNCH_K8SP(KT)                                    \
+  if (vb.per_view_scales) { GSR_LAUNCH_K8SP1(KT, true); }      \
+  else { GSR_LAUNCH_K8SP1(KT, false); }
     switch (v.sh_stride) {
       case 16: GSR_LAUNCH_K8SP(16); break;
       case 9: GSR_LAUNCH_K8SP(9); break;
       default: return GSR_EINVAL;
     }
+#undef GSR_LAUNCH_K8SP1
 #undef GSR_LAUNCH_K8SP
     GSR_HIP(hipGetLastError());
     return GSR_OK;
