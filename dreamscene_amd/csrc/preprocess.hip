@@ -2219,9 +2219,10 @@ int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const Gsr
   // (rows of 12 floats or fewer, K <= 4: skipping them saves less than the classification costs -- the 2 M indoor scene
   //  at K = 4 measured 36 us per view sparse, 33 dense -- so those keep the dense kernel)
   if (gsr_k8_sparse() && v.sh_stride >= 9) {
-    // 1 024 Gaussians per workgroup when that still gives every CU its two workgroups (the form's occupancy), 256 otherwise
-    // (100 k Gaussians: 98 workgroups of 1 024 on 256 CUs took 51 us against 28 for 391 of 256)
-    const bool big = (int64_t)v.P >= (int64_t)400 * kK8Block;
+    // 1 024 Gaussians per workgroup when that gives every CU a workgroup, 256 otherwise (the form holds two workgroups per
+    // CU: 512 slots. 100 k Gaussians: 98 workgroups of 1 024 took 51 us against 26 for 391 of 256 in one shift; from
+    // ~260 k on the small workgroups need two shifts and the large ones win)
+    const bool big = (int64_t)v.P >= (int64_t)256 * kK8Block;
     const int64_t per_wg = big ? kK8Block : 256;
     const uint32_t nbr = (uint32_t)(((int64_t)v.P + per_wg - 1) / per_wg);
 #define GSR_LAUNCH_K8SP1(KT, PVS_)                                                                                         \
