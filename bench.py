@@ -70,6 +70,32 @@ def algorithmic_bytes(stage: str, P: int, N: int, HW: int, K: int, D: int, views
     }[stage]
 
 
+def self_launch_cmd(n_gpus: int, argv, port: int):
+    """The command `python bench.py --gpus N ...` turns itself into when no launcher set up the ranks: the same line the
+    task contract says the driver uses (one process per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus: int, argv) -> None:
+    import socket
+    share = os.environ.get("GSR_BENCH_SHARE_GPU", "0") == "1"
+    n_dev = torch.cuda.device_count()
+    if not share and n_dev < n_gpus:
+        raise SystemExit(f"bench.py --gpus {n_gpus}: this node exposes {n_dev} GPU(s); one rank per GPU is the only "
+                         "measurement configuration (GSR_BENCH_BACKEND=gloo GSR_BENCH_SHARE_GPU=1 runs the ranks on one "
+                         "device for functional tests)")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    os.execve(sys.executable, self_launch_cmd(n_gpus, argv, port), env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,9 +109,11 @@ def main():
     ap.add_argument("--init-opacity", action="store_true",
                     help="object scene in the reference's initial state: every Gaussian at opacity 0.1 "
                          "(gs_renderer.py:598; ~87 layers blend before T < 1e-4 stops a pixel)")
-    ap.add_argument("--exchange", choices=["dense", "auto", "rows", "sparse_rs", "direct"], default="dense",
+    ap.add_argument("--exchange", choices=["measure", "dense", "auto", "rows", "sparse_rs", "direct"], default="measure",
                     help="wire format of the multi-GPU gradient exchange (multiview.GradExchange); dense = one in-place "
-                         "all-reduce of the active columns, the only format that needs no host read")
+                         "all-reduce of the active columns, the only format that needs no host read; measure (default) = "
+                         "after the warm-up time dense / direct / sparse_rs for a few steps each and keep the fastest "
+                         "(every rank takes the same decision); with one rank there is nothing to exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the drop-in measurement after the timed region (profiling runs: keeps the per-kernel "
@@ -98,6 +126,12 @@ def main():
                     help="then: a run that renders 4 NEW cameras (of 64 sampled like the reference's random cameras) every "
                          "step and applies a fused Adam update in between, for at least this long -> `rotating_cameras` "
                          "(0 = skip)")
+    ap.add_argument("--train-seconds", type=float, default=1.2,
+                    help="then: `training_like` (what object_render(test=False) hands the rasterizer: fresh scale noise per "
+                         "view = scales [V,P,3], SH degree 0 with probability 0.1, random / black background with probability "
+                         "0.5; scene_gaussian.py:938-947, 1004-1008, config.py:20-23), `init_state` (every opacity 0.1, "
+                         "gs_renderer.py:598) and `forward_only` (video_inference, object_trainer.py:81-118), each for at "
+                         "least this long (0 = skip)")
     ap.add_argument("--fwd-mode", type=int, default=None, help="force the forward compositing variant (0 / 1)")
     ap.add_argument("--capture", choices=["auto", "on", "off"], default="auto",
                     help="batched call: replay the step's launches from captured hipGraphs (graph.CapturedViews: 2 graph "
@@ -108,9 +142,19 @@ def main():
     ap.add_argument("--unbatched", action="store_true",
                     help="render the views of a step one call at a time (GaussianRasterizer) instead of through "
                          "GaussianRasterizerViews (same kernels; the depth sorts of all views share their launches)")
+    ap.add_argument("--exchange-probe-steps", type=int, default=12,
+                    help="--exchange measure: timed steps per wire format after the warm-up")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU under torch.distributed.run);
+        # under the driver's own `python -m torch.distributed.run ... bench.py --gpus N` the environment is already there
+        self_launch(args.gpus, sys.argv[1:])
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: measuring {world}",
+              file=sys.stderr, flush=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GSR_BENCH_BACKEND=gloo + GSR_BENCH_SHARE_GPU=1: every rank on cuda:0 with the gloo backend -- lets the whole
@@ -121,10 +165,12 @@ def main():
     dev = torch.device("cuda", 0 if share_gpu else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("GSR_BENCH_PG_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     torch.cuda.set_device(dev)
 
     def allreduce_scalars(vals, op):
@@ -164,7 +210,7 @@ def main():
     my_cams = [cams[(rank * V + j) % len(cams)] for j in range(V)]
     cam = my_cams[0]
     arena = multiview.GradArena(P, K, dev)
-    exchange = multiview.GradExchange(arena, sh_degree=D, mode=args.exchange)
+    exchange = multiview.GradExchange(arena, sh_degree=D, mode="dense" if args.exchange == "measure" else args.exchange)
     prof_holder = [None]       # the contexts below share one profile slot (set for the stage pass / the timed region)
 
     def ctx(accumulate):
@@ -193,7 +239,11 @@ def main():
         for c_ in contexts + [views_ctx]:
             c_.profile = p
 
+    skip_reduce = [False]
+
     def reduce_grads():
+        if skip_reduce[0]:
+            return
         if exchange is not None:
             exchange.reduce()
         else:
@@ -267,6 +317,40 @@ def main():
         use_capture[0] = rates[True] > rates[False]
         capture_probe = {"eager_views_per_s": round(rates[False], 1), "captured_views_per_s": round(rates[True], 1)}
     captured = bool(use_capture[0])
+
+    # ---- the exchange, measured then chosen (world > 1): `--exchange measure` times the step with each wire format and
+    # keeps the fastest; `rccl` = the plain in-place all-reduce of the REAL arena (236 P bytes at K = 16) on its own
+    exchange_probe, rccl = None, None
+    if world > 1:
+        rccl = measure_allreduce(arena, dev, backend, allreduce_scalars)
+        if args.exchange == "measure":
+            # gloo (functional tests on one device) stages device tensors through the host for dense / rows only
+            cands = ["dense", "direct", "sparse_rs"] if backend == "nccl" else ["dense", "rows"]
+            exchange_probe = {}
+            for fmt in cands:
+                ok = 1.0
+                try:
+                    exchange.mode = fmt
+                    for _ in range(3):
+                        step()
+                    sync()
+                    tp = time.perf_counter()
+                    for _ in range(args.exchange_probe_steps):
+                        step()
+                    sync()
+                    dt_f = (time.perf_counter() - tp) / args.exchange_probe_steps
+                except Exception as e:          # a format that fails on this stack is dropped on EVERY rank
+                    ok, dt_f = 0.0, float("inf")
+                    print(f"bench.py rank {rank}: exchange format {fmt} failed: {e!r}", file=sys.stderr, flush=True)
+                ok = allreduce_scalars([ok], dist.ReduceOp.MIN)[0]
+                dt_f = allreduce_scalars([dt_f if ok else 0.0], dist.ReduceOp.MAX)[0]
+                exchange_probe[fmt] = {"ms_per_step": round(dt_f * 1e3, 4), "last": dict(exchange.last)} if ok else \
+                    {"failed": True}
+            good = {f: v["ms_per_step"] for f, v in exchange_probe.items() if "ms_per_step" in v}
+            exchange.mode = min(good, key=good.get) if good else "dense"
+            for _ in range(2):
+                step()
+            sync()
     stage_ms = {}
     dominant = None
     if prof is not None:
@@ -375,28 +459,168 @@ def main():
                 params[n_].copy_(saved[n_])
         del saved, opt
 
+    # ---- what training really feeds the rasterizer: object_render(test=False) adds fresh noise to
+    # the activated scales of EVERY view (scene_gaussian.py:1004-1008, scale_aug_ratio = 1.0: config.py:23) => scales
+    # [V,P,3], cov3D per view in K1, one scale gradient per view in K8; act_SH = 0 with probability sh_deg_aug_ratio = 0.1
+    # (:938-941); background random or black with probability bg_aug_ratio = 0.5 (:943-947). Cameras: the 64 random ones.
+    # The noise is drawn inside the timed loop with torch, as the trainers do. Then the same plain step in the reference's
+    # INITIAL state (every opacity 0.1: gs_renderer.py:598 -- ~87 layers blend before a pixel stops), and forward-only
+    # rendering (video_inference, object_trainer.py:81-118: test=True views under no_grad).
+    training_like = init_state = forward_only = None
+    if args.train_seconds > 0 and args.scene == "object" and world == 1:
+        import random as _random
+        rng_t = np.random.default_rng(11)
+        pyrng = _random.Random(11)
+        cams_t = [synth.orbit_camera(float(rng_t.uniform(5.2, 5.5)), float(rng_t.uniform(60.0, 90.0)), 360.0 * i / 64.0,
+                                     float(rng_t.uniform(0.32, 0.60)), H, W) for i in range(64)]
+        white, black = t([1.0, 1.0, 1.0]), t([0.0, 0.0, 0.0])
+        cam_t = [(c, t(c.world_view_transform), t(c.full_proj_transform), t(c.camera_center)) for c in cams_t]
+
+        def train_settings(i):
+            out_ = []
+            for j in range(V):
+                c, vm_, pm_, cp_ = cam_t[(V * i + j) % 64]
+                bg_ = white
+                if pyrng.random() < 0.5:
+                    bg_ = torch.rand(3, device=dev) if pyrng.random() < 0.5 else black
+                out_.append(GaussianRasterizationSettings(
+                    image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=bg_, scale_modifier=1.0,
+                    viewmatrix=vm_, projmatrix=pm_, sh_degree=(0 if pyrng.random() < 0.1 else D), campos=cp_,
+                    prefiltered=False, score_flag=False))
+            return out_
+
+        def noisy_scales(shape):
+            sc = params["scales"].detach()
+            return torch.clamp(sc + torch.randn(shape, device=dev) * ((0.2 ** 0.5) * sc / 4), 0.0).requires_grad_(True)
+
+        tl_ctx = ctx(False)
+        tl_captured = CapturedViews(context=tl_ctx) if (captured and batched) else None
+
+        def step_train_batched(i):
+            sl = train_settings(i)
+            means2D = torch.zeros((V,) + tuple(params["means3D"].shape), device=dev, requires_grad=True)
+            sc = noisy_scales((V,) + tuple(params["scales"].shape))
+            if tl_captured is not None:
+                outs = tl_captured(sl, means3D=params["means3D"], means2D=means2D, opacities=params["opacities"],
+                                   shs=params["shs"], scales=sc, rotations=params["rotations"])
+            else:
+                outs = GaussianRasterizerViews(sl, context=tl_ctx)(
+                    means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
+                    opacities=params["opacities"], scales=sc, rotations=params["rotations"], cov3D_precomp=None)
+            torch.autograd.grad([t_ for (img, _, da) in outs for t_ in (img, da)], [means2D, sc], [gi, gda] * V)
+
+        def step_train_dropin(i):
+            sl = train_settings(i)
+            for j in range(V):
+                means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+                sc = noisy_scales(tuple(params["scales"].shape))
+                # (no arena here: exactly the unmodified trainers' call -- autograd receives every parameter gradient)
+                img, radii, da = GaussianRasterizer(raster_settings=sl[j])(
+                    means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
+                    opacities=params["opacities"], scales=sc, rotations=params["rotations"], cov3D_precomp=None)
+                torch.autograd.grad([img, da], [params["means3D"], params["shs"], params["opacities"], params["rotations"],
+                                                means2D, sc], [gi, gda])
+
+        def timed(fn, seconds, chunk=8, indexed=True):
+            for i in range(6):
+                fn(i) if indexed else fn()
+            sync()
+            n_, t_ = 0, time.perf_counter()
+            while time.perf_counter() - t_ < seconds:
+                for _ in range(chunk):
+                    fn(6 + n_) if indexed else fn()
+                    n_ += 1
+            sync()
+            return n_, time.perf_counter() - t_
+
+        set_profile(None)
+        tl = {}
+        if batched:
+            n_, dt_ = timed(step_train_batched, args.train_seconds)
+            tl.update(views_per_s=round(n_ * V / dt_, 3), steps=n_, seconds=round(dt_, 3),
+                      through="graph.CapturedViews" if tl_captured is not None else "views.GaussianRasterizerViews")
+        n_, dt_ = timed(step_train_dropin, args.train_seconds)
+        tl.update(dropin_views_per_s=round(n_ * V / dt_, 3), dropin_steps=n_,
+                  what="per-view scale noise (scales [V,P,3], drawn with torch inside the loop), SH degree 0 w.p. 0.1, "
+                       "random / black background w.p. 0.5, 64 random cameras, 4 new ones per step; batched: gradients to the "
+                       "noisy scales and means2D through autograd, the other parameter gradients summed in the arena; "
+                       "drop-in: the unmodified trainers' call, every gradient through autograd")
+        training_like = tl
+        # the reference's initial state: every opacity 0.1
+        held_op = params["opacities"].detach().clone()
+        with torch.no_grad():
+            params["opacities"].fill_(0.1)
+        n_, dt_ = timed(step, args.train_seconds, chunk=4, indexed=False)
+        init_state = {"views_per_s": round(n_ * V / dt_, 3), "steps": n_, "seconds": round(dt_, 3),
+                      "what": "the headline step with every opacity at 0.1 (gs_renderer.py:598)"}
+        if batched:
+            n_, dt_ = timed(step_train_batched, args.train_seconds, chunk=4)
+            init_state["training_like_views_per_s"] = round(n_ * V / dt_, 3)
+        with torch.no_grad():
+            params["opacities"].copy_(held_op)
+        del held_op
+        for _ in range(3):
+            step()
+        # forward only (video_inference): test=True views, no_grad
+        fo_rast = [GaussianRasterizer(raster_settings=s_) for s_ in settings_list]
+        fo_views = GaussianRasterizerViews(settings_list)
+
+        def fwd_dropin():
+            with torch.no_grad():
+                for r_ in fo_rast:
+                    r_(means3D=params["means3D"], means2D=None, shs=params["shs"], colors_precomp=None,
+                       opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"],
+                       cov3D_precomp=None)
+
+        def fwd_batched():
+            with torch.no_grad():
+                fo_views(means3D=params["means3D"], means2D=torch.empty((V, 0)), shs=params["shs"], colors_precomp=None,
+                         opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"],
+                         cov3D_precomp=None)
+
+        n_, dt_ = timed(fwd_dropin, args.train_seconds / 2, indexed=False)
+        forward_only = {"dropin_views_per_s": round(n_ * V / dt_, 3)}
+        if batched:
+            n_, dt_ = timed(fwd_batched, args.train_seconds / 2, indexed=False)
+            forward_only["batched_views_per_s"] = round(n_ * V / dt_, 3)
+        forward_only["what"] = "forward only under no_grad (video_inference, object_trainer.py:81-118): one GaussianRasterizer " \
+                               "call per view / the same views through one GaussianRasterizerViews call"
+
     # the drop-in figure: the same views through one GaussianRasterizer call per view (untimed w.r.t. `value`)
     dropin = None
     if batched and not args.no_dropin:
         set_profile(None)
-        n_drop = max(10, args.steps // 4)
         for _ in range(3):
             step_dropin()
         sync()
+        n_drop = 0
         td = time.perf_counter()
-        for _ in range(n_drop):
-            step_dropin()
+        while True:                   # >= max(10 steps, --sustain-seconds), like `sustained`
+            for _ in range(10):
+                step_dropin()
+            n_drop += 10
+            go = time.perf_counter() - td < args.sustain_seconds
+            if world > 1:
+                go = allreduce_scalars([1.0 if go else 0.0], dist.ReduceOp.MIN)[0] > 0.5
+            if not go:
+                break
         sync()
-        dropin = {"views_per_s": world * n_drop * V / (time.perf_counter() - td), "steps": n_drop}
+        dt_d = time.perf_counter() - td
+        if world > 1:
+            dt_d = allreduce_scalars([dt_d], dist.ReduceOp.MAX)[0]
+        dropin = {"views_per_s": world * n_drop * V / dt_d, "steps": n_drop, "seconds": round(dt_d, 3)}
 
     # what the exchange would have to move for this rank's step (the arena holds the sum over the step's V views)
     exch = None
     if exchange is not None:
+        skip_reduce[0] = True          # this rank's own step, before any exchange: the rows ITS views reached
         step()
+        skip_reduce[0] = False
         torch.cuda.synchronize(dev)
         nz = int(exchange.nonzero_rows().numel())
         exch = {"row_floats": exchange.row_floats, "dense_bytes": int(4 * exchange.row_floats * P),
-                "nonzero_row_frac": round(nz / max(P, 1), 4), "last": exchange.last or None}
+                "nonzero_row_frac": round(nz / max(P, 1), 4), "format": exchange.mode, "last": exchange.last or None,
+                "probe_ms_per_step": exchange_probe}
 
     N_pairs = None
     roofline = None
@@ -502,6 +726,10 @@ def main():
             "sustained_views_per_s": sustained["views_per_s"] if sustained else None,
             "sustained": sustained,
             "rotating_cameras": rotating,
+            "training_like": training_like,
+            "init_views_per_s": init_state["views_per_s"] if init_state else None,
+            "init_state": init_state,
+            "forward_only": forward_only,
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 4),
             "host_wait_ms_per_step": round(host_wait_s / args.steps * 1e3, 4),
             "host_busy_ms_per_step": round((host_enqueue_s - host_wait_s) / args.steps * 1e3, 4),
@@ -517,21 +745,47 @@ def main():
                        "capture_mode": cap_mode, "capture_probe": capture_probe,
                        "capture_stats": dict(rast_captured.stats) if captured else None,
                        "dropin": ("`dropin_views_per_s`: the same views through one GaussianRasterizer call per view (the "
-                                  f"reference's interface), {dropin['steps']} steps after the timed region") if dropin else
+                                  f"reference's interface), {dropin['steps']} steps / {dropin['seconds']} s after the timed region") if dropin else
                                  ("not measured (--no-dropin)" if batched else
                                   "`value` IS the drop-in figure (one GaussianRasterizer call per view)"),
                        "parallelism": f"{V} view(s)/GPU/step x {world} GPUs, gradients summed on the device, then 1 RCCL "
-                                      f"gradient exchange per step (multiview.GradExchange, format {args.exchange}: "
+                                      f"gradient exchange per step (multiview.GradExchange, format {exchange.mode}: "
                                       f"{exchange.last})" if world > 1 else
                                       f"single GPU, {V} view(s) per step, gradients summed on the device"},
             "roofline": roofline,
             "exchange": exch,
+            "rccl": rccl,
+            "gpus_requested": args.gpus,
             "cpu_baseline": cpu_baseline,
             "max_grad_err_vs_oracle": grad_err,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_allreduce(arena, dev, backend, allreduce_scalars, reps: int = 20):
+    """The in-place sum of the real gradient arena over all ranks on its own (no rendering): ms per all-reduce (max over
+    ranks) and the bus bandwidth 2 (W-1)/W bytes / t the ring formula defines. RCCL over xGMI under the nccl backend; under
+    gloo (functional tests, ranks sharing one device) the tensor goes through the host and the figure means nothing."""
+    from dreamscene_amd import multiview
+    W = dist.get_world_size()
+    for _ in range(3):
+        multiview.allreduce_grads(arena)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        multiview.allreduce_grads(arena)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    dt = allreduce_scalars([dt], dist.ReduceOp.MAX)[0]
+    nbytes = arena.nbytes()
+    return {"ranks": W, "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend),
+            "arena_bytes": int(nbytes), "allreduce_ms": round(dt * 1e3, 4),
+            "bus_GBps": round(2 * (W - 1) / W * nbytes / dt / 1e9, 2),
+            "alg_GBps": round(nbytes / dt / 1e9, 2), "reps": reps}
 
 
 def _torch_cpu_leg(P, res, n_views, budget_s):

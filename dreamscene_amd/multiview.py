@@ -63,6 +63,12 @@ def allreduce_grads(arena: GradArena, group=None, async_op: bool = False):
     No-op without an initialised process group. GradExchange below sends less."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return None
+    arena.touch()          # the arena now holds the sum over ALL ranks: this rank's reached-row bitmap no longer describes it
+    if _host_staged(group, arena.flat):
+        host = arena.flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        arena.flat.copy_(host)
+        return None
     return dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
@@ -198,7 +204,15 @@ class GradExchange:
 
     # ---- the exchange
     def reduce(self):
-        """Leaves the sum over all ranks in the arena, on every rank, bit-identical across ranks."""
+        """Leaves the sum over all ranks in the arena, on every rank, bit-identical across ranks. Afterwards the arena's
+        reached-row bitmap (this rank's views only) no longer describes its contents: GradArena.touch()."""
+        try:
+            self._reduce()
+        finally:
+            if self.last.get("format") != "none":
+                self.arena.touch()
+
+    def _reduce(self):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             self.last = dict(format="none", bytes_sent=0)
             return
@@ -377,16 +391,25 @@ def shard_views(n_views: int, rank: int, world: int):
     return [i for i in range(n_views) if i % world == rank]
 
 
-def _accepts_accumulate(fn) -> bool:
-    """Does the per-view callback take the `accumulate` argument (by name, as a fifth positional, or through **kwargs)?"""
+def _accumulate_style(fn) -> str:
+    """How the per-view callback takes the `accumulate` flag: "keyword" (a parameter of that name, or **kwargs),
+    "positional" (a fifth positional parameter under any name, or *args) or "none" (the four-argument contract of round 1:
+    the callback always overwrites grad_out)."""
     import inspect
     try:
         ps = list(inspect.signature(fn).parameters.values())
     except (TypeError, ValueError):
-        return True
+        return "keyword"
     if any(p.kind is p.VAR_KEYWORD or p.name == "accumulate" for p in ps):
-        return True
-    return False
+        return "keyword"
+    n_pos = sum(p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) for p in ps)
+    if n_pos >= 5 or any(p.kind is p.VAR_POSITIONAL for p in ps):
+        return "positional"
+    return "none"
+
+
+def _accepts_accumulate(fn) -> bool:
+    return _accumulate_style(fn) != "none"
 
 
 def render_views_data_parallel(rasterize_view, params: Dict[str, torch.Tensor], cameras, upstream, arena: GradArena,
@@ -396,9 +419,12 @@ def render_views_data_parallel(rasterize_view, params: Dict[str, torch.Tensor], 
 
     rasterize_view(params, camera, grad_out, upstream, accumulate=...) runs one view forward+backward and writes that
     view's parameter gradients into the tensors of grad_out (the arena's views): overwriting them when accumulate is
-    False, ADDING to them when it is True (the argument is passed BY KEYWORD; a callback without a parameter of that
-    name is taken to overwrite always and the sum over the rank's views is then formed here on the host side) -- K8's accumulate mode (RasterContext.accumulate): the sum over a rank's views is
-    formed on the device by the kernel that produces the gradients, no extra pass over the arena.
+    False, ADDING to them when it is True -- K8's accumulate mode (RasterContext.accumulate): the sum over a rank's views is
+    formed on the device by the kernel that produces the gradients, no extra pass over the arena. The flag is passed by
+    keyword to a callback with a parameter named `accumulate` (or **kwargs), as the fifth positional argument to one with
+    five or more positional parameters (or *args); a four-parameter callback is taken to overwrite always and the sum over
+    the rank's views is then formed here (clone + add; the arena's reached-row bitmap is invalidated, since the callback's
+    K8 overwrote it with the last view's rows).
     Equivalent, to fp32 summation order, to the sequential accumulation the reference performs."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -406,18 +432,22 @@ def render_views_data_parallel(rasterize_view, params: Dict[str, torch.Tensor], 
     outs = []
     # A callback written against the earlier contract takes four arguments and always OVERWRITES grad_out: for those the
     # sum over this rank's views is formed here (clone + add per extra view), as it was before K8 learnt to accumulate.
-    takes_accumulate = _accepts_accumulate(rasterize_view)
+    style = _accumulate_style(rasterize_view)
     for j, vi in enumerate(mine):
-        if takes_accumulate:
+        if style == "keyword":
             outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi], accumulate=j > 0))
+        elif style == "positional":
+            outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi], j > 0))
         elif j == 0:
             outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi]))
         else:
             held = arena.flat.clone()
             outs.append(rasterize_view(params, cameras[vi], arena.views, upstream[vi]))
             arena.flat.add_(held)
+            arena.touch()      # K8 (accumulate = 0) left the LAST view's rows in the bitmap; the arena holds the sum of all
     if not mine:
         arena.flat.zero_()
+        arena.touch()
     if exchange is not None:
         exchange.reduce()
     else:

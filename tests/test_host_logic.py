@@ -63,3 +63,63 @@ def test_view_stats_single_process():
     r = torch.tensor([5, 0], dtype=torch.int32)
     norm, vis, maxr = multiview.reduce_view_stats(g, r)
     assert norm.tolist() == [5.0, 0.0] and vis.tolist() == [1.0, 0.0] and maxr.tolist() == [5, 0]
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` without a launcher environment re-execs itself under torch.distributed.run with one rank
+    per GPU on 127.0.0.1 (the flag used to be parsed and ignored)."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.self_launch_cmd(8, ["--gpus", "8", "--steps", "20"], 29555)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29555" and "--nnodes=1" in cmd
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20"]
+
+
+def test_accumulate_flag_styles_and_bitmap_invalidation():
+    """the per-view callback gets `accumulate` by keyword, as a fifth positional (any name, or *args), or not at
+    all (four-parameter callbacks: host-side sum, and the arena's reached-row bitmap -- which the callback's K8 overwrote
+    with the LAST view's rows -- must be marked invalid so that a rows-format exchange does not drop the other views' rows)."""
+    assert multiview._accumulate_style(lambda p, c, g, u, accumulate=False: None) == "keyword"
+    assert multiview._accumulate_style(lambda p, c, g, u, **kw: None) == "keyword"
+    assert multiview._accumulate_style(lambda p, c, g, u, acc: None) == "positional"
+    assert multiview._accumulate_style(lambda p, c, g, u, acc=False: None) == "positional"
+    assert multiview._accumulate_style(lambda *a: None) == "positional"
+    assert multiview._accumulate_style(lambda p, c, g, u: None) == "none"
+    P, K = 130, 16
+    arena = multiview.GradArena(P, K, "cpu")
+    seen = []
+
+    def legacy(params, cam, grad_out, upstream):            # overwrites grad_out, and (like K8 without accumulate) the bitmap
+        for t in grad_out.values():
+            t.zero_()
+        grad_out["means3D"][cam] = float(cam + 1)
+        arena.reached.zero_()
+        arena.reached[cam // 64] = 1 << (cam % 64)
+        arena.reached_valid = True
+
+    def positional(params, cam, grad_out, upstream, acc):
+        seen.append(bool(acc))
+        if not acc:
+            for t in grad_out.values():
+                t.zero_()
+        grad_out["means3D"][cam] += 1.0
+
+    multiview.render_views_data_parallel(legacy, {}, [3, 70, 129], [None] * 3, arena)
+    assert not arena.reached_valid, "stale bitmap (last view only) left valid over a three-view sum"
+    ex = multiview.GradExchange(arena, sh_degree=3, mode="rows")
+    assert ex.nonzero_rows().tolist() == [3, 70, 129]
+    assert arena.views["means3D"][70, 0] == 71.0 and arena.views["means3D"][3, 0] == 4.0
+    multiview.render_views_data_parallel(positional, {}, [1, 2], [None] * 2, arena)
+    assert seen == [False, True] and arena.views["means3D"][2, 0] == 1.0 and arena.views["means3D"][3, 0] == 0.0
+    # no view for this rank: the arena is cleared and the bitmap no longer trusted
+    arena.reached_valid = True
+    multiview.render_views_data_parallel(positional, {}, [], [], arena)
+    assert not arena.reached_valid and float(arena.flat.abs().sum()) == 0.0
