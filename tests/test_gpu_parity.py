@@ -445,3 +445,61 @@ def test_c1_workload_vs_both_oracles(built_lib, c_oracle):
             ref = np.asarray(r["grads"][tk], dtype=np.float64)
             got = o[hk].cpu().numpy().astype(np.float64).reshape(ref.shape)
             assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max())), f"{hk} vs float64 autograd"
+
+
+@pytest.mark.parametrize("case", ["equal300", "equal3000", "equal4500_of_20000", "plane", "two_clusters", "one_visible"])
+def test_depth_order_distribution_sort_corner_cases(built_lib, c_oracle, case):
+    """The depth order comes from a distribution sort (csrc/depth_sort.h): bins of equal width over [min, max] of the
+    view's depth bits, buckets of whole bins sorted inside LDS, ties by Gaussian index, and a one-workgroup global-memory
+    sort for buckets beyond the LDS capacity. Depth distributions that stress each branch; the lists must stay bit-exact:
+      equal300 / equal3000  runs of equal keys inside an LDS bucket (tie order by counting inside the run);
+      equal4500_of_20000    one bin beyond the LDS capacity (the global-memory path), next to ordinary buckets;
+      plane                 20 000 Gaussians on a plane facing the camera + a few far outliers: nearly all keys in a
+                            handful of bins of the [min, max] range;
+      two_clusters          two tight depth clusters far apart: buckets whose key range spans the empty gap;
+      one_visible           a single visible Gaussian (range 0, one bucket of one pair)."""
+    from dreamscene_amd import synth
+    rng = np.random.default_rng(5)
+    K, D, H, W = 4, 1, 128, 128
+    cam = synth.object_cameras(2, H, W, radius=3.0)[1]
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    P = 6000
+    if case.startswith("equal"):
+        n_eq = int(case[5:].split("_")[0])
+        P = 20000 if "of_20000" in case else 6000
+        g = synth.g_object(P, seed=78, K=K)
+        g["means3D"][:n_eq] = g["means3D"][0]
+    elif case == "plane":
+        P = 20040
+        g = synth.g_object(P, seed=79, K=K)
+        # the camera looks at the origin: a plane through the origin orthogonal to the viewing direction, +- 1e-4 of jitter
+        fwd = -np.asarray(cam.camera_center, np.float64)
+        fwd /= np.linalg.norm(fwd)
+        a = np.cross(fwd, [0.0, 0.0, 1.0]); a /= np.linalg.norm(a)
+        b = np.cross(fwd, a)
+        uv = rng.uniform(-0.4, 0.4, size=(20000, 2))
+        g["means3D"][:20000] = (uv[:, :1] * a + uv[:, 1:] * b + rng.normal(scale=1e-4, size=(20000, 1)) * fwd).astype(np.float32)
+        g["means3D"][20000:] = (fwd * rng.uniform(2.0, 60.0, size=(40, 1))).astype(np.float32)      # far outliers stretch the range
+        g["scales"] = (g["scales"] * 0.3).astype(np.float32)
+    elif case == "two_clusters":
+        P = 9000
+        g = synth.g_object(P, seed=80, K=K)
+        fwd = -np.asarray(cam.camera_center, np.float64)
+        fwd /= np.linalg.norm(fwd)
+        g["means3D"] = (g["means3D"] * 0.05).astype(np.float32)
+        g["means3D"][4500:] += (fwd * 40.0).astype(np.float32)
+        g["scales"] = (g["scales"] * 0.2).astype(np.float32)
+        g["scales"][4500:] *= 8.0
+    else:
+        P = 3000
+        g = synth.g_object(P, seed=81, K=K)
+        g["means3D"][1:] += (np.asarray(cam.camera_center, np.float32) * 3.0)       # everything but Gaussian 0 behind the camera
+    v = oracle_view(c_oracle, cam, P, K, D, bg)
+    f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    if case == "one_visible":
+        assert int((f["radii"] > 0).sum()) == 1
+    else:
+        assert int((f["radii"] > 0).sum()) > P // 2
+    for rep in range(2):
+        out, _ = _run_hip(g, cam, bg, D)
+        _check_forward(out, f, P)

@@ -112,7 +112,8 @@ def test_bench_two_ranks_one_gpu(built_lib, tmp_path):
     env = dict(os.environ, GSR_BENCH_BACKEND="gloo", GSR_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
-           "--warmup", "2", "--gaussians", "20000", "--res", "256", "--no-cpu-baseline", "--capture", "off"]
+           "--warmup", "2", "--gaussians", "20000", "--res", "256", "--no-cpu-baseline", "--capture", "off", "--exchange", "dense",
+           "--sustain-seconds", "0", "--rotate-seconds", "0", "--train-seconds", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
