@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     cc = hipcc()
     objdir = objdir or os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "gsr_common.h"), os.path.join(CSRC, "radix_sort.h"), os.path.join(CSRC, "depth_sort.h"),
+    headers = [os.path.join(CSRC, "gsr_common.h"), os.path.join(CSRC, "radix_sort.h"),
                os.path.join(ROOT, "include", "gsrast.h"), os.path.abspath(__file__)]
     jobs = []
     for src, flags in SOURCES.items():

@@ -27,9 +27,7 @@
 // memory and clamps it to the capacity of the caller's buffers, so the whole forward can be enqueued without a
 // host round trip; the host checks N against the capacity afterwards (gsrast.h, gsr_forward_render).
 #include "gsr_common.h"
-#include <cstdlib>
 #include "radix_sort.h"
-#include "depth_sort.h"
 
 namespace {
 
@@ -546,8 +544,7 @@ static uint32_t col_runs(int32_t P) { return (uint32_t)(((P > 0 ? P : 1) + kColR
 extern "C" size_t gsr_project_scratch_bytes(int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
   return 5 * align256(m * 4) + sort_hist_bytes(m, kItemsSmall, kOsItemsSmall) + align256(kRadix * 4) +
-         align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + align256(264 * 4) + 256 +
-         align256(ds_state_words((int64_t)m) * 4) + 1024;
+         align256((size_t)256 * col_runs((int32_t)m) * 4) + align256(256 * 4) + align256(264 * 4) + 256 + 1024;
 }
 
 // Scratch of the binning stage: tile keys x2, one value ping buffer, histograms (the column path needs less).
@@ -561,7 +558,6 @@ extern "C" size_t gsr_sort_scratch_bytes(uint64_t n, uint32_t n_tiles) {
 struct ProjectScratch {
   uint32_t *k0, *k1, *v0, *v1, *hist, *totals, *rects, *hist1, *totals1, *colstart;
   uint64_t* counts;   // [0] = N (pairs), [1] = visible Gaussians
-  uint32_t* ds;       // state of the distribution sort of the depth keys (depth_sort.h)
 };
 static ProjectScratch carve_project(void* scratch, int32_t P) {
   const uint64_t m = P > 0 ? (uint64_t)P : 1;
@@ -577,8 +573,7 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
   s.hist1 = (uint32_t*)b; b += align256((size_t)256 * col_runs((int32_t)m) * 4);
   s.totals1 = (uint32_t*)b; b += align256(256 * 4);
   s.colstart = (uint32_t*)b; b += align256(264 * 4);
-  s.counts = (uint64_t*)b; b += 256;
-  s.ds = (uint32_t*)b;
+  s.counts = (uint64_t*)b;
   return s;
 }
 
@@ -586,12 +581,6 @@ uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P) { return carve_project(
 uint32_t* gsr_tile_rects(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).rects; }
 // device words [0] = N (pairs), [1] = number of visible Gaussians; they live in the projection scratch
 uint64_t* gsr_pair_counts(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).counts; }
-
-// GSR_DEPTH_SORT=radix: the LSD radix sort of rounds 1-3 (A/B measurements and the parity tests of both paths)
-static bool gsr_legacy_depth_sort() {
-  static const int legacy = [] { const char* e = getenv("GSR_DEPTH_SORT"); return (e && e[0] == 'r') ? 1 : 0; }();
-  return legacy != 0;
-}
 
 // After K1 (which wrote the depth keys into scratch.k0): depth sort, depth-ordered counts, scan -> N.
 // batch > 1: `batch` views whose projection scratch buffers are `bstride` bytes apart (geom = the first view's) go
@@ -609,13 +598,13 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
   int where;
   {
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
-    if (P < (1 << 24) && !gsr_legacy_depth_sort()) {
-      // distribution sort (depth_sort.h): keys k0 -> pairs grouped by bin in (k1, v1) -> sorted indices in v0
-      where = depth_sort_launch(s.k0, s.v0, s.k1, s.v1, s.k0, s.ds, n_vis_dev, (int64_t)P, stream, batch, bstride);
-    } else {
-      where = radix_sort_u32<kItemsSmall, kOsItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
-                                                         s.totals, stream, batch, bstride);
-    }
+    // (round 4 measured a distribution sort in its place -- equal-width bins over [min, max] of the depth bits, global
+    //  histogram + returning atomics, buckets of whole bins sorted inside LDS: tools/probe/depth_sort_distribution.h, lists
+    //  bit-identical -- at 108 us per view against 45 for this one: random-address global atomics run at ~25 G/s on this
+    //  part (2 M keys x 3 atomics = 290 us per 4-view step), and two LDS-local radix passes over 2 M pairs cost what two
+    //  one-sweep passes cost: profiles/r04_distribution_sort_kernel_stats.txt)
+    where = radix_sort_u32<kItemsSmall, kOsItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
+                                                       s.totals, stream, batch, bstride);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }

@@ -448,16 +448,14 @@ def test_c1_workload_vs_both_oracles(built_lib, c_oracle):
 
 
 @pytest.mark.parametrize("case", ["equal300", "equal3000", "equal4500_of_20000", "plane", "two_clusters", "one_visible"])
-def test_depth_order_distribution_sort_corner_cases(built_lib, c_oracle, case):
-    """The depth order comes from a distribution sort (csrc/depth_sort.h): bins of equal width over [min, max] of the
-    view's depth bits, buckets of whole bins sorted inside LDS, ties by Gaussian index, and a one-workgroup global-memory
-    sort for buckets beyond the LDS capacity. Depth distributions that stress each branch; the lists must stay bit-exact:
-      equal300 / equal3000  runs of equal keys inside an LDS bucket (tie order by counting inside the run);
-      equal4500_of_20000    one bin beyond the LDS capacity (the global-memory path), next to ordinary buckets;
-      plane                 20 000 Gaussians on a plane facing the camera + a few far outliers: nearly all keys in a
-                            handful of bins of the [min, max] range;
-      two_clusters          two tight depth clusters far apart: buckets whose key range spans the empty gap;
-      one_visible           a single visible Gaussian (range 0, one bucket of one pair)."""
+def test_depth_order_on_skewed_depth_distributions(built_lib, c_oracle, case):
+    """Depth distributions far from the object workloads' (written for the distribution sort measured in round 4,
+    tools/probe/depth_sort_distribution.h; kept for whatever produces the depth order): the lists must stay bit-exact.
+      equal300 / equal3000 / equal4500_of_20000   long runs of identical depth bits: ties in ascending Gaussian index;
+      plane          20 000 Gaussians on a plane facing the camera + a few far outliers: nearly all keys in a sliver of
+                     the [min, max] range (one digit value in every upper pass of a radix sort);
+      two_clusters   two tight depth clusters 40 units apart;
+      one_visible    a single visible Gaussian."""
     from dreamscene_amd import synth
     rng = np.random.default_rng(5)
     K, D, H, W = 4, 1, 128, 128

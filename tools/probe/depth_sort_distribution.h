@@ -1,4 +1,4 @@
-// depth_sort.h -- order of the visible Gaussians of a view by (depth bits, Gaussian index), gfx950.
+// depth_sort_distribution.h (round-4 experiment, NOT part of libgsrast; was csrc/depth_sort.h) -- order of the visible Gaussians of a view by (depth bits, Gaussian index), gfx950.
 //
 // Round 4. The LSD radix sort of the depth keys (radix_sort.h: one-sweep passes with decoupled look-back) moves 2 MB of
 // keys per view and took 79 us for one view / 101 us for the four views of a step: four DEPENDENT passes, each waiting
