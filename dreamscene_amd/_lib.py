@@ -24,6 +24,7 @@ class GsrView(C.Structure):
 
 GSR_MAX_MODELS = 16
 GSR_PACKED_VIEW_FLOATS = 44
+GSR_PARTIAL_WORDS = 32     # 32-bit words per Gaussian of GsrGrads.partials (16 doubles, 12 used)
 
 
 class GsrModel(C.Structure):

@@ -398,7 +398,7 @@ static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom
 
 // The scratch of one view (GsrGrads.partials + .reach) -> zeros
 static int clear_scratch(const GsrView* v, const GsrGrads* out, hipStream_t stream, bool partials = true) {
-  if (partials) GSR_HIP(gsr_zero_async(out->partials, (size_t)v->P * 12 * sizeof(float), stream));
+  if (partials) GSR_HIP(gsr_zero_async(out->partials, (size_t)v->P * GSR_PARTIAL_WORDS * sizeof(float), stream));
   if (out->reach) GSR_HIP(gsr_zero_async(out->reach, ((size_t)v->P + 63) / 64 * 8, stream));
   return GSR_OK;
 }
@@ -459,8 +459,8 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
         if (!outs[k].dL_dscales || outs[k].dL_dscales == outs[j].dL_dscales) return GSR_EINVAL;
   const bool fused = n_views > 1 && gsr_preprocess_bwd_views_supported(views[0], *g, outs[0]);
   if (per_view_scales && !fused) return GSR_EINVAL;   // per-view scales are only supported by the fused pass
-  // the views' partials usually are the rows of one [n_views, P, 12] tensor: one clear instead of n_views
-  const size_t pbytes = (size_t)views[0].P * 12 * sizeof(float);
+  // the views' partials usually are the rows of one [n_views, P, 32] tensor: one clear instead of n_views
+  const size_t pbytes = (size_t)views[0].P * GSR_PARTIAL_WORDS * sizeof(float);
   bool contiguous = true;
   for (int k = 1; k < n_views; ++k)
     contiguous = contiguous && ((char*)outs[k].partials == (char*)outs[0].partials + (size_t)k * pbytes);

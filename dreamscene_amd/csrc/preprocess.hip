@@ -958,9 +958,41 @@ __device__ __forceinline__ void sigma_backward(const float dS[9], const float R[
   drot[2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
   drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
 }
+// ---- K7's per-Gaussian sums: a row of 16 doubles, 12 used (render.hip, render_bwd_body) -- wave results added across
+// waves in double, rounded to fp32 HERE, once. partial_rows() hands them out as the chain rule below was written:
+// a = (S1, S2, S3, S4), b = (S5, dL/dopacity, r, g), c = (b, depth, b', depth').
+struct PartialRaw { float4 w[6]; };     // as loaded: 12 doubles, still raw bits (conversions wait for the loads: do them late)
+__device__ __forceinline__ PartialRaw partial_load(const float* __restrict__ partials, int64_t i) {
+  const float4* pp = reinterpret_cast<const float4*>(partials + GSR_PARTIAL_WORDS * i);
+  PartialRaw r;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) r.w[k] = pp[k];
+  return r;
+}
+__device__ __forceinline__ PartialRaw partial_none() {
+  PartialRaw r;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) r.w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  return r;
+}
+__device__ __forceinline__ float f64_words(float lo, float hi) {
+  return (float)__hiloint2double(__float_as_int(hi), __float_as_int(lo));
+}
+__device__ __forceinline__ void partial_rows(const PartialRaw& r, float4& a, float4& b, float4& c) {
+  a = make_float4(f64_words(r.w[0].x, r.w[0].y), f64_words(r.w[0].z, r.w[0].w), f64_words(r.w[1].x, r.w[1].y), f64_words(r.w[1].z, r.w[1].w));
+  b = make_float4(f64_words(r.w[2].x, r.w[2].y), f64_words(r.w[2].z, r.w[2].w), f64_words(r.w[3].x, r.w[3].y), f64_words(r.w[3].z, r.w[3].w));
+  c = make_float4(f64_words(r.w[4].x, r.w[4].y), f64_words(r.w[4].z, r.w[4].w), f64_words(r.w[5].x, r.w[5].y), f64_words(r.w[5].z, r.w[5].w));
+}
+__device__ __forceinline__ void partial_zero(float* __restrict__ partials, int64_t i) {
+  float4* pp = reinterpret_cast<float4*>(partials + GSR_PARTIAL_WORDS * i);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) pp[k] = z;
+}
+
 // --------------------------------------------------------------------------------------------------------- K8
-// partials [P,12] from K7: (S1 = sum q u, S2 = sum q v, S3 = sum q u^2, S4 = sum q u v, S5 = sum q v^2  [(u, v) = -conic d],
-//                          dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, -, -), q = dL/dG * G
+// partials [P,16 doubles] from K7 (see above): S1 = sum q u, S2 = sum q v, S3 = sum q u^2, S4 = sum q u v, S5 = sum q v^2
+// [(u, v) = -conic d], dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth; q = dL/dG * G
 template <int KT, bool SCENE = false, typename TAB = NoScene, typename GTAB = NoScene>
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB sg,
@@ -988,8 +1020,7 @@ k_preprocess_bwd(const GsrView v, const GsrGaussians g, const TAB sc, const GTAB
   float4 pa = make_float4(0, 0, 0, 0), pb = pa, pc = pa;
   if (vis) {
     px = p_xyz[3 * row]; py = p_xyz[3 * row + 1]; pz = p_xyz[3 * row + 2];
-    const float4* pp = reinterpret_cast<const float4*>(partials + 12 * i);
-    pa = pp[0]; pb = pp[1]; pc = pp[2];
+    partial_rows(partial_load(partials, i), pa, pb, pc);
     pc.x += pc.z; pc.y += pc.w;      // (K7 commits the last two sums from the two halves of a wave: render.hip, reduce10)
   }
   const float S1 = pa.x, S2 = pa.y, S3 = pa.z, S4 = pa.w, S5 = pb.x, gop = pb.y;
@@ -1480,9 +1511,8 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
 #pragma unroll
           for (int t = 0; t < kPer; ++t) {
             if (r[u][t] > 0) {
-              const float4* pp = reinterpret_cast<const float4*>(vb.partials[v0 + u] + 12 * (chunk_base(4 * t + wave) + lane));
-              const float4 pa = pp[0], pb = pp[1];
-              const float4 pc = pp[2];
+              float4 pa, pb, pc;
+              partial_rows(partial_load(vb.partials[v0 + u], chunk_base(4 * t + wave) + lane), pa, pb, pc);
               reached[t] = reached[t] || (pa.x != 0.f) || (pa.y != 0.f) || (pa.z != 0.f) || (pa.w != 0.f) || (pb.x != 0.f) ||
                            (pb.y != 0.f) || (pb.z != 0.f) || (pb.w != 0.f) || (pc.x != 0.f) || (pc.y != 0.f) ||
                            (pc.z != 0.f) || (pc.w != 0.f);
@@ -1539,17 +1569,14 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   // the next view are requested before the current view's arithmetic and before its stores
   int32_t r_nx = 0;
   uint32_t mk_nx = 1u;
-  float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f), b_nx = a_nx, c_nx = a_nx;
+  PartialRaw p_nx = partial_none();   // (raw words: the f64 -> f32 conversions wait for the loads, so they happen where the row is consumed)
   const auto prefetch_view = [&](int vv) {
     r_nx = ok ? vb.radii[vv][i] : 0;
     if (!vb.reach[0]) mk_nx = 1u;
     else if constexpr (REACHED) mk_nx = (uint32_t)((vmask[vv][entry >> 6] >> (entry & 63)) & 1ull);
     else mk_nx = ok ? (uint32_t)((vb.reach[vv][i >> 6] >> (i & 63)) & 1ull) : 0u;
     if constexpr (REACHED) {
-      if (ok) {
-        const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
-        a_nx = pp[0]; b_nx = pp[1]; c_nx = pp[2];
-      }
+      if (ok) p_nx = partial_load(vb.partials[vv], i);
     }
   };
   // every request of the round goes out before anything is consumed: one memory latency, not four
@@ -1643,7 +1670,8 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   for (int vv = 0; vv < vb.nv; ++vv) {
     const int32_t rad_v = r_nx;
     const bool take = mk_nx != 0u;                      // (an unmarked Gaussian's sums are zero: not used)
-    float4 pa = a_nx, pb = b_nx, pc = c_nx;
+    const PartialRaw p_cur = p_nx;
+    float4 pa, pb, pc;
     if (vv + 1 < vb.nv) prefetch_view(vv + 1);
     if constexpr (!REACHED) {     // (the wave owns the mark word of its 64 Gaussians; the REACHED form: wave_exit)
       if (vb.restore && vb.reach[0] && ok && (i & 63) == 0) vb.reach[vv][i >> 6] = 0ull;
@@ -1658,15 +1686,14 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       const int D = vd.sh_degree;
       const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
       const float limx = 1.3f * tfx, limy = 1.3f * tfy;
-      float4* pp = reinterpret_cast<float4*>(vb.partials[vv] + 12 * i);
       if constexpr (!REACHED) {
-        if (take) { pa = pp[0]; pb = pp[1]; pc = pp[2]; }
+        if (take) partial_rows(partial_load(vb.partials[vv], i), pa, pb, pc);
+      } else {
+        partial_rows(p_cur, pa, pb, pc);
       }
       if (!take) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; pc = pa; }
       pc.x += pc.z; pc.y += pc.w;      // (K7 commits the last two sums from the two halves of a wave: render.hip, reduce10)
-      if (take && vb.restore) {                         // GsrGrads.scratch_clean: leave the scratch as it was found
-        pp[0] = make_float4(0.f, 0.f, 0.f, 0.f); pp[1] = pp[0]; pp[2] = pp[0];
-      }
+      if (take && vb.restore) partial_zero(vb.partials[vv], i);     // GsrGrads.scratch_clean: leave the scratch as it was found
       gop += pb.y;
       const float grgb[3] = {pb.z, pb.w, pc.x};
       // (1) colour -> SH coefficients, view direction
@@ -1880,9 +1907,8 @@ k_preprocess_bwd_views_scene(const GsrView v, const SceneTab sc, const SceneGrad
       const float tfx = vd.tanfovx, tfy = vd.tanfovy;
       const int D = vd.sh_degree;
       const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
-      const float4* pp = reinterpret_cast<const float4*>(vb.partials[vv] + 12 * i);
-      const float4 pa = pp[0], pb = pp[1];
-      float4 pc = pp[2];
+      float4 pa, pb, pc;
+      partial_rows(partial_load(vb.partials[vv], i), pa, pb, pc);
       pc.x += pc.z; pc.y += pc.w;      // (see k_preprocess_bwd)
       gop += pb.y;
       const float grgb[3] = {pb.z, pb.w, pc.x};

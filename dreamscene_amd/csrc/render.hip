@@ -638,10 +638,20 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
   return R;
 }
 
-// Accumulates into partials [P,12], with q = dL/dG * G per (pixel, splat), d = centre - pixel and (u, v) = -Sigma^-1 d =
+// Accumulates into partials [P,16 doubles], with q = dL/dG * G per (pixel, splat), d = centre - pixel and (u, v) = -Sigma^-1 d =
 // (-(A dx + B dy), -(C dy + B dx)) (Sigma^-1 = the conic):
-//   (sum q u, sum q v, sum q u^2, sum q u v, sum q v^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, dL/db', dL/ddepth')
+//   (sum q u, sum q v, sum q u^2, sum q u v, sum q v^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth, dL/db', dL/ddepth', -, -, -, -)
 // (the last two pairs: the sums over the lower / upper half of a wave, added by K8 -- see reduce10)
+// Inside a wave the sums are reduced in fp32 in a FIXED order (reduce10); ACROSS waves they are added by atomics in whatever
+// order the workgroups arrive. In fp32 that order showed: the covariance chain amplifies sum q u^2 / q u v / q v^2 by
+// cond(Sigma)^2 on needle-shaped splats and dL/dopacity collects the 7e4-weighted extremal pixels of the reference's disp
+// normalisation (scene_gaussian.py:1025-1032) -- the worst dL/drotations entry of the needle case moved between 2.7e-6 and
+// 1.5e-5 from run to run, dL/dopacity of the boundary records between 1e-5 and 1e-4 (round 3). Now every wave result is
+// added in DOUBLE (global_atomic_add_f64: 29 spare mantissa bits over the fp32 addends -- the sum of a splat's <= 2^20 wave
+// results is exact, hence the same in every order) and K8 rounds the total to fp32 once: the backward is bit-reproducible.
+// One atomic instruction per (splat, block) as before -- 12 lanes, one 128-byte row. (Measured first: doubles for the four
+// sensitive sums only, in a second atomic instruction next to the f32 one: K7 217 -> 238 us -- two atomic instructions per
+// iteration run into the atomic issue limit of ~80 ns per instruction and SIMD, DESIGN.md "Issue costs".)
 // dG/dd = G (u, v), so the first two sums are dL/d(pixel centre), and dL/dSigma = 1/2 sum q (Sigma^-1 d)(Sigma^-1 d)^T, so
 // the other three are the gradient of the 2-D covariance itself (K8 only scales them) -- both formed PER PIXEL, as the
 // scalar oracle does (gsr_oracle.c, orc_pixel_bwd; SEMANTICS.md section 5). Rounds 1-2 summed the raw moments of d
@@ -697,6 +707,15 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   const uint32_t r0 = ranges[2 * tile];
   const size_t pix = (size_t)p.py * W + p.px, HW = (size_t)H * W;
 
+  // Depths are staged RELATIVE to the depth of the segment's last entry (uniform: two scalar loads). The loop carries
+  // R' = sum_k w_k (s_k - c) over the splats k composited behind, with s = <(colour, depth, 1), upstream gradient> and the
+  // per-pixel constant c = zref g_depth + g_alpha, next to A = sum_k w_k (the alpha composited behind): s - R = (s' - R') +
+  // c (1 - A). With the reference's disp normalisation |g_depth|, |g_alpha| reach 7e4 on the extremal pixels
+  // (scene_gaussian.py:1025-1032): s and R are then ~4e5 each and, in front of an opaque object (A -> 1), cancel to
+  // g_depth (z - z_behind) ~ 1e3 -- in the plain form that difference carried eps x 4e5 of rounding (dL/dopacity of the
+  // boundary records: 2e-5 .. 9e-5 of max|ref|, deterministic since the sums are added in double); in this form the large
+  // part c (1 - A) vanishes exactly where the cancellation happens and s' - R' is a difference of terms ~ g_depth x 0.1.
+  const float zref = reinterpret_cast<const float*>(splat + 3 * (size_t)point_list[r0 + (hi - 1u)] + 1)[2];
   // stage the segment, last entry first (one gather per thread)
   {
     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = make_float4(0, 0, -1.f, -1.f);
@@ -707,7 +726,7 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       n0 = r[0]; n1 = r[1]; n2 = r[2];
     }
     s0[tid] = make_float4(n0.x, n0.y, -0.5f * n0.z, -n0.w);              // conic staged as (hA, nB, hC)
-    s1[tid] = make_float4(-0.5f * n1.x, n1.y, n1.z, n1.w);
+    s1[tid] = make_float4(-0.5f * n1.x, n1.y, n1.z - zref, n1.w);
     s2[tid] = n2;
     sid[tid] = nid;
     smask[tid] = (tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u;
@@ -725,7 +744,7 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   const float bg_dot = (bg0 * gC0 + bg1 * gC1) + bg2 * gC2;
 
   float T = Tf;
-  float R = 0.f;
+  float R = 0.f, A = 0.f;
   if (last > hi) {
     // this pixel keeps compositing beyond the segment: start from the forward's checkpoint at position hi
     const float* ck = ckpt + (size_t)((r0 + hi) / kBatch) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
@@ -737,13 +756,15 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
     const float rc2 = ((color[2 * HW + pix] - Tf * bg2) - ck[768]) * inv;
     const float rec_z = (depth_alpha[pix] - ck[1024]) * inv;
     const float rec_a = (depth_alpha[HW + pix] - ck[1280]) * inv;
-    R = rc0 * gC0 + rc1 * gC1 + rc2 * gC2 + rec_z * gD + rec_a * gA;
+    R = rc0 * gC0 + rc1 * gC1 + rc2 * gC2 + (rec_z - zref * rec_a) * gD;     // = R - c A  (the g_alpha terms cancel exactly)
+    A = rec_a;
   }
+  const float cshift = zref * gD + gA;
 
   // one lane per quad commits with the single atomic of a splat's 10 sums; its component: bit 3 -> 1, bit 2 -> 2, bit 5 -> 4, bit 4 -> 8 (see reduce10)
   const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
-  const int comp = b4 ? 8 + 2 * b5 + b3 : (b3 | (b2 << 1) | (b5 << 2));      // word of the 12-float row (see reduce10)
-  const bool commit = ((lane & 3) == 0) && !(b4 && b2);                      // 8 + 4 lanes, twelve different words
+  const int comp = b4 ? 8 + 2 * b5 + b3 : (b3 | (b2 << 1) | (b5 << 2));      // double of the 16-double row (see reduce10)
+  const bool commit = ((lane & 3) == 0) && !(b4 && b2);                      // 8 + 4 lanes, twelve different doubles
   __syncthreads();
 
   for (int k = 0; k < kBatch / 64; ++k) {
@@ -782,10 +803,12 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
         // R = <(colour, depth, alpha) composited behind this splat, normalised to start here; upstream gradient>: the
         // recurrence of the behind-state is linear, so its dot product with the pixel's upstream gradient can be
         // carried instead of its five components (dL/dalpha only ever needs that dot product)
-        const float sdot = b.w * gC0 + c.x * gC1 + c.y * gC2 + b.z * gD + gA;
-        float dL_dalpha = (sdot - R) * T;
+        const float sdot = b.w * gC0 + c.x * gC1 + c.y * gC2 + b.z * gD;       // s - c  (b.z is staged relative to zref)
+        const float t1 = 1.0f - A;
+        float dL_dalpha = ((sdot - R) + cshift * t1) * T;
         dL_dalpha -= (Tf * inv) * bg_dot;
         R = alpha * sdot + (1.0f - alpha) * R;
+        A = __fmaf_rn(alpha, t1, A);
         // raw moments of q = dL/dG * G over the pixels; K8 turns them into dL/dmean2D and dL/dconic
         qv = (b.y * dL_dalpha) * G;
         gdl = G * dL_dalpha;
@@ -804,7 +827,7 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
         v[9] = wv * gD;
       }
       const float sred = reduce10(v, lane);
-      if (commit) unsafeAtomicAdd(partials + 12 * (size_t)sid[j] + comp, sred);
+      if (commit) unsafeAtomicAdd(reinterpret_cast<double*>(partials) + (GSR_PARTIAL_WORDS / 2) * (size_t)sid[j] + comp, (double)sred);
     }
     if (reach && hitk && lane == 0) atomicOr(&hitw[k], hitk);
   }

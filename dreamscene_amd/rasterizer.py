@@ -507,14 +507,14 @@ def _model_grad_rows(sc_struct, leaves_of, model_grads, accumulate, K, dev):
 
 
 class _Scratch:
-    """K7 -> K8 scratch of V views of P Gaussians, kept between calls under GsrGrads.scratch_clean: `partials` [V,P,12] (the
+    """K7 -> K8 scratch of V views of P Gaussians, kept between calls under GsrGrads.scratch_clean: `partials` [V,P,32] (the
     per-Gaussian sums K7 adds to) and `reach` [V, (P+63)//64] int64 (one bit per Gaussian K7 marked) are ALL ZERO whenever no backward is
     in flight -- K8 zeroes what it consumed -- so a step launches no clear (96 MB of stores + as many of loads at 500 k
     Gaussians x 4 views). `dirty` guards the invariant: set while a call is being enqueued, cleared when it returned OK."""
     __slots__ = ("partials", "reach", "dirty")
 
     def __init__(self, V, P, dev):
-        self.partials = torch.zeros((V, max(P, 1), 12), dtype=torch.float32, device=dev)
+        self.partials = torch.zeros((V, max(P, 1), L.GSR_PARTIAL_WORDS), dtype=torch.float32, device=dev)
         self.reach = torch.zeros((V, (max(P, 1) + 63) // 64), dtype=torch.int64, device=dev)
         self.dirty = False
 

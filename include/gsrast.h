@@ -197,7 +197,12 @@ typedef struct GsrGrads {
   float* dL_dview;      /* [16] or NULL; zero-initialised by the caller                              */
   float* dL_dproj;      /* [16] or NULL; zero-initialised by the caller                              */
   float* dL_dcampos;    /* [3]  or NULL; zero-initialised by the caller                              */
-  float* partials;      /* scratch [P,12]: per-Gaussian screen-space gradient accumulators           */
+  float* partials;      /* scratch [P,32] 32-bit words (128 B / Gaussian, 16-byte aligned) = 16 f64 per Gaussian, 12 used:
+                           sum q u, sum q v, sum q u^2, sum q u v, sum q v^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth
+                           (the last two as two half-wave sums each: doubles 8-11). K7 reduces a splat's sums over the 64
+                           pixels of a wave in fp32 in a fixed order and adds the wave's result ACROSS waves in double
+                           (one global_atomic_add_f64 instruction, 12 lanes, one 128-byte line): the order in which K7's
+                           workgroups arrive does not show in the gradients -- the backward is bit-reproducible       */
   int32_t accumulate;   /* 0: overwrite the parameter gradients; 1: ADD this view's gradients to what the buffers
                            hold (device-side sum over the views of one optimizer step). dL_dmeans2D is per view
                            and always overwritten; dL_dview/proj/campos always accumulate                     */
@@ -279,6 +284,7 @@ int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uin
  * kernel and is valid once the work enqueued so far has finished.
  * The views then continue with gsr_forward_render_batch (or each with its own gsr_forward_render). */
 #define GSR_MAX_BATCH_VIEWS 16
+#define GSR_PARTIAL_WORDS 32   /* 32-bit words per Gaussian of GsrGrads.partials (16 doubles) */
 int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGaussians* gaussians /* [n_views] */,
                               GsrGeom* geoms, uint64_t* n_pairs_pinned, void* stream, GsrProfile* prof);
 

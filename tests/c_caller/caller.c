@@ -83,7 +83,7 @@ static int run_gpu(void) {
   GsrGrads gr; memset(&gr, 0, sizeof gr);
   gr.dL_dmeans3D = (float*)dalloc(P * 12); gr.dL_dmeans2D = (float*)dalloc(P * 12); gr.dL_dopacities = (float*)dalloc(P * 4);
   gr.dL_dshs = (float*)dalloc((size_t)P * K * 12); gr.dL_dscales = (float*)dalloc(P * 12); gr.dL_drotations = (float*)dalloc(P * 16);
-  gr.partials = (float*)dalloc((size_t)P * 48);
+  gr.partials = (float*)dalloc((size_t)P * GSR_PARTIAL_WORDS * 4);
   GSRCHECK(gsr_backward(&v, &g, &geom, &b, &im, &ig, &gr, NULL, NULL));
   HIPCHECK(hipDeviceSynchronize());
   static float gop[P], gm[P * 3];

@@ -35,12 +35,10 @@ CONFIGS = {
     # what the reference's training augmentation hands the rasterizer (scene_gaussian.py:1005-1008): per-axis scale noise
     # s + n * (sqrt(0.2) s / 4), then clamp(.., 0.0) -- some axes collapse to EXACTLY zero (flat / needle-shaped splats
     # whose conic is ill-conditioned), on top of a share of strongly anisotropic ones
-    # On these splats the ORDER in which K7's fp32 atomics arrive moves the worst entry of dL/drotations (one of 400 000)
-    # between 2.7e-6 and 1.5e-5 from run to run (eight runs of this case on one box; every other tensor stays below 4e-6):
-    # the covariance sums of a 1 : 100 needle are amplified by its condition number on the way to the quaternion. The bar for
-    # that tensor and dL/dscales is therefore 3e-5 here; everything else, and every other configuration, stays at 1e-5.
-    "C2-needles": dict(scene="object", P=100_000, res=512, K=16, D=3, cams=[0], needles=True, smooth_upstream=True,
-                       tol=dict(dL_drotations=3e-5, dL_dscales=3e-5)),
+    # (Round 3 held dL/drotations and dL/dscales to 3e-5 here: the ORDER in which K7's fp32 atomics arrived moved their worst
+    # entry between 2.7e-6 and 1.5e-5 from run to run. K7's wave results are now added across waves in double -- the backward
+    # is bit-reproducible, test_backward_is_bit_reproducible below -- and every tensor is back at 1e-5: measured 1.4e-6.)
+    "C2-needles": dict(scene="object", P=100_000, res=512, K=16, D=3, cams=[0], needles=True, smooth_upstream=True),
 }
 _scene_cache = {}
 
@@ -139,9 +137,37 @@ def test_full_size_vs_oracle(built_lib, c_oracle, name):
         assert np.array_equal(nc, f["n_contrib"]), f"n_contrib differs at {(nc != f['n_contrib']).sum()} pixels"
         assert np.array_equal(out["final_T"].cpu().numpy().view(np.uint32), f["final_T"].view(np.uint32)), "final_T bits"
         for k, (frac, mx) in report.items():
-            tol_k = cfg.get("tol", {}).get(k, TOL)
-            assert mx <= tol_k and (frac <= OUTLIERS or tol_k > TOL), \
-                f"{name} {k}: {frac:.2e} of the entries beyond 1e-5 (max {mx:.2e}, bar {tol_k:.0e})"
+            assert mx <= TOL and frac <= OUTLIERS, f"{name} {k}: {frac:.2e} of the entries beyond 1e-5 (max {mx:.2e})"
+        del out, st, o
+
+
+@pytest.mark.parametrize("name", ["C2-needles", "C2-init"])
+def test_backward_is_bit_reproducible(built_lib, name):
+    """Eight forward + backward runs of the same inputs give the same BITS in every gradient: K7 reduces a splat's sums
+    over the pixels of a wave in a fixed order and adds the waves' results in double (global_atomic_add_f64; the sum of
+    fp32 addends is exact in double whatever the arrival order), K8 rounds once. Needles = the case whose worst
+    dL/drotations entry used to move between 2.7e-6 and 1.5e-5 with the order of fp32 atomics; init = ~87 layers per pixel,
+    the most cross-wave traffic per Gaussian."""
+    from dreamscene_amd import rasterizer as R
+    cfg = CONFIGS[name]
+    g, cams = _scene(cfg)
+    cam, D = cams[0], cfg["D"]
+    g_dev = {k: torch.tensor(v, device=DEV) for k, v in g.items()}
+    bg = np.array([1.0, 1.0, 1.0], np.float32)
+    gi, gda = _upstream(cfg, cam.image_height, cam.image_width, 0)
+    gi_d, gda_d = torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV)
+    first = None
+    for rep in range(8):
+        out, st = _forward(g_dev, cam, bg, D, want_keys=False)
+        o = R.rasterize_backward_raw(st, gi_d, gda_d)
+        torch.cuda.synchronize()
+        got = {k: o[k].clone() for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacities", "dL_dshs", "dL_dscales", "dL_drotations")}
+        if first is None:
+            first = got
+            assert all(float(v.abs().max()) > 0 for v in got.values())
+        else:
+            for k in first:
+                assert torch.equal(first[k], got[k]), f"{name}: {k} differs between run 0 and run {rep}"
         del out, st, o
 
 

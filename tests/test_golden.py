@@ -223,7 +223,10 @@ def test_object_render_training_augmentations_hip(built_lib, seed):
     for k, attr in TRAIN_KEYS.items():
         got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
         scale = max(1.0, float(np.abs(ref[k]).max()))
-        np.testing.assert_allclose(got.cpu().numpy(), ref[k], atol=3e-3 * scale, err_msg=k)
+        # (the fixture was captured with the glue AND the rasterizer in float64; here the glue -- activations, noise, the disp
+        #  normalisation with its division by (max - min) -- runs in fp32 torch ops on the GPU: measured <= 2e-4 on g_xyz, <= 7e-5
+        #  elsewhere. The rasterizer itself is pinned at 1e-5 / 3e-5 by the fp32 boundary records, tests/test_boundary_fixture.py)
+        np.testing.assert_allclose(got.cpu().numpy(), ref[k], atol=4e-4 * scale, err_msg=k)
 
 
 @pytest.mark.gpu
@@ -250,6 +253,7 @@ def test_object_render_plumbing_hip_vs_reference_fixture(built_lib):
                g_f_rest=p._features_rest.grad)
     for k, gr in ref.items():
         scale = max(1.0, float(np.abs(d[k]).max()))
-        # the disp post-processing divides by (depth + 10 alpha + 1e-5) and by (max - min): fp32 vs the float64
-        # capture differs at the 1e-3 relative level on the largest entries
-        np.testing.assert_allclose(gr.cpu().numpy(), d[k], atol=3e-3 * scale, err_msg=k)
+        # the disp post-processing divides by (depth + 10 alpha + 1e-5) and by (max - min): the fp32 glue vs the float64
+        # capture differs by <= 1.7e-4 of the largest entry (g_xyz; <= 4e-5 elsewhere) -- the rasterizer's own bar is
+        # tests/test_boundary_fixture.py
+        np.testing.assert_allclose(gr.cpu().numpy(), d[k], atol=4e-4 * scale, err_msg=k)
