@@ -212,11 +212,13 @@ def main():
     arena = multiview.GradArena(P, K, dev)
     exchange = multiview.GradExchange(arena, sh_degree=D, mode="dense" if args.exchange == "measure" else args.exchange)
     prof_holder = [None]       # the contexts below share one profile slot (set for the stage pass / the timed region)
+    host_stats = R.HostStats()   # seconds blocked on the pair counts, summed over the calls of the contexts below
 
     def ctx(accumulate):
         # view 0 of a step overwrites the arena, views 1.. are added on the device; the parameter gradients live in the
         # arena (what the exchange works on), autograd only delivers means2D.grad
-        return RasterContext(grad_arena=arena, accumulate=accumulate, fwd_variant=args.fwd_mode, profile=prof_holder[0])
+        return RasterContext(grad_arena=arena, accumulate=accumulate, fwd_variant=args.fwd_mode, profile=prof_holder[0],
+                             host_stats=host_stats)
 
     settings_list = [GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=t([1.0, 1.0, 1.0]),
@@ -262,7 +264,30 @@ def main():
         reduce_grads()
         return outs[0], g2d[0]
 
+    plain_rasts = [GaussianRasterizer(raster_settings=s_) for s_ in settings_list]
+
     def step_dropin():
+        """The reference's interface, used the way its trainers use it (training/object_trainer.py:302-382): the V views of a
+        step are rendered one GaussianRasterizer call after the other, all outputs are kept, then the backward of every
+        view runs (here one torch.autograd.grad per view, last view first -- the order autograd runs them in -- so that
+        no torch-side gradient accumulation is timed with the rasterizer). No context, no arena: the module as imported.
+        With several ranks the per-view gradients have to meet in the arena for the exchange: the arena form below."""
+        if world > 1:
+            return step_dropin_arena()
+        held = []
+        for rast in plain_rasts:
+            means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+            img, radii, da = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
+                                  opacities=params["opacities"], scales=params["scales"],
+                                  rotations=params["rotations"], cov3D_precomp=None)
+            held.append((img, radii, da, means2D))
+        g2d0 = None
+        for img, radii, da, means2D in reversed(held):
+            gr = torch.autograd.grad([img, da], leaves + [means2D], [gi, gda])
+            g2d0 = gr[-1]
+        return held[0][:3], g2d0
+
+    def step_dropin_arena():
         out0 = g2d0 = None
         for j, rast in enumerate(rasts):
             means2D = torch.zeros_like(params["means3D"], requires_grad=True)
@@ -373,11 +398,11 @@ def main():
             step()
 
     sync()
-    R.HOST_WAIT_S[0] = 0.0
+    host_stats.wait_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    host_wait_s = R.HOST_WAIT_S[0]                   # of which: blocked on the pair counts of the projection
+    host_wait_s = host_stats.wait_s                  # of which: blocked on the pair counts of the projection
     host_enqueue_s = time.perf_counter() - t0        # the host is done enqueueing; the GPU may still be working
     sync()
     elapsed = time.perf_counter() - t0
@@ -511,6 +536,7 @@ def main():
 
         def step_train_dropin(i):
             sl = train_settings(i)
+            held = []
             for j in range(V):
                 means2D = torch.zeros_like(params["means3D"], requires_grad=True)
                 sc = noisy_scales(tuple(params["scales"].shape))
@@ -518,6 +544,8 @@ def main():
                 img, radii, da = GaussianRasterizer(raster_settings=sl[j])(
                     means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
                     opacities=params["opacities"], scales=sc, rotations=params["rotations"], cov3D_precomp=None)
+                held.append((img, da, means2D, sc))
+            for img, da, means2D, sc in reversed(held):      # all views forward, then their backwards: the trainers' order
                 torch.autograd.grad([img, da], [params["means3D"], params["shs"], params["opacities"], params["rotations"],
                                                 means2D, sc], [gi, gda])
 
@@ -726,6 +754,7 @@ def main():
             "sustained_views_per_s": sustained["views_per_s"] if sustained else None,
             "sustained": sustained,
             "rotating_cameras": rotating,
+            "dropin_graphs": dropin_ring_stats(),
             "training_like": training_like,
             "init_views_per_s": init_state["views_per_s"] if init_state else None,
             "init_state": init_state,
@@ -762,6 +791,11 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def dropin_ring_stats():
+    from dreamscene_amd import dropin
+    return {"enabled": dropin.ENABLED, "rings": dropin.stats()}
 
 
 def measure_allreduce(arena, dev, backend, allreduce_scalars, reps: int = 20):

@@ -198,7 +198,8 @@ class CapturedViews(torch.nn.Module):
                 spins += 1
                 if (spins & 63) == 0 and cap.evF.query():
                     break
-            R.HOST_WAIT_S[0] += time.perf_counter() - t_wait
+            if rc.host_stats is not None:
+                rc.host_stats.wait_s += time.perf_counter() - t_wait
         ns = [int(x) for x in cap.pinned_np[:V]]
         self._peak_n = max([self._peak_n] + ns)
         self.stats["replays"] += 1

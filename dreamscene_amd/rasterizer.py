@@ -65,6 +65,10 @@ class RasterContext:
     forward_mode   "auto": speculate the pair capacity from previous calls and enqueue the whole forward without draining
                    the GPU (exact re-run if it was too small); "sync": always the exact two-phase forward
     fwd_variant    forward compositing variant (GsrBinning.fwd_mode): None = per call from the previous view's statistics
+    dropin_graphs  GaussianRasterizer only: replay the call's launches from captured graphs (dropin.py) when the call is
+                   eligible (SH + scales + rotations inputs, no arena / profile / statistics); False = always eager
+    host_stats     optional HostStats: seconds the calls made with this context spent blocked on the projection's pair
+                   counts (bench.py reports it per step)
     """
     score_mode: int = 0
     profile: Optional[L.Profile] = None
@@ -74,15 +78,24 @@ class RasterContext:
     stats_views: Optional[Sequence[int]] = None
     forward_mode: str = "auto"
     fwd_variant: Optional[int] = None
+    dropin_graphs: bool = True
+    host_stats: Optional["HostStats"] = None
 
     def snapshot(self) -> "RasterContext":
         return dataclasses.replace(self)
 
 
+class HostStats:
+    """Seconds spent blocked on the projection's pair counts by the calls that carry this object in their RasterContext (a
+    statistic, not a switch: how much of a step the host is idle, i.e. how far the path is from being bound by host-side
+    enqueueing). Shared by reference between a context and its per-call snapshots."""
+    __slots__ = ("wait_s",)
+
+    def __init__(self):
+        self.wait_s = 0.0
+
+
 DEFAULT_CONTEXT = RasterContext()
-# seconds this process has spent blocked on the projection's pair count (a statistic, not a switch; bench.py reports it
-# per step: how much of a step the host is idle, i.e. how far the path is from being bound by host-side enqueueing)
-HOST_WAIT_S = [0.0]
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -384,7 +397,8 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
             if batch is None or not batch.get("synced", [False])[0]:
                 t_wait = time.perf_counter()
                 event.synchronize()          # (the render is already enqueued behind the projection: the GPU stays busy)
-                HOST_WAIT_S[0] += time.perf_counter() - t_wait
+                if rc.host_stats is not None:
+                    rc.host_stats.wait_s += time.perf_counter() - t_wait
                 if batch is not None and "synced" in batch:
                     batch["synced"][0] = True     # one wait covers the pair counts of all views of the batch
             N = int(pinned[pidx].item()) if P > 0 else 0
@@ -832,6 +846,11 @@ class GaussianRasterizer(torch.nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         s = self.raster_settings
+        from . import dropin
+        if dropin.eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, self.context):
+            out = dropin.rasterize(s, means3D, means2D, opacities, shs, scales, rotations, self.context)
+            if out is not None:
+                return out
         rc = (self.context or DEFAULT_CONTEXT).snapshot()
         return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                          cov3D_precomp, s.viewmatrix, s.projmatrix, s.campos, s, rc)

@@ -31,7 +31,8 @@ sets = [GaussianRasterizationSettings(image_height=res, image_width=res, tanfovx
                                       projmatrix=t(c.full_proj_transform), sh_degree=D, campos=t(c.camera_center),
                                       prefiltered=False, score_flag=False) for c in cams]
 arena = multiview.GradArena(P, K, dev)
-rast = CapturedViews(context=R.RasterContext(grad_arena=arena))
+hs = R.HostStats()
+rast = CapturedViews(context=R.RasterContext(grad_arena=arena, host_stats=hs))
 
 
 def step():
@@ -44,14 +45,14 @@ def step():
 for _ in range(30):
     step()
 torch.cuda.synchronize()
-R.HOST_WAIT_S[0] = 0.0
+hs.wait_s = 0.0
 t0 = time.perf_counter()
 for _ in range(300):
     step()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"enqueue {1e3 * (t1 - t0) / 300:.3f} ms/step of which waiting {1e3 * R.HOST_WAIT_S[0] / 300:.3f}; wall {1e3 * (t2 - t0) / 300:.3f} ms/step; {rast.stats}")
+print(f"enqueue {1e3 * (t1 - t0) / 300:.3f} ms/step of which waiting {1e3 * hs.wait_s / 300:.3f}; wall {1e3 * (t2 - t0) / 300:.3f} ms/step; {rast.stats}")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(300):
