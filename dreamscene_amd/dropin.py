@@ -26,7 +26,8 @@ allow ~8 000). This module puts the launches of a view behind two graph launches
 
 Not eligible (the eager path runs, as before): colors_precomp / cov3D_precomp inputs, score_flag, camera gradients, a
 RasterContext with an arena / profile / densify_stats, non-fp32 or non-contiguous inputs, P = 0, grids beyond 256 x 256
-tiles, `GSR_DROPIN_GRAPHS=0`.
+tiles. OPT-IN: `GSR_DROPIN_GRAPHS=1` in the environment (unmodified trainers construct the module without a context) or
+`RasterContext(dropin_graphs=True)` -- see the measurements at ENABLED below for when it pays.
 """
 from __future__ import annotations
 
@@ -39,7 +40,13 @@ import torch
 from . import rasterizer as R
 
 MAX_SLOTS = 8           # per key: views of a step in flight (C_batch_size = 4) + the ones whose graph is still alive
-ENABLED = os.environ.get("GSR_DROPIN_GRAPHS", "1") != "0"
+# Opt-in (GSR_DROPIN_GRAPHS=1, or RasterContext(dropin_graphs=True) per module). Measured on MI355X / ROCm 7.2, round 4
+# (gpurun_out/r4d, profiles/r04_dropin_graphs.txt): a graph launch of the 17 forward nodes costs the host 10 us instead of
+# ~85 us of launches + ~60 us of Python, but the GPU then runs the 21 dependent kernels of a view with 5-8 us between
+# nodes, and the copy-out adds launches: 100 k @512^2, forward + backward of a view right after each other 3 270 -> 3 900
+# views/s; the trainers' pattern (four forwards, then four backwards) 3 440 -> 3 210, and at 500 k @1024^2 2 390 -> 1 940
+# (eight slots' state cycling through the caches). Neither pattern reaches what ONE batched call gives (10 600 / 4 900).
+ENABLED = os.environ.get("GSR_DROPIN_GRAPHS", "0") == "1"
 
 _RINGS = {}
 _LOCK = threading.Lock()
@@ -107,13 +114,15 @@ class _Ring:
 
 
 def eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, context) -> bool:
-    if not ENABLED or shs is None or colors_precomp is not None or cov3D_precomp is not None:
+    want = getattr(context, "dropin_graphs", None) if context is not None else None
+    if not (ENABLED if want is None else want):
+        return False
+    if shs is None or colors_precomp is not None or cov3D_precomp is not None:
         return False
     if scales is None or rotations is None or s.score_flag:
         return False
     if context is not None and (context.grad_arena is not None or context.profile is not None or
-                                context.densify_stats is not None or context.forward_mode != "auto" or
-                                not getattr(context, "dropin_graphs", True)):
+                                context.densify_stats is not None or context.forward_mode != "auto"):
         return False
     if means3D.device.type != "cuda" or means3D.shape[0] == 0 or means3D.shape[0] >= (1 << 24):
         return False

@@ -65,8 +65,9 @@ class RasterContext:
     forward_mode   "auto": speculate the pair capacity from previous calls and enqueue the whole forward without draining
                    the GPU (exact re-run if it was too small); "sync": always the exact two-phase forward
     fwd_variant    forward compositing variant (GsrBinning.fwd_mode): None = per call from the previous view's statistics
-    dropin_graphs  GaussianRasterizer only: replay the call's launches from captured graphs (dropin.py) when the call is
-                   eligible (SH + scales + rotations inputs, no arena / profile / statistics); False = always eager
+    dropin_graphs  GaussianRasterizer only: True = replay the call's launches from captured graphs (dropin.py) when the call is
+                   eligible (SH + scales + rotations inputs, no arena / profile / statistics); False = always eager; None =
+                   what the environment says (GSR_DROPIN_GRAPHS=1: on; default off -- dropin.py has the measurements)
     host_stats     optional HostStats: seconds the calls made with this context spent blocked on the projection's pair
                    counts (bench.py reports it per step)
     """
@@ -78,7 +79,7 @@ class RasterContext:
     stats_views: Optional[Sequence[int]] = None
     forward_mode: str = "auto"
     fwd_variant: Optional[int] = None
-    dropin_graphs: bool = True
+    dropin_graphs: Optional[bool] = None
     host_stats: Optional["HostStats"] = None
 
     def snapshot(self) -> "RasterContext":

@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _graphs_on(monkeypatch):
+    """The captured path is opt-in (GSR_DROPIN_GRAPHS=1); these tests switch it on for modules built without a context,
+    which is how the reference builds them (scene_gaussian.py:966)."""
+    from dreamscene_amd import dropin
+    monkeypatch.setattr(dropin, "ENABLED", True)
+    yield
+    dropin.reset()
+
+
 def _scene(P=20_000, K=16, res=256, n_cams=4, seed=3):
     from dreamscene_amd import synth
     g = synth.g_object(P, seed=seed, K=K)
