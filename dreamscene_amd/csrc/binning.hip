@@ -579,6 +579,18 @@ static ProjectScratch carve_project(void* scratch, int32_t P) {
 
 uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).k0; }
 uint32_t* gsr_tile_rects(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).rects; }
+// The words K1 clears for the depth sort that follows it (the one-sweep state: digit histograms, tickets, look-back words):
+// K1 and the sort are always enqueued as a pair (gsr_forward_project*), so the sort launches no clear of its own -- one
+// launch less in front of a latency-bound chain. 0 words when the sort takes the three-kernel passes.
+// (Round 4 also folded k_col_plan into the tail of the column scan and k_work_order_fwd into the tail of k_row_scatter --
+//  "the workgroup that draws the last ticket does the next kernel's work", release / acquire on the ticket: lists
+//  bit-identical, but an agent-scope release writes the XCD's whole L2 back: k_row_scatter 46 -> 86 us per 4-view launch for
+//  the 8 us launch it saved, the fused scan + plan 17.8 us against 8.8 + 4.9. Not kept: gpurun_out/r4e, profiles/HISTORY.md.)
+uint32_t* gsr_depth_sort_state(const GsrGeom& geom, int32_t P, uint32_t* words) {
+  const uint64_t m = P > 0 ? (uint64_t)P : 1;
+  *words = m < kOsMaxN ? (uint32_t)os_state_words(m, kOsItemsSmall) : 0u;
+  return carve_project(geom.scratch, P).hist;
+}
 // device words [0] = N (pairs), [1] = number of visible Gaussians; they live in the projection scratch
 uint64_t* gsr_pair_counts(const GsrGeom& geom, int32_t P) { return carve_project(geom.scratch, P).counts; }
 
@@ -604,7 +616,7 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
     //  part (2 M keys x 3 atomics = 290 us per 4-view step), and two LDS-local radix passes over 2 M pairs cost what two
     //  one-sweep passes cost: profiles/r04_distribution_sort_kernel_stats.txt)
     where = radix_sort_u32<kItemsSmall, kOsItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
-                                                       s.totals, stream, batch, bstride);
+                                                       s.totals, stream, batch, bstride, /*state_cleared=*/true);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }

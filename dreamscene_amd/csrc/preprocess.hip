@@ -461,8 +461,11 @@ template <int KT, bool SCENE = false, typename TAB = NoScene>
 __global__ void __launch_bounds__(256)
 k_preprocess(const GsrView v, const GsrGaussians g, const TAB sc, float* __restrict__ splat,
              int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_keys,
-             uint32_t* __restrict__ rects) {
+             uint32_t* __restrict__ rects, uint32_t* __restrict__ sort_state, const uint32_t sort_state_words) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // the depth sort that follows starts from a zeroed state (digit histograms, tickets, look-back words; radix_sort.h): cleared
+  // here, a few words per workgroup, instead of by a launch of its own in front of the sort
+  for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < sort_state_words; w += gridDim.x * 256u) sort_state[w] = 0u;
   const int P = v.P, W = v.image_width, H = v.image_height, K = KT > 0 ? KT : v.sh_stride;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const Rows rw = resolve_rows<SCENE>(sc, P);
@@ -665,7 +668,14 @@ struct K1Views {
   uint32_t* tiles_touched[GSR_MAX_BATCH_VIEWS];
   uint32_t* depth_keys[GSR_MAX_BATCH_VIEWS];
   uint32_t* rects[GSR_MAX_BATCH_VIEWS];
+  uint32_t* sort_state[GSR_MAX_BATCH_VIEWS];   // state of the depth sort that follows, cleared here (see k_preprocess)
+  uint32_t sort_state_words;
 };
+
+__device__ __forceinline__ void k1_clear_sort_state(const K1Views& vb) {
+  for (int vv = 0; vv < vb.nv; ++vv)
+    for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < vb.sort_state_words; w += gridDim.x * 256u) vb.sort_state[vv][w] = 0u;
+}
 
 template <int KT>
 // (4 waves per SIMD: 128 VGPRs instead of 131 at K = 16, no spills -- the kernel is latency-bound on its division chains)
@@ -674,6 +684,7 @@ k_preprocess_views(const GsrView v, const GsrGaussians g, const K1Views vb) {
   constexpr int F = 3 * KT;
   const int P = v.P, W = v.image_width, H = v.image_height;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  k1_clear_sort_state(vb);
   if (i >= P) return;
   const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
   const float px = g.means3D[3 * i], py = g.means3D[3 * i + 1], pz = g.means3D[3 * i + 2];
@@ -741,6 +752,7 @@ __global__ void __launch_bounds__(256)
 k_preprocess_views_scene(const GsrView v, const SceneTab sc, const K1Views vb) {
   constexpr int F = 3 * KT;
   const int W = v.image_width, H = v.image_height;
+  k1_clear_sort_state(vb);
   const Rows rw = resolve_rows<true>(sc, v.P);
   if (!rw.ok) return;
   const int64_t i = rw.i, row = rw.row;
@@ -2033,6 +2045,7 @@ k_preprocess_bwd_views_scene(const GsrView v, const SceneTab sc, const SceneGrad
 }  // namespace
 
 uint32_t* gsr_depth_keys(const GsrGeom& geom, int32_t P);   // binning.hip: first key buffer of the depth sort
+uint32_t* gsr_depth_sort_state(const GsrGeom& geom, int32_t P, uint32_t* words);   // binning.hip: state K1 clears for the sort
 uint32_t* gsr_tile_rects(const GsrGeom& geom, int32_t P);   // binning.hip: packed tile rectangles, one per Gaussian
 
 size_t gsr_preprocess_lds_bytes(int K) { return (size_t)4 * 64 * sh_lds_stride(K) * sizeof(float); }
@@ -2067,9 +2080,12 @@ int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom
     SceneTab t; SceneGradTab gt;
     const uint32_t nbs = scene_tables(*g.scene, nullptr, t, gt);
     const size_t lds = gsr_preprocess_lds_bytes(v.sh_stride);
+    uint32_t ss_words = 0;
+    uint32_t* ss = gsr_depth_sort_state(geom, v.P, &ss_words);
 #define GSR_LAUNCH_K1S(KT)                                                                                         \
   hipLaunchKernelGGL((k_preprocess<KT, true, SceneTab>), dim3(nbs), dim3(256), (KT) > 0 ? 0 : lds, stream, v, g, t, \
-                     geom.splat, geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P), gsr_tile_rects(geom, v.P))
+                     geom.splat, geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P), gsr_tile_rects(geom, v.P), \
+                     ss, ss_words)
     switch (v.sh_stride) {
       case 16: GSR_LAUNCH_K1S(16); break;
       case 9: GSR_LAUNCH_K1S(9); break;
@@ -2084,9 +2100,11 @@ int gsr_launch_preprocess(const GsrView& v, const GsrGaussians& g, GsrGeom& geom
   const uint32_t nb = gsr_num_blocks(v.P);
   const size_t lds = g.shs ? gsr_preprocess_lds_bytes(v.sh_stride) : 0;
   // compile-time strides read their rows directly (no LDS); only the generic stride stages through LDS
+  uint32_t ss_words = 0;
+  uint32_t* ss = gsr_depth_sort_state(geom, v.P, &ss_words);
 #define GSR_LAUNCH_K1(KT)                                                                                         \
   hipLaunchKernelGGL(k_preprocess<KT>, dim3(nb), dim3(256), (KT) > 0 ? 0 : lds, stream, v, g, NoScene{}, geom.splat, \
-                     geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P), gsr_tile_rects(geom, v.P))
+                     geom.radii, geom.tiles_touched, gsr_depth_keys(geom, v.P), gsr_tile_rects(geom, v.P), ss, ss_words)
   switch (g.shs ? v.sh_stride : 0) {
     case 16: GSR_LAUNCH_K1(16); break;
     case 9: GSR_LAUNCH_K1(9); break;
@@ -2309,6 +2327,7 @@ int gsr_launch_preprocess_views(int n_views, const GsrView* views, const GsrGaus
     vb.dyn[k] = views[k].dynamic;
     vb.splat[k] = geoms[k].splat; vb.radii[k] = geoms[k].radii; vb.tiles_touched[k] = geoms[k].tiles_touched;
     vb.depth_keys[k] = gsr_depth_keys(geoms[k], views[k].P); vb.rects[k] = gsr_tile_rects(geoms[k], views[k].P);
+    vb.sort_state[k] = gsr_depth_sort_state(geoms[k], views[k].P, &vb.sort_state_words);
   }
   const GsrView& v = views[0];
   if (g.scene) {

@@ -249,7 +249,10 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
 #endif
 constexpr int kOsItemsSmall = GSR_OS_ITEMS_SMALL;     // keys per thread, P-sized sorts (4096-key tiles: see the phase timings below)
 constexpr int kOsMaxPasses = 4;
-constexpr uint32_t kOsHistTile = 2048;  // keys per workgroup of k_os_hist
+#ifndef GSR_OS_HIST_TILE
+#define GSR_OS_HIST_TILE 2048
+#endif
+constexpr uint32_t kOsHistTile = GSR_OS_HIST_TILE;  // keys per workgroup of k_os_hist
 constexpr uint32_t kOsTableOff = kOsMaxPasses * kRadix + 16;   // u32 words: [passes][256] histograms | 4 tickets (+ pad) | table
 constexpr uint64_t kOsMaxN = 1ull << 28;
 
@@ -548,13 +551,16 @@ int radix_sort_u32_legacy(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1
 template <int ITEMS, int OS_ITEMS>
 int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
                    int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream,
-                   int batch = 1, size_t bstride = 0) {
+                   int batch = 1, size_t bstride = 0, bool state_cleared = false) {
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
   if (cap >= kOsMaxN || passes > kOsMaxPasses)
     return radix_sort_u32_legacy<ITEMS>(k0, v0, k1, v1, n_dev, cap, bits, iota, n_compact, hist, totals, stream, batch, bstride);
   const uint32_t ntile = os_tiles(cap, OS_ITEMS), nhist = (uint32_t)((cap + kOsHistTile - 1) / kOsHistTile);
   const dim3 grid(ntile, (uint32_t)batch), grid_h(nhist ? nhist : 1, (uint32_t)batch);
-  if (gsr_zero_async(hist, os_state_words(cap, OS_ITEMS) * 4, stream, bstride, (uint32_t)batch) != hipSuccess) return passes & 1;
+  // state_cleared: the caller's previous kernel left the os_state_words(cap, OS_ITEMS) words at `hist` zero (K1 does, for the
+  // depth sort: one launch less in front of a latency-bound chain)
+  if (!state_cleared &&
+      gsr_zero_async(hist, os_state_words(cap, OS_ITEMS) * 4, stream, bstride, (uint32_t)batch) != hipSuccess) return passes & 1;
   const bool drop = iota && n_compact;
   if (drop)
     hipLaunchKernelGGL((k_os_hist<true>), grid_h, dim3(kSortThreads), 0, stream, k0, n_dev, cap, passes, hist, bstride);
