@@ -332,6 +332,13 @@ int gsr_forward_render_batch(int32_t n_views, const GsrView* views, const GsrGeo
     if (rc) return rc;
     if (views[k].image_height != views[0].image_height || views[k].image_width != views[0].image_width) return GSR_EINVAL;
   }
+  // score_mode 0 leaves u32 pixel COUNTS in important_score and converts them in place once per view (k_score_finalize): two
+  // views adding into one buffer would have the second conversion reinterpret the first view's floats as counts. Sums over
+  // views take score_mode 2 (raw counts, converted by the caller) or 1 (float atomics).
+  for (int k = 0; k < n_views; ++k)
+    for (int j = 0; j < k; ++j)
+      if (imgs[k].important_score && imgs[k].important_score == imgs[j].important_score && views[k].score_mode == 0)
+        return GSR_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   GsrDeviceGuard dev(imgs[0].color);
   // capacity mode + equally spaced scratch buffers: emission and the ty pass of all views share their launches

@@ -43,6 +43,7 @@ from . import views as VW
 WARM_CALLS = 2          # eager calls (they learn the pair counts) before the first capture
 MAX_DIRECT_GRAPHS = 4   # backward graphs captured over callers' gradient addresses (beyond that: copy + the static one)
 PTR_MISSES_TO_STAGE = 2  # consecutive captures invalidated by nothing but new input ADDRESSES before the inputs are staged
+PTR_REPEATS_TO_UNSTAGE = 8   # consecutive calls with identical input addresses before staged inputs go back to zero-copy
 
 
 class _Captured:
@@ -82,9 +83,13 @@ class _CapturedFn(torch.autograd.Function):
     def backward(ctx, *grads):
         cap = ctx.cap_state
         if cap is not None and cap.generation != ctx.generation:
-            # the static forward state / outputs of a capture belong to its LATEST replay: a backward of an earlier call
-            # (gradient accumulation over two forwards, retain_graph, an eval render in between) would silently use the
-            # later step's state -- the eager path's version check has no equivalent here, so refuse
+            # The static forward state AND the outputs of a capture belong to its LATEST replay: a backward of an earlier
+            # call (gradient accumulation over two forwards, retain_graph, an eval render in between) would use the later
+            # step's state. Re-running the forward eagerly could restore the state, but not the OUTPUT tensors the caller's
+            # loss saved for its own backward (they are the capture's static tensors, overwritten as well): the upstream
+            # gradient would be computed from the wrong image. So: refuse. Callers with this pattern use the module whose
+            # outputs are the caller's own -- GaussianRasterizerViews, or GaussianRasterizer with GSR_DROPIN_GRAPHS=1
+            # (dropin.py: outputs copied out, state leased until the backward) -- INTEGRATION.md section 5b.
             raise RuntimeError(
                 "CapturedViews: backward of a forward whose captured state has been overwritten by a later forward "
                 f"(replay {ctx.generation}, now {cap.generation}); run backward before the next forward of the same "
@@ -109,6 +114,7 @@ class CapturedViews(torch.nn.Module):
         self._warm = 0
         self._staged = False        # inputs copied into static buffers owned by the capture (see _forward)
         self._ptr_misses = 0
+        self._ptr_repeats, self._last_ptr_sig = 0, None
         self._peak_n = 0
         self._fwd_mode = 0
         self.stats = dict(captures=0, replays=0, eager_steps=0, overflows=0, staged_inputs=False)
@@ -154,7 +160,16 @@ class CapturedViews(torch.nn.Module):
         # STAGED instead: copied into static buffers owned by the capture (one fused copy, 236 B per Gaussian at K = 16)
         # and the capture is keyed on shapes only.
         shape_sig = _sig(settings_list, persistent, rc, per_view, by_ptr=False) + (tuple(scales.shape),)
-        sig = shape_sig if self._staged else _sig(settings_list, persistent, rc, per_view) + (tuple(scales.shape),)
+        ptr_sig = _sig(settings_list, persistent, rc, per_view) + (tuple(scales.shape),)
+        if self._staged:
+            # staging is not for ever: a caller that has settled on persistent tensors (the same addresses for
+            # PTR_REPEATS_TO_UNSTAGE calls in a row) goes back to the zero-copy capture keyed on addresses
+            self._ptr_repeats = self._ptr_repeats + 1 if ptr_sig == self._last_ptr_sig else 0
+            self._last_ptr_sig = ptr_sig
+            if self._ptr_repeats >= PTR_REPEATS_TO_UNSTAGE:
+                self._staged, self._ptr_misses, self._ptr_repeats = False, 0, 0
+                self.stats["staged_inputs"] = False
+        sig = shape_sig if self._staged else ptr_sig
         cap = self._cap
         if cap is None or cap.sig != sig:
             if cap is not None and not self._staged and cap.shape_sig == shape_sig:
@@ -308,7 +323,8 @@ class CapturedViews(torch.nn.Module):
         with torch.cuda.device(dev):
             # run it once eagerly: allocates the result tensors (kept as the static ones) and validates the arguments
             o = R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
-                                               accumulate=rc.accumulate, stats=None, per_view_scales=per_view)
+                                               accumulate=rc.accumulate, stats=None, per_view_scales=per_view,
+                                               private_scratch=True)
             torch.cuda.synchronize(dev)
             with torch.cuda.graph(cap.gC, pool=cap.gF.pool(), capture_error_mode="thread_local"):
                 R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,

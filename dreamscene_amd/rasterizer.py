@@ -526,12 +526,29 @@ class _Scratch:
     per-Gaussian sums K7 adds to) and `reach` [V, (P+63)//64] int64 (one bit per Gaussian K7 marked) are ALL ZERO whenever no backward is
     in flight -- K8 zeroes what it consumed -- so a step launches no clear (96 MB of stores + as many of loads at 500 k
     Gaussians x 4 views). `dirty` guards the invariant: set while a call is being enqueued, cleared when it returned OK."""
-    __slots__ = ("partials", "reach", "dirty")
+    __slots__ = ("partials", "reach", "dirty", "lock")
 
     def __init__(self, V, P, dev):
         self.partials = torch.zeros((V, max(P, 1), L.GSR_PARTIAL_WORDS), dtype=torch.float32, device=dev)
         self.reach = torch.zeros((V, (max(P, 1) + 63) // 64), dtype=torch.int64, device=dev)
         self.dirty = False
+        # held from _scratch_acquire until the K7 / K8 pair that uses the buffers has been ENQUEUED (_scratch_release): two
+        # host threads on one stream cannot interleave K7(A), K7(B), K8(A) on the same sums
+        self.lock = threading.Lock()
+
+    def begin(self):
+        """Exclusive use for one enqueue; re-zeroed first if a previous call failed half-way (dirty)."""
+        self.lock.acquire()
+        if self.dirty:
+            self.partials.zero_()
+            self.reach.zero_()
+        self.dirty = True
+        return self
+
+    def end(self, ok: bool):
+        if ok:
+            self.dirty = False
+        self.lock.release()
 
 
 _SCRATCH: "collections.OrderedDict" = collections.OrderedDict()
@@ -539,9 +556,14 @@ _SCRATCH_LOCK = threading.Lock()
 _SCRATCH_MAX = 4
 
 
-def _scratch_acquire(dev, V: int, P: int) -> _Scratch:
-    """The scratch of (device, current stream, V, P): calls on one stream are ordered, so they can share it; another
-    stream gets its own. Allocated (zeroed) on first use, re-zeroed if a previous call failed half-way."""
+def _scratch_acquire(dev, V: int, P: int, private: bool = False) -> _Scratch:
+    """The scratch of (device, current stream, V, P): calls on one stream are ordered, so they can share it; another stream
+    gets its own. Allocated (zeroed) on first use. The caller brackets its enqueue with scratch.begin() (exclusive use;
+    re-zeroes after a call that failed half-way) ... scratch.end(ok). private: a scratch of the caller's own, not from the cache (captured graphs keep theirs:
+    a replay does not pass through here, and a graph may be replayed on another stream than the one it was made on).
+    Memory that stays pinned: 128 B per Gaussian and view per cached key (up to _SCRATCH_MAX keys), e.g. 256 MB for 500 k x 4."""
+    if private:
+        return _Scratch(V, P, dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream, V, P)
     with _SCRATCH_LOCK:
         s = _SCRATCH.get(key)
@@ -551,10 +573,6 @@ def _scratch_acquire(dev, V: int, P: int) -> _Scratch:
                 _SCRATCH.popitem(last=False)
         else:
             _SCRATCH.move_to_end(key)
-            if s.dirty:
-                s.partials.zero_()
-                s.reach.zero_()
-        s.dirty = True
     return s
 
 
@@ -595,10 +613,15 @@ def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, mod
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
     stream = torch.cuda.current_stream(dev).cuda_stream
     prof = profile.handle if profile is not None else None
-    with torch.cuda.device(dev):
-        L.check(lib.gsr_backward(C.byref(st.view), C.byref(st.gauss), C.byref(st.geom), C.byref(st.binning),
-                                 C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
-    scratch.dirty = False
+    ok = False
+    scratch.begin()
+    try:
+        with torch.cuda.device(dev):
+            L.check(lib.gsr_backward(C.byref(st.view), C.byref(st.gauss), C.byref(st.geom), C.byref(st.binning),
+                                     C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
+        ok = True
+    finally:
+        scratch.end(ok)
     return o
 
 
@@ -646,10 +669,15 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
     stream = torch.cuda.current_stream(dev).cuda_stream
     prof = profile.handle if profile is not None else None
-    with torch.cuda.device(dev):
-        L.check(lib.gsr_backward(C.byref(st.view), C.byref(g), C.byref(st.geom), C.byref(st.binning),
-                                 C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
-    scratch.dirty = False
+    ok = False
+    scratch.begin()
+    try:
+        with torch.cuda.device(dev):
+            L.check(lib.gsr_backward(C.byref(st.view), C.byref(g), C.byref(st.geom), C.byref(st.binning),
+                                     C.byref(st.images), C.byref(ig), C.byref(gr), stream, prof), "gsr_backward")
+        ok = True
+    finally:
+        scratch.end(ok)
     return o
 
 
@@ -698,15 +726,20 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
             _bind_stats(grs[k], stats, P, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     prof = profile.handle if profile is not None else None
-    with torch.cuda.device(dev):
-        L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof), "gsr_backward_views")
-    scratch.dirty = False
+    ok = False
+    scratch.begin()
+    try:
+        with torch.cuda.device(dev):
+            L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof), "gsr_backward_views")
+        ok = True
+    finally:
+        scratch.end(ok)
     return dict(dL_dmeans2D=m2d[:, :P], model_grads=outs)
 
 
 def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=None, accumulate: bool = False,
                                  stats=None, stats_views=None, per_view_scales: Optional[bool] = None,
-                                 profile=None, reuse: Optional[dict] = None) -> dict:
+                                 profile=None, reuse: Optional[dict] = None, private_scratch: bool = False) -> dict:
     """Backward of several views of the same Gaussians through gsr_backward_views: K7 per view, one K8 pass over all
     views. Returns the SUMMED parameter gradients (written to / added to the arena's views when given) and the per-view
     means2D gradients [V,P,3]. per_view_scales (default: whether the views' scales are different tensors): every view has
@@ -745,8 +778,9 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
             o["dL_dscales"] = torch.empty((V, P, 3), dtype=f32, device=dev)
         m2d = torch.empty((V, max(P, 1), 3), dtype=f32, device=dev)
         # (a reused dict -- graph capture -- keeps the scratch of the call that made it: static addresses, and the
-        #  captured K7 / K8 pair maintains the all-zero invariant like an eager one)
-        scratch = _scratch_acquire(dev, V, P)
+        #  captured K7 / K8 pair maintains the all-zero invariant like an eager one; private_scratch: that call asks for a
+        #  scratch of its own instead of the cached one eager calls share)
+        scratch = _scratch_acquire(dev, V, P, private=private_scratch)
     views = (L.GsrView * V)(*[st.view for st in states])
     gauss = (L.GsrGaussians * V)(*[st.gauss for st in states])
     geoms = (L.GsrGeom * V)(*[st.geom for st in states])
@@ -776,10 +810,15 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
             _bind_stats(grs[k], stats, P, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     prof = profile.handle if profile is not None else None
-    with torch.cuda.device(dev):
-        L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof),
-                "gsr_backward_views")
-    scratch.dirty = False
+    ok = False
+    scratch.begin()        # (a reused dict's scratch as well: same exclusivity, same re-zeroing after a failed call)
+    try:
+        with torch.cuda.device(dev):
+            L.check(lib.gsr_backward_views(V, views, gauss, geoms, bins, imgs, igs, grs, stream, prof),
+                    "gsr_backward_views")
+        ok = True
+    finally:
+        scratch.end(ok)
     o["dL_dmeans2D"] = m2d[:, :P]
     o["_m2d"], o["_scratch"] = m2d, scratch
     return o

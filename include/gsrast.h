@@ -174,7 +174,12 @@ typedef struct GsrImages {
   float* ckpt;            /* [n_pairs/256 + 1][6][256] per-pixel prefix state (T, C rgb, depth, alpha) at the 256-entry
                              boundaries of the tile lists (slot = absolute list position / 256), written by the
                              forward as far as it composites, read by the backward                                 */
-  float* important_score; /* [P] zero-initialised by the caller, or NULL (score_flag False)   */
+  float* important_score; /* [P], or NULL (score_flag False). MUST BE ALL ZERO ON ENTRY: K6 adds to it. score_mode 1: float
+                             sums (several views may add into one buffer); score_mode 2: u32 pixel counts (bit patterns; several
+                             views may add into one buffer, the caller converts); score_mode 0: u32 counts converted IN PLACE
+                             to opacity x count at the end of the call -- one buffer per view (views of one batched call that
+                             share a buffer are refused with GSR_EINVAL: the second conversion would read the first one's
+                             floats as counts)                                                                             */
 } GsrImages;
 
 typedef struct GsrImageGrads {

@@ -202,3 +202,41 @@ def test_backward_of_an_overwritten_replay_is_refused(built_lib):
         loss_first.backward()
     sum(img.sum() for img, _, _ in second).backward()       # the latest forward still differentiates
     assert rast.stats["captures"] == 1
+
+
+def test_staged_inputs_go_back_to_zero_copy_when_addresses_settle(built_lib):
+    """`_staged` used to be sticky. A caller that first hands over fresh tensors (staging kicks in) and then
+    settles on persistent ones gets the zero-copy capture (keyed on addresses) back after PTR_REPEATS_TO_UNSTAGE calls."""
+    from dreamscene_amd import synth
+    from dreamscene_amd.graph import CapturedViews, PTR_MISSES_TO_STAGE, PTR_REPEATS_TO_UNSTAGE, WARM_CALLS
+    V, P, H, W, K, D = 2, 2000, 96, 128, 4, 1
+    g, raw = _setup(P, H, W, K, seed=33)
+    cams = synth.object_cameras(4, H, W, radius=3.0)
+    sets = [settings_for(cams[k], [1, 1, 1], D, DEV) for k in range(V)]
+    gis = [torch.tensor(synth.upstream_grads(H, W, seed=k)[0], device=DEV) for k in range(V)]
+    gdas = [torch.tensor(synth.upstream_grads(H, W, seed=k)[1], device=DEV) for k in range(V)]
+    rast = CapturedViews()
+    keep = []
+
+    def step(t):
+        m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+        outs = rast(sets, means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                    rotations=t["rotations"])
+        leaves = [t[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+        grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [m2d],
+                                    [y for k in range(V) for y in (gis[k], gdas[k])])
+        return [tuple(x.clone() for x in o) for o in outs], [x.clone() for x in grads]
+    for s_ in range(WARM_CALLS + PTR_MISSES_TO_STAGE + 2):          # fresh tensors every call -> staged
+        t = {k: (v.detach() + 0.0).requires_grad_(True) for k, v in raw.items()}
+        keep.append(t)
+        step(t)
+    assert rast.stats["staged_inputs"] is True
+    fixed = {k: (v.detach() + 0.0).requires_grad_(True) for k, v in raw.items()}
+    ref_outs, ref_grads = _eager(sets, fixed, gis, gdas)
+    for s_ in range(PTR_REPEATS_TO_UNSTAGE + 3):                     # the same tensors call after call -> zero-copy again
+        outs, grads = step(fixed)
+        for (img, radii, da), (rimg, rradii, rda) in zip(outs, ref_outs):
+            assert torch.equal(radii, rradii) and torch.equal(img, rimg) and torch.equal(da, rda), s_
+        for a, b in zip(grads, ref_grads):
+            assert tol_ok(a.reshape(b.shape).cpu().numpy(), b.cpu().numpy(), atol=2e-6), s_
+    assert rast.stats["staged_inputs"] is False, rast.stats

@@ -112,3 +112,42 @@ def test_scene_forms_clear_the_scratch_behind_them(built_lib):
         else:
             for a, b in zip(grads, ref):      # (run-to-run: the order of K7's fp32 atomics)
                 assert float(np.abs(a - b).max()) <= 1e-5 * max(1.0, float(np.abs(b).max()))
+
+
+def test_a_failed_enqueue_releases_the_scratch_and_the_next_call_rezeroes_it(built_lib, monkeypatch):
+    """the persistent K7 -> K8 scratch is locked for the length of one enqueue (two host threads on a stream must
+    not interleave K7(A), K7(B), K8(A)); a call that raises half-way releases the lock, leaves the scratch flagged dirty, and
+    the next call zeroes it before use."""
+    from dreamscene_amd import rasterizer as R, synth, _lib as L
+    dev = torch.device(DEV)
+    P, H, W, K, D = 1500, 96, 96, 16, 3
+    g, _ = small_scene(P=P, H=H, W=W, K=K, seed=17)
+    cam = synth.object_cameras(2, H, W, radius=3.0)[1]
+    t = {k: torch.tensor(v, device=dev) for k, v in g.items()}
+    s = settings_for(cam, [1, 1, 1], D, dev)
+    gi, gda = (torch.tensor(x, device=dev) for x in synth.upstream_grads(H, W, 0))
+
+    def backward():
+        out, st = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None)
+        return R.rasterize_backward_raw(st, gi, gda)
+    ref = backward()
+    torch.cuda.synchronize()
+    sc = next(iter(R._SCRATCH.values()))
+    real_check = L.check
+
+    def failing_check(code, what):
+        if what == "gsr_backward":
+            sc.partials.fill_(3.0)              # (what a half-enqueued K7 would leave behind)
+            raise L.GsrError("injected failure")
+        return real_check(code, what)
+    monkeypatch.setattr(R.L, "check", failing_check)
+    with pytest.raises(L.GsrError):
+        backward()
+    monkeypatch.setattr(R.L, "check", real_check)
+    assert sc.dirty and not sc.lock.locked()
+    again = backward()
+    torch.cuda.synchronize()
+    assert not sc.dirty and not sc.lock.locked()
+    for k in ("dL_dmeans3D", "dL_dshs", "dL_dscales", "dL_drotations", "dL_dopacities"):
+        assert torch.equal(ref[k], again[k]), k
+    assert int(torch.count_nonzero(sc.partials)) == 0
