@@ -132,7 +132,8 @@ def test_a_failed_enqueue_releases_the_scratch_and_the_next_call_rezeroes_it(bui
         return R.rasterize_backward_raw(st, gi, gda)
     ref = backward()
     torch.cuda.synchronize()
-    sc = next(iter(R._SCRATCH.values()))
+    sc = list(R._SCRATCH.values())[-1]              # (most recently used: this call's)
+    assert sc.partials.shape[:2] == (1, P)
     real_check = L.check
 
     def failing_check(code, what):
