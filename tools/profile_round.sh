@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --rotate-seconds 0 $*"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --rotate-seconds 0 --train-seconds 0 $*"
 T="timeout 420"
 $T rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 $T rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- $BENCH --no-roofline > $OUT/pmc_fetch.log 2>&1

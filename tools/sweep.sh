@@ -6,7 +6,7 @@ OUT=gpurun_out/${TAG}_sweep.jsonl
 mkdir -p gpurun_out; : > $OUT
 for P in 100000 500000 1000000 2000000; do
   for R in 512 800 1024; do
-    timeout 240 python bench.py --no-cpu-baseline --steps 60 --warmup 10 --rotate-seconds 0 --sustain-seconds 1 --gaussians $P --res $R 2>/dev/null | tail -1 >> $OUT
+    timeout 240 python bench.py --no-cpu-baseline --steps 60 --warmup 10 --rotate-seconds 0 --train-seconds 0 --sustain-seconds 1 --gaussians $P --res $R 2>/dev/null | tail -1 >> $OUT
     tail -1 $OUT | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['config']['gaussians'], d['config']['resolution'][0], d['value'], 'dropin', d['dropin_views_per_s'], d['config']['batched_through'][:22], r['kernel'], r['frac'], (r.get('valu') or {}).get('issue_frac'))"
   done
 done
