@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/$1; mkdir -p $O; shift
 cd /tmp && export TMPDIR=/tmp
 for v in new "$@"; do
   if [ $v = new ]; then unset GSR_LIB; else export GSR_LIB=$ROOT/dreamscene_amd/libgsrast_$v.so; fi
-  timeout 200 rocprofv3 --kernel-trace --stats -d $O/t_$v -o trace -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin --sustain-seconds 0 --rotate-seconds 0 --no-roofline $BENCH_ARGS > $O/t_$v.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --stats -d $O/t_$v -o trace -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin --sustain-seconds 0 --rotate-seconds 0 --no-roofline --train-seconds 0 $BENCH_ARGS > $O/t_$v.log 2>&1
   python $ROOT/tools/kstats.py $O/t_$v 2>/dev/null | grep -E "preprocess|render_bwd |steps" | sed "s/^/$v: /"
   rm -rf $O/t_$v
 done
