@@ -18,6 +18,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.util import same_bits
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-5
 
@@ -111,7 +113,7 @@ def test_hip_replays_the_record(built_lib, c_oracle, name):
     for rep in range(7):
         _, _, _, again = _hip_replay(c, up_img, up_da)
         for k in got:
-            assert np.array_equal(got[k], again[k]), f"{k}: run {rep + 1} differs from run 0 (the backward must be bit-reproducible)"
+            same_bits(got[k], again[k], f"{k}: run {rep + 1} vs run 0")
     # the same record with the spike pixels clipped: the usual bar
     cl_img, cl_da = np.clip(up_img, -50.0, 50.0), np.clip(up_da, -50.0, 50.0)
     _, _, _, got = _hip_replay(c, cl_img, cl_da)

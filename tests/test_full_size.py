@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import oracle_view, settings_for
+from tests.util import oracle_view, same_bits, settings_for
 
 pytestmark = pytest.mark.gpu
 
@@ -167,7 +167,7 @@ def test_backward_is_bit_reproducible(built_lib, name):
             assert all(float(v.abs().max()) > 0 for v in got.values())
         else:
             for k in first:
-                assert torch.equal(first[k], got[k]), f"{name}: {k} differs between run 0 and run {rep}"
+                same_bits(first[k], got[k], f"{name}: {k}, run {rep} vs run 0")
         del out, st, o
 
 
