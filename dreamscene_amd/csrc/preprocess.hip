@@ -1588,7 +1588,11 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
     else if constexpr (REACHED) mk_nx = (uint32_t)((vmask[vv][entry >> 6] >> (entry & 63)) & 1ull);
     else mk_nx = ok ? (uint32_t)((vb.reach[vv][i >> 6] >> (i & 63)) & 1ull) : 0u;
     if constexpr (REACHED) {
-      if (ok) p_nx = partial_load(vb.partials[vv], i);
+      // (only the views that MARKED the Gaussian: a listed Gaussian is reached by 1.3 of the 4 views of a step on average, and
+      //  a row is 96 bytes since the sums are doubles -- round 3 loaded the 48-byte rows of all views unconditionally. The mark
+      //  comes from the LDS copy of K7's bit words: no memory round trip in front of the load)
+      if (ok && mk_nx) p_nx = partial_load(vb.partials[vv], i);
+      else p_nx = partial_none();
     }
   };
   // every request of the round goes out before anything is consumed: one memory latency, not four
