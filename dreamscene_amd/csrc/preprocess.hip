@@ -1693,8 +1693,13 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       if (vb.restore && vb.reach[0] && ok && (i & 63) == 0) vb.reach[vv][i >> 6] = 0ull;
     }
     const bool vis = ok && (rad_v > 0);
+    // A view that SAW the Gaussian but composited nothing of it (no mark: its ten K7 sums are zero) contributes exact zeros
+    // to every output: its chain rule -- ~1 400 dependent instructions -- is skipped (round 4; a listed Gaussian is marked by
+    // 1.3 of the 4 views of a step on average at C3, and the kernel is bound by that dependent chain). What does not depend
+    // on the sums still happens below: the visibility statistics, the zero rows of dL/dmeans2D and of per-view scales.
+    const bool work = vis && take;
     float gndx = 0.f, gndy = 0.f;
-    if (vis) {
+    if (work) {
       ViewConst vc;
       load_view_const(vb.viewmatrix[vv], vb.projmatrix[vv], vb.campos[vv], vc);
       const ViewDyn vd = view_dyn(vb.dyn[vv], vb.tanfovx[vv], vb.tanfovy[vv], vb.sh_degree[vv]);
@@ -1703,13 +1708,12 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       const float fx = (float)W / (2.0f * tfx), fy = (float)H / (2.0f * tfy);
       const float limx = 1.3f * tfx, limy = 1.3f * tfy;
       if constexpr (!REACHED) {
-        if (take) partial_rows(partial_load(vb.partials[vv], i), pa, pb, pc);
+        partial_rows(partial_load(vb.partials[vv], i), pa, pb, pc);
       } else {
         partial_rows(p_cur, pa, pb, pc);
       }
-      if (!take) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; pc = pa; }
       pc.x += pc.z; pc.y += pc.w;      // (K7 commits the last two sums from the two halves of a wave: render.hip, reduce10)
-      if (take && vb.restore) partial_zero(vb.partials[vv], i);     // GsrGrads.scratch_clean: leave the scratch as it was found
+      if (vb.restore) partial_zero(vb.partials[vv], i);     // GsrGrads.scratch_clean: leave the scratch as it was found
       gop += pb.y;
       const float grgb[3] = {pb.z, pb.w, pc.x};
       // (1) colour -> SH coefficients, view direction
@@ -1774,16 +1778,16 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
 #pragma unroll
         for (int k = 0; k < 9; ++k) dS[k] += dSv[k];
       }
-      if (out.stat_denom && ((vb.stat_mask >> vv) & 1u)) {
-        out.stat_xyz_gradient_accum[i] += sqrtf(gndx * gndx + gndy * gndy);
-        out.stat_denom[i] += 1.0f;
-        out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)rad_v);
-      }
+    }
+    if (vis && out.stat_denom && ((vb.stat_mask >> vv) & 1u)) {
+      out.stat_xyz_gradient_accum[i] += sqrtf(gndx * gndx + gndy * gndy);
+      out.stat_denom[i] += 1.0f;
+      out.stat_max_radii2D[i] = fmaxf(out.stat_max_radii2D[i], (float)rad_v);
     }
     if (ok) {
       float* m2 = vb.dL_dmeans2D[vv];
       m2[3 * i] = gndx; m2[3 * i + 1] = gndy; m2[3 * i + 2] = 0.f;
-      if (PVS && !vis) {
+      if (PVS && !work) {
         float* o = vb.dL_dscales[vv];
         o[3 * i] = 0.f; o[3 * i + 1] = 0.f; o[3 * i + 2] = 0.f;
       }
