@@ -243,3 +243,55 @@ def test_full_size_properties(built_lib, name):
     culled = out["radii"] == 0
     for k in names:
         assert float(b1[k][culled].abs().max() if bool(culled.any()) else 0.0) == 0.0, f"{k} of culled Gaussians"
+
+
+@pytest.mark.parametrize("name,n_views", [("C4", 8), ("C5", 4)])
+def test_multi_view_sum_at_full_size_equals_the_oracle_sum(built_lib, c_oracle, name, n_views):
+    """BASELINE.json configs[3] / [4] are multi-GPU: 8 cameras @800^2 one per GPU (C4), the 2 M indoor scene with 4 cameras on 4
+    GPUs (C5), the per-view parameter gradients summed by one all-reduce. What that all-reduce has to deliver is the SUM over
+    the step's views (training/object_trainer.py:302-382); here all views of the configuration go through ONE batched call
+    on one GPU, summed on the device into the GradArena (K8's accumulate form -- the buffer the exchange works on), and the
+    arena is compared with the sum of the oracle's per-view gradients: every view of C4 / C5 at full size, not the one or two
+    cameras of test_full_size_vs_oracle; per-view images and radii against the oracle as well."""
+    from dreamscene_amd import multiview, synth
+    from dreamscene_amd.rasterizer import RasterContext
+    from dreamscene_amd.views import GaussianRasterizerViews
+    cfg = dict(CONFIGS[name], cams=list(range(n_views)))
+    g, cams = _scene(cfg)
+    P, K, D = g["means3D"].shape[0], cfg["K"], cfg["D"]
+    bg = np.array([1.0, 1.0, 1.0], np.float32)
+    params = {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in g.items()}
+    ups = [_upstream(cfg, cam.image_height, cam.image_width, i) for i, cam in enumerate(cams)]
+    arena = multiview.GradArena(P, K, torch.device(DEV))
+    sl = [settings_for(cam, bg, D, DEV) for cam in cams]
+    rast = GaussianRasterizerViews(sl, context=RasterContext(grad_arena=arena))
+    for rep in range(2):                # (the first call of a new (P, H, W) runs view by view and learns the pair counts)
+        m2d = torch.zeros((n_views, P, 3), device=DEV, requires_grad=True)
+        outs = rast(means3D=params["means3D"], means2D=m2d, opacities=params["opacities"], shs=params["shs"],
+                    scales=params["scales"], rotations=params["rotations"])
+        ts, gs = [], []
+        for (img, _, da), (gi, gda) in zip(outs, ups):
+            ts += [img, da]
+            gs += [torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV)]
+        (g2d,) = torch.autograd.grad(ts, [m2d], gs)
+        torch.cuda.synchronize()
+    ref = {k: None for k in ("dL_dmeans3D", "dL_dshs", "dL_dopacity", "dL_dscales", "dL_drotations")}
+    for j, cam in enumerate(cams):
+        v = oracle_view(c_oracle, cam, P, K, D, bg)
+        f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        b = c_oracle.backward(v, f, ups[j][0], ups[j][1], g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        assert np.array_equal(outs[j][1].cpu().numpy(), f["radii"]), f"view {j}: radii"
+        fr, mx = _frac_over(outs[j][0].detach().cpu().numpy(), f["image"])
+        assert mx <= TOL and fr <= OUTLIERS, f"view {j}: image {mx:.2e}"
+        fr, mx = _frac_over(g2d[j].cpu().numpy(), b["dL_dmeans2D"])
+        assert mx <= TOL and fr <= OUTLIERS, f"view {j}: dL/dmeans2D {mx:.2e}"
+        for k in ref:
+            x = np.asarray(b[k], dtype=np.float64)
+            ref[k] = x if ref[k] is None else ref[k] + x
+        del f, b
+    got = dict(dL_dmeans3D=arena.views["means3D"], dL_dshs=arena.views["shs"], dL_dopacity=arena.views["opacities"],
+               dL_dscales=arena.views["scales"], dL_drotations=arena.views["rotations"])
+    for k, r in ref.items():
+        fr, mx = _frac_over(got[k].cpu().numpy().reshape(r.shape), r)
+        print(f"[{name} sum of {n_views} views] {k}: {mx:.1e}")
+        assert mx <= TOL and fr <= OUTLIERS, f"{name}: sum over {n_views} views of {k}: max {mx:.2e} ({fr:.1e} of the entries beyond 1e-5)"
