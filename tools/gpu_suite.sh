@@ -17,5 +17,5 @@ except Exception as e:
     print("no bench line:", e)
 PY
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin > $O/trace.log 2>&1
-python $ROOT/tools/kstats.py $O/trace > $O/kernel_stats.txt 2>&1; head -40 $O/kernel_stats.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin --sustain-seconds 0 --rotate-seconds 0 --train-seconds 0 > $O/trace.log 2>&1
+python $ROOT/tools/kstats.py $O/trace > $O/kernel_stats.txt 2>&1; rm -rf $O/trace; head -40 $O/kernel_stats.txt
