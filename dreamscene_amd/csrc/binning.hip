@@ -206,9 +206,13 @@ __device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n) {
 // depth order.
 __global__ void __launch_bounds__(256)
 k_col_hist(const uint64_t* __restrict__ n_vis, const uint32_t* __restrict__ sorted_idx,
+           const uint32_t* __restrict__ sorted_idx_alt, const uint32_t* __restrict__ os_state,
            const uint32_t* __restrict__ rects, uint32_t* __restrict__ rect_sorted, const int gx, const uint32_t nrun,
            uint32_t* __restrict__ hist1, size_t bstride) {
-  n_vis = batch_ptr(n_vis, bstride); sorted_idx = batch_ptr(sorted_idx, bstride); rects = batch_ptr(rects, bstride);
+  n_vis = batch_ptr(n_vis, bstride); rects = batch_ptr(rects, bstride);
+  // the depth order is in `sorted_idx`, or -- when the last pass of the sort was the identity and moved nothing
+  // (radix_sort.h, kOsSkipFlag) -- still in the buffer that pass would have read
+  sorted_idx = batch_ptr(batch_ptr(os_state, bstride)[kOsSkipFlag] ? sorted_idx_alt : sorted_idx, bstride);
   rect_sorted = batch_ptr(rect_sorted, bstride); hist1 = batch_ptr(hist1, bstride);
   __shared__ uint32_t bins[4][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -284,10 +288,12 @@ k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restr
 // scatter of a radix pass, fused with the generation of its input. One word per pair: ty << 24 | Gaussian index.
 __global__ void __launch_bounds__(64)
 k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x, const uint32_t* __restrict__ rect_sorted,
-            const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ hist1, const uint32_t nrun,
+            const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ sorted_idx_alt,
+            const uint32_t* __restrict__ os_state, const uint32_t* __restrict__ hist1, const uint32_t nrun,
             const uint32_t* __restrict__ colstart, const uint32_t cap, uint32_t* __restrict__ vals, size_t ps, size_t ss) {
   // several views per launch (blockIdx.y): projection scratch buffers ps bytes apart, sort scratch buffers ss bytes apart
-  n_vis = batch_ptr(n_vis, ps); rect_sorted = batch_ptr(rect_sorted, ps); sorted_idx = batch_ptr(sorted_idx, ps);
+  n_vis = batch_ptr(n_vis, ps); rect_sorted = batch_ptr(rect_sorted, ps);
+  sorted_idx = batch_ptr(batch_ptr(os_state, ps)[kOsSkipFlag] ? sorted_idx_alt : sorted_idx, ps);      // (see k_col_hist)
   hist1 = batch_ptr(hist1, ps); colstart = batch_ptr(colstart, ps); vals = batch_ptr(vals, ss);
   __shared__ uint32_t col_run[256];
   __shared__ uint32_t pbase[65];
@@ -615,8 +621,11 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
     //  bit-identical -- at 108 us per view against 45 for this one: random-address global atomics run at ~25 G/s on this
     //  part (2 M keys x 3 atomics = 290 us per 4-view step), and two LDS-local radix passes over 2 M pairs cost what two
     //  one-sweep passes cost: profiles/r04_distribution_sort_kernel_stats.txt)
+    // (column path: an identity last pass -- the top byte of the depths of one object -- is not copied; k_col_hist / k_emit_cols
+    //  take the order from the buffer the flag word names)
     where = radix_sort_u32<kItemsSmall, kOsItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
-                                                       s.totals, stream, batch, bstride, /*state_cleared=*/true);
+                                                       s.totals, stream, batch, bstride, /*state_cleared=*/true,
+                                                       /*last_pass_may_skip=*/columns);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }
@@ -628,8 +637,9 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
       uint32_t* rect_sorted = where ? s.k0 : s.k1;   // the key buffer the sort result is NOT in
       const uint32_t nrun = col_runs(P);
       const uint32_t nby = (uint32_t)batch;
-      hipLaunchKernelGGL(k_col_hist, dim3((nb + 7u) / 8u * 8u, nby), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx, s.rects, rect_sorted,
-                         gx, nrun, s.hist1, bstride);
+      hipLaunchKernelGGL(k_col_hist, dim3((nb + 7u) / 8u * 8u, nby), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx,
+                         (const uint32_t*)(where ? s.v0 : s.v1), (const uint32_t*)s.hist, s.rects, rect_sorted, gx, nrun, s.hist1,
+                         bstride);
       hipLaunchKernelGGL(k_radix_scan, dim3(gx, nby), dim3(256), 0, stream, s.hist1, nrun, s.totals1,
                          (const uint64_t*)n_vis_dev, (uint32_t)kColRun, bstride);
       hipLaunchKernelGGL(k_col_plan, dim3(1, nby), dim3(256), 0, stream, s.totals1, gx, s.colstart, n_pairs_dev, bstride,
@@ -670,7 +680,8 @@ static int launch_binning_columns(int n, const GsrView& v, const GsrGeom* geoms,
     int nbits_x = 1;
     while ((1 << nbits_x) < gx) ++nbits_x;
     hipLaunchKernelGGL(k_emit_cols, dim3((nrun + 7u) / 8u * 8u, ny), dim3(64), 0, stream, n_dev_vis, gx, nbits_x, rect_sorted,
-                       geom.sorted_idx, s.hist1, nrun, s.colstart, cap, vals1, ps, ss);
+                       geom.sorted_idx, (const uint32_t*)((geom.sorted_idx == s.v0) ? s.v1 : s.v0), (const uint32_t*)s.hist,
+                       s.hist1, nrun, s.colstart, cap, vals1, ps, ss);
     GSR_HIP(hipGetLastError());
   }
   {

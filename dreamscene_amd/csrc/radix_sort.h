@@ -254,6 +254,10 @@ constexpr int kOsMaxPasses = 4;
 #endif
 constexpr uint32_t kOsHistTile = GSR_OS_HIST_TILE;  // keys per workgroup of k_os_hist
 constexpr uint32_t kOsTableOff = kOsMaxPasses * kRadix + 16;   // u32 words: [passes][256] histograms | 4 tickets (+ pad) | table
+// A pass whose digit is the same for every key is the identity; when it is the LAST pass and the caller allows it, nothing
+// is copied: this word of the state is set instead and the result stays in the buffers the pass would have read (the top
+// byte of the depths of one object: 8 us of every depth sort)
+constexpr uint32_t kOsSkipFlag = kOsMaxPasses * kRadix + 8;
 constexpr uint64_t kOsMaxN = 1ull << 28;
 
 typedef __attribute__((address_space(1))) uint32_t gsr_gu32;
@@ -364,7 +368,7 @@ template <bool IOTA, int ITEMS, bool DROP>
 __global__ void __launch_bounds__(kSortThreads)
 k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
           uint32_t* __restrict__ vals_out, const uint64_t* __restrict__ n_dev, uint64_t cap, int pass,
-          uint32_t* __restrict__ os, uint64_t* __restrict__ n_out, size_t bstride) {
+          uint32_t* __restrict__ os, uint64_t* __restrict__ n_out, size_t bstride, const int may_skip) {
   keys_in = batch_ptr(keys_in, bstride); vals_in = batch_ptr(vals_in, bstride);
   keys_out = batch_ptr(keys_out, bstride); vals_out = batch_ptr(vals_out, bstride);
   n_dev = batch_ptr(n_dev, bstride); os = batch_ptr(os, bstride); n_out = batch_ptr(n_out, bstride);
@@ -383,6 +387,11 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
     // pass take this branch, nobody waits for anybody).
     const uint32_t x = os[pass * kRadix + tid];
     if (__syncthreads_or((uint64_t)x == n && n > 0)) {
+      if (may_skip) {
+        // the LAST pass of a sort whose consumers take the result from wherever it is (kOsSkipFlag): nothing moves
+        if (blockIdx.x == 0 && tid == 0) os[kOsSkipFlag] = 1u;
+        return;
+      }
 #pragma unroll
       for (int it = 0; it < ITEMS; ++it) {
         const uint64_t e = sort_index<ITEMS>(blockIdx.x, wave, it, lane);
@@ -551,7 +560,7 @@ int radix_sort_u32_legacy(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1
 template <int ITEMS, int OS_ITEMS>
 int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
                    int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream,
-                   int batch = 1, size_t bstride = 0, bool state_cleared = false) {
+                   int batch = 1, size_t bstride = 0, bool state_cleared = false, bool last_pass_may_skip = false) {
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
   if (cap >= kOsMaxN || passes > kOsMaxPasses)
     return radix_sort_u32_legacy<ITEMS>(k0, v0, k1, v1, n_dev, cap, bits, iota, n_compact, hist, totals, stream, batch, bstride);
@@ -570,14 +579,14 @@ int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const
   for (int p = 0; p < passes; ++p) {
     if (p == 0 && drop) {
       hipLaunchKernelGGL((k_os_pass<true, OS_ITEMS, true>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap, p,
-                         hist, n_compact, bstride);
+                         hist, n_compact, bstride, 0);
       n_dev = n_compact;
     } else if (p == 0 && iota) {
       hipLaunchKernelGGL((k_os_pass<true, OS_ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap, p,
-                         hist, (uint64_t*)nullptr, bstride);
+                         hist, (uint64_t*)nullptr, bstride, 0);
     } else {
       hipLaunchKernelGGL((k_os_pass<false, OS_ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap, p,
-                         hist, (uint64_t*)nullptr, bstride);
+                         hist, (uint64_t*)nullptr, bstride, (last_pass_may_skip && p == passes - 1 && p > 0) ? 1 : 0);
     }
     uint32_t* t = ka; ka = kb; kb = t;
     t = va; va = vb; vb = t;
