@@ -123,3 +123,38 @@ def test_accumulate_flag_styles_and_bitmap_invalidation():
     arena.reached_valid = True
     multiview.render_views_data_parallel(positional, {}, [], [], arena)
     assert not arena.reached_valid and float(arena.flat.abs().sum()) == 0.0
+
+
+def test_dropin_ring_bookkeeping_without_a_gpu():
+    """dreamscene_amd/dropin.py: the captured drop-in path is opt-in, never taken for CPU tensors or ineligible inputs, and a
+    slot is leased exactly as long as the call that took it can still run a backward."""
+    import gc
+    from dreamscene_amd import dropin
+    from dreamscene_amd.rasterizer import GaussianRasterizationSettings, RasterContext
+    s = GaussianRasterizationSettings(64, 64, 0.5, 0.5, torch.ones(3), 1.0, torch.eye(4), torch.eye(4), 3, torch.zeros(3), False, False)
+    P, K = 10, 16
+    args = (torch.zeros(P, 3), torch.zeros(P, 3), torch.zeros(P, 1), torch.zeros(P, K, 3), None, torch.ones(P, 3),
+            torch.zeros(P, 4), None)
+    assert dropin.ENABLED is False                                   # (GSR_DROPIN_GRAPHS is not set under pytest)
+    assert not dropin.eligible(s, *args, None)
+    assert not dropin.eligible(s, *args, RasterContext(dropin_graphs=True))      # CPU tensors: the eager path raises its error
+    # leases
+    class Slot:
+        busy, stamp = False, 0
+    sl = Slot()
+    le = dropin._Lease(sl)
+    assert sl.busy
+    le.release()
+    assert not sl.busy
+    le2 = dropin._Lease(sl)
+    assert sl.busy
+    del le2
+    gc.collect()
+    assert not sl.busy, "a lease that dies with its autograd graph must free the slot"
+    # a context's host statistics are shared with its per-call snapshots
+    from dreamscene_amd.rasterizer import HostStats
+    hs = HostStats()
+    rc = RasterContext(host_stats=hs)
+    snap = rc.snapshot()
+    snap.host_stats.wait_s += 1.5
+    assert hs.wait_s == 1.5 and rc.snapshot().host_stats is hs
