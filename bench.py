@@ -642,7 +642,7 @@ def main():
     exch = None
     if exchange is not None:
         skip_reduce[0] = True          # this rank's own step, before any exchange: the rows ITS views reached
-        step()
+        step() if batched else step_dropin_arena()      # (the plain per-view module does not write the arena)
         skip_reduce[0] = False
         torch.cuda.synchronize(dev)
         nz = int(exchange.nonzero_rows().numel())
