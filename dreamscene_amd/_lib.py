@@ -59,7 +59,7 @@ class GsrGeom(C.Structure):
 
 class GsrBinning(C.Structure):
     _fields_ = [("point_list", _f), ("ranges", _f), ("tile_work", _f), ("bwd_items_cap", C.c_uint32),
-                ("reserved2_", C.c_uint32), ("keys_sorted", _f), ("scratch", _f), ("scratch_bytes", C.c_size_t),
+                ("seg_len", C.c_uint32), ("keys_sorted", _f), ("scratch", _f), ("scratch_bytes", C.c_size_t),
                 ("count_on_device", C.c_int32), ("fwd_mode", C.c_int32), ("stats_host", _f)]
 
 

@@ -296,7 +296,9 @@ static int check_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs,
   if (!geom || !b || !img) return GSR_EINVAL;
   if (!b->ranges || !img->color || !img->depth_alpha || !img->final_T || !img->n_contrib) return GSR_EINVAL;
   if (!b->tile_work || !img->tile_depth || !img->ckpt) return GSR_EINVAL;
-  if ((uint64_t)b->bwd_items_cap < n_pairs / 256 + gsr_num_tiles(v->image_height, v->image_width)) return GSR_EINVAL;
+  if (b->seg_len != 0u && b->seg_len != 64u && b->seg_len != 128u && b->seg_len != 256u) return GSR_EINVAL;
+  if (b->fwd_mode == 1 && gsr_seg_len(*b) != 256u) return GSR_EINVAL;     // the whole-tile forward checkpoints every 256 entries
+  if ((uint64_t)b->bwd_items_cap < n_pairs / gsr_seg_len(*b) + gsr_num_tiles(v->image_height, v->image_width)) return GSR_EINVAL;
   if (n_pairs && (!b->point_list || !geom->splat)) return GSR_EINVAL;
   if (v->P > 0 && (!geom->scratch || geom->scratch_bytes < gsr_project_scratch_bytes(v->P))) return GSR_ESCRATCH;
   if (n_pairs >= (1ull << 32)) return GSR_ECAPACITY;
@@ -358,7 +360,7 @@ int gsr_forward_render_batch(int32_t n_views, const GsrView* views, const GsrGeo
   // K6 of all views in one launch when they use the same variant / outputs
   bool uniform = true;
   for (int k = 1; k < n_views; ++k)
-    uniform = uniform && bs[k].fwd_mode == bs[0].fwd_mode &&
+    uniform = uniform && bs[k].fwd_mode == bs[0].fwd_mode && gsr_seg_len(bs[k]) == gsr_seg_len(bs[0]) &&
               (imgs[k].important_score != nullptr) == (imgs[0].important_score != nullptr) &&
               views[k].score_mode == views[0].score_mode;
   if (uniform) return gsr_launch_render_fwd_views(n_views, views, geoms, bs, imgs, stream, prof);
@@ -450,7 +452,7 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   for (int k = 0; k < n_views; ++k) {
     const int rc = check_backward(&views[k], &gs[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k]);
     if (rc) return rc;
-    if (!same_except_scales(gs[k], gs[0])) return GSR_EINVAL;
+    if (!same_except_scales(gs[k], gs[0]) || gsr_seg_len(bs[k]) != gsr_seg_len(bs[0])) return GSR_EINVAL;
     per_view_scales = per_view_scales || gs[k].scales != gs[0].scales;
     if (views[k].P != views[0].P || views[k].image_height != views[0].image_height ||
         views[k].image_width != views[0].image_width || views[k].sh_stride != views[0].sh_stride ||

@@ -5,6 +5,9 @@
 
 #include "gsrast.h"
 
+// entries per checkpoint / backward work item (GsrBinning.seg_len; 0 = 256)
+static inline uint32_t gsr_seg_len(const GsrBinning& b) { return (b.seg_len == 64u || b.seg_len == 128u) ? b.seg_len : 256u; }
+
 #define GSR_WAVE 64
 #define GSR_NEAR_Z 0.2f
 #define GSR_ALPHA_MIN (1.0f / 255.0f)

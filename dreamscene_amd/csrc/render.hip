@@ -158,6 +158,7 @@ struct WorkBwdViews {
   const uint32_t* tile_depth[GSR_MAX_BATCH_VIEWS];
   uint32_t* items[GSR_MAX_BATCH_VIEWS];
   uint32_t items_cap[GSR_MAX_BATCH_VIEWS];
+  uint32_t seg_len;
 };
 
 __global__ void __launch_bounds__(1024)
@@ -189,45 +190,47 @@ k_work_order_fwd(const uint32_t n_tiles, const WorkFwdViews wv) {
   }
 }
 
-// Backward work list: one item (tile, segment) per started 256-entry segment of [0, tile_depth[tile]), ordered
-// by decreasing number of entries (16 buckets: all the full segments first, then the partial tails longest
-// first) so that the in-order hardware dispatch does longest-first scheduling.
-// items[0] = number of items, items[2 + 2 i] = tile, items[3 + 2 i] = segment. Single workgroup.
+// Backward work list: one item (tile, segment) per started kb-entry segment of [0, tile_depth[tile]) -- kb = GsrBinning.seg_len,
+// the distance of the forward's checkpoints. Order = longest processing time first for the in-order hardware dispatch: full
+// segments by what is left of the tile's depth behind their start (r = d - kb s: the more is left, the more pixels are still
+// alive; segment 0 of a deep tile is the heaviest item there is, the last full segment of any tile the lightest), 16
+// buckets of 256 entries; then the partial tails, longest first, 16 buckets. (Round 4, one call: against "all full segments in
+// tile order, then the tails" K7 -1 % ... -2 % in every configuration and this kernel 8.8 -> 6.7 us.)
+// items[0] = number of items, items[2 + 2 i] = tile, items[3 + 2 i] = segment. Single workgroup per view.
 __global__ void __launch_bounds__(1024)
 k_work_order_bwd(const uint32_t n_tiles, const WorkBwdViews wv) {
   const uint32_t* __restrict__ tile_depth = wv.tile_depth[blockIdx.x];
   uint32_t* __restrict__ items = wv.items[blockIdx.x];
   const uint32_t items_cap = wv.items_cap[blockIdx.x];
-  __shared__ uint32_t cnt[16], cur[16];
+  const uint32_t kb = wv.seg_len;
+  __shared__ uint32_t cnt[32], cur[32];
   const int tid = threadIdx.x;
-  if (tid < 16) cnt[tid] = 0;
+  if (tid < 32) cnt[tid] = 0;
   __syncthreads();
-  // bucket b (0 = largest): full segments and tails of 241..256 entries in bucket 0, ..., 1..16 entries in 15
   for (uint32_t t = tid; t < n_tiles; t += 1024) {
     const uint32_t d = tile_depth[t];
     if (d == 0) continue;
-    const uint32_t full = d / kBatch, tail = d % kBatch;
-    if (full) atomicAdd(&cnt[0], full);
-    if (tail) atomicAdd(&cnt[15 - ((tail - 1) >> 4)], 1u);
+    const uint32_t full = d / kb, tail = d % kb;
+    for (uint32_t sgi = 0; sgi < full; ++sgi) atomicAdd(&cnt[15u - min(15u, (d - kb * sgi - 1u) >> 8)], 1u);
+    if (tail) atomicAdd(&cnt[16u + 15u - ((tail - 1u) * 16u) / kb], 1u);
   }
   __syncthreads();
   if (tid == 0) {
     uint32_t run = 0;
-    for (int b = 0; b < 16; ++b) { cur[b] = run; run += cnt[b]; }
+    for (int b = 0; b < 32; ++b) { cur[b] = run; run += cnt[b]; }
     items[0] = min(run, items_cap);
   }
   __syncthreads();
   for (uint32_t t = tid; t < n_tiles; t += 1024) {
     const uint32_t d = tile_depth[t];
     if (d == 0) continue;
-    const uint32_t full = d / kBatch, tail = d % kBatch;
-    if (full) {
-      const uint32_t base = atomicAdd(&cur[0], full);
-      for (uint32_t sgi = 0; sgi < full; ++sgi)
-        if (base + sgi < items_cap) { items[2 + 2 * (base + sgi)] = t; items[3 + 2 * (base + sgi)] = sgi; }
+    const uint32_t full = d / kb, tail = d % kb;
+    for (uint32_t sgi = 0; sgi < full; ++sgi) {
+      const uint32_t i = atomicAdd(&cur[15u - min(15u, (d - kb * sgi - 1u) >> 8)], 1u);
+      if (i < items_cap) { items[2 + 2 * i] = t; items[3 + 2 * i] = sgi; }
     }
     if (tail) {
-      const uint32_t i = atomicAdd(&cur[15 - ((tail - 1) >> 4)], 1u);
+      const uint32_t i = atomicAdd(&cur[16u + 15u - ((tail - 1u) * 16u) / kb], 1u);
       if (i < items_cap) { items[2 + 2 * i] = t; items[3 + 2 * i] = full; }
     }
   }
@@ -255,7 +258,10 @@ __device__ __forceinline__ uint32_t stage_mask(const float4& s2row) { return __f
 // 4x more (and 4x finer) work items, tighter 4x4 culling; same gates in the same list order on the same bits (the
 // transmittance is multiplied up in list order inside the quad; only the colour / depth / alpha SUMS associate
 // differently from a sequential loop, at the 1e-7 level).
-template <bool SCORE>
+// KB = distance of the checkpoints in list entries (GsrBinning.seg_len: 256, 128 or 64). The batches stay 256 entries long;
+// for KB < 256 a wave's candidate list is padded to a multiple of four at every KB boundary inside the batch, so that a
+// step never straddles one, and the state is written out when the loop reaches that point.
+template <bool SCORE, int KB>
 __device__ __forceinline__ void
 render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* __restrict__ work, float* __restrict__ ckpt,
              const uint32_t* __restrict__ ranges,
@@ -266,7 +272,7 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   // Row kBatch of every staged array is a candidate no pixel takes (opacity 0 -> alpha 0 < 1/255): the per-wave candidate
   // lists are padded with it to a multiple of four, so the compositing loop has no partial step.
   __shared__ Stage<SCORE, 1> st;
-  __shared__ uint16_t cand[4][kBatch + 4];   // per wave: the batch's candidates for its 4x4 block, in list order
+  __shared__ uint16_t cand[4][kBatch + 16];  // per wave: the batch's candidates for its 4x4 block, in list order (+ padding)
   if (threadIdx.x < 2) {
     st.s0[threadIdx.x][kBatch] = make_float4(0.f, 0.f, 0.f, 0.f);
     st.s1[threadIdx.x][kBatch] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -329,9 +335,9 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
                                     __uint_as_float((tid < n) ? block_mask_t<4>(n0, n1, n2, q_x0, q_y0) : 0u));
       if constexpr (SCORE) st.sid[buf][tid] = nid;
       if (__syncthreads_count(__builtin_amdgcn_inverse_ballot_w64(donem)) == 256) break;
-      if (base != r0) {
-        // checkpoint of the per-pixel prefix state at this batch boundary: lets the backward start a traversal
-        // at any multiple of 256 list entries (k_render_bwd splits deep tiles into independent segments)
+      // checkpoint of the per-pixel prefix state at list position pos (r0 + a multiple of KB): lets the backward start a
+      // traversal there (k_render_bwd splits deep tiles into independent segments of KB entries)
+      auto checkpoint = [&](const uint32_t pos) {
         float f0 = C0, f1 = C1, f2 = C2, f3 = Dp, f4 = Wt;       // folds over the slots (row_ror:4, :8): all lanes take part
         f0 += gsr_dpp<0x124>(f0); f0 += gsr_dpp<0x128>(f0);
         f1 += gsr_dpp<0x124>(f1); f1 += gsr_dpp<0x128>(f1);
@@ -339,12 +345,13 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
         f3 += gsr_dpp<0x124>(f3); f3 += gsr_dpp<0x128>(f3);
         f4 += gsr_dpp<0x124>(f4); f4 += gsr_dpp<0x128>(f4);
         if (slot == 0 && inside) {
-          // slot = absolute list position / 256: boundaries of one list are 256 apart and the first boundary of
-          // a tile lies >= 256 entries after the end of the previous tile's list, so slots never collide
-          float* ck = ckpt + (size_t)(base / kBatch) * (6 * 256) + ((py - ty * GSR_TILE) * GSR_TILE + (px - tx * GSR_TILE));
+          // slot = absolute list position / KB: boundaries of one list are KB apart and the first boundary of a tile lies
+          // >= KB entries after the end of the previous tile's list, so slots never collide
+          float* ck = ckpt + (size_t)(pos / KB) * (6 * 256) + ((py - ty * GSR_TILE) * GSR_TILE + (px - tx * GSR_TILE));
           ck[0] = T; ck[256] = f0; ck[512] = f1; ck[768] = f2; ck[1024] = f3; ck[1280] = f4;
         }
-      }
+      };
+      if (base != r0) checkpoint(base);
       {
         const uint32_t idx = base + kBatch + tid;
         if (idx < r1) {
@@ -357,19 +364,35 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       // order into a byte list of its own: the compositing loop then reads "its" candidate with one LDS load instead
       // of peeling four bits off a 64-bit scalar mask per step, and only the last step of a batch can be partial
       int cnt = 0;
+      int cut_at[3] = {-1, -1, -1};        // step index of the KB boundaries inside the batch (KB < 256)
+#pragma unroll
       for (int k = 0; k < kBatch / 64; ++k) {
         if (k * 64 >= n) break;
         const bool m = (stage_mask(st.s2[buf][k * 64 + lane]) >> wave) & 1u;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(m);
         if (m) cand[wave][cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint8_t)(k * 64 + lane);
         cnt += (int)__popcll(bal);
+        if constexpr (KB < kBatch) {
+          if (((k + 1) * 64) % KB == 0 && k + 1 < kBatch / 64 && (k + 1) * 64 < n) {
+            const int pad = (-cnt) & 3;
+            if (lane < pad) cand[wave][cnt + lane] = (uint16_t)kBatch;
+            cnt += pad;
+            cut_at[(k + 1) * 64 / KB - 1] = cnt;
+          }
+        }
       }
       if (lane < 3) cand[wave][cnt + lane] = (uint16_t)kBatch;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       {
-        for (int i = 0; i < cnt; i += 4) {
-          if (donem == ~0ull) break;
+        for (int i = 0;; i += 4) {
+          if (donem == ~0ull) break;       // (no pixel of the wave composites any further: nobody reads its checkpoints)
+          if constexpr (KB < kBatch) {
+#pragma unroll
+            for (int c = 0; c < kBatch / KB - 1; ++c)
+              if (i == cut_at[c]) checkpoint(base + (uint32_t)((c + 1) * KB));
+          }
+          if (i >= cnt) break;
           const int j = (int)cand[wave][i + slot];
           const float4 a = st.s0[buf][j];
           const float4 b = st.s1[buf][j];
@@ -680,6 +703,7 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 //    free, the loop is bound by instruction issue);
 //  * the launch zero-filling the 142 MB of gradient buffers K8's sparse form otherwise clears itself ("K7 is VALU-bound,
 //    the stores are free"): K8 100 -> 86 us, K7 236 -> 274 us. The stores are not free: K7's atomics share the path.
+template <int KB>
 __device__ __forceinline__ void
 render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* __restrict__ items, const uint32_t* __restrict__ tile_depth,
              const float* __restrict__ ckpt,
@@ -688,9 +712,9 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
              const float* __restrict__ depth_alpha, const float* __restrict__ final_T,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
              const float* __restrict__ dL_dda, float* __restrict__ partials, unsigned long long* __restrict__ reach) {
-  __shared__ float4 s0[kBatch], s1[kBatch], s2[kBatch];
-  __shared__ uint32_t sid[kBatch], smask[kBatch];
-  __shared__ unsigned long long hitw[kBatch / 64];    // staged entries some wave committed sums for (-> GsrGrads.reach)
+  __shared__ float4 s0[KB], s1[KB], s2[KB];
+  __shared__ uint32_t sid[KB], smask[KB];
+  __shared__ unsigned long long hitw[KB / 64];    // staged entries some wave committed sums for (-> GsrGrads.reach)
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (item >= items[0]) return;
@@ -698,7 +722,7 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   const int tile = (int)items[2 + 2 * item];
   const uint32_t seg = items[3 + 2 * item];
   const uint32_t depth = tile_depth[tile];
-  const uint32_t lo = seg * kBatch, hi = min(lo + (uint32_t)kBatch, depth);
+  const uint32_t lo = seg * KB, hi = min(lo + (uint32_t)KB, depth);
   const int n = (int)(hi - lo);
 
   const TilePix p = tile_pixel(tile, gx, W, H);
@@ -725,12 +749,14 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       const float4* r = splat + 3 * (size_t)nid;
       n0 = r[0]; n1 = r[1]; n2 = r[2];
     }
-    s0[tid] = make_float4(n0.x, n0.y, -0.5f * n0.z, -n0.w);              // conic staged as (hA, nB, hC)
-    s1[tid] = make_float4(-0.5f * n1.x, n1.y, n1.z - zref, n1.w);
-    s2[tid] = n2;
-    sid[tid] = nid;
-    smask[tid] = (tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u;
-    if (tid < kBatch / 64) hitw[tid] = 0ull;
+    if (tid < KB) {                                                        // (256 threads, KB <= 256 staged rows)
+      s0[tid] = make_float4(n0.x, n0.y, -0.5f * n0.z, -n0.w);            // conic staged as (hA, nB, hC)
+      s1[tid] = make_float4(-0.5f * n1.x, n1.y, n1.z - zref, n1.w);
+      s2[tid] = n2;
+      sid[tid] = nid;
+      smask[tid] = (tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u;
+    }
+    if (tid < KB / 64) hitw[tid] = 0ull;
   }
 
   const float Tf = p.inside ? final_T[pix] : 0.f;
@@ -747,7 +773,7 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   float R = 0.f, A = 0.f;
   if (last > hi) {
     // this pixel keeps compositing beyond the segment: start from the forward's checkpoint at position hi
-    const float* ck = ckpt + (size_t)((r0 + hi) / kBatch) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
+    const float* ck = ckpt + (size_t)((r0 + hi) / KB) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
     const float Tc = ck[0];
     const float inv = 1.0f / Tc;
     T = Tc;
@@ -767,7 +793,7 @@ render_bwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   const bool commit = ((lane & 3) == 0) && !(b4 && b2);                      // 8 + 4 lanes, twelve different doubles
   __syncthreads();
 
-  for (int k = 0; k < kBatch / 64; ++k) {
+  for (int k = 0; k < KB / 64; ++k) {
     if (k * 64 >= n) break;
     unsigned long long bits = __ballot((smask[k * 64 + lane] >> wave) & 1u);
     unsigned long long hitk = 0ull;       // (scalar unit: free next to the vector instructions of the other waves)
@@ -893,13 +919,13 @@ struct BwdViews {
   unsigned long long* reach[GSR_MAX_BATCH_VIEWS];
 };
 
-template <bool SCORE>
+template <bool SCORE, int KB = kBatch>
 __global__ void __launch_bounds__(256)
 k_render_fwd(const int W, const int H, const FwdViews fv, const int score_mode, const uint32_t n_views,
              const uint32_t per_view) {
   const uint32_t item = per_view ? blockIdx.x % per_view : blockIdx.x / n_views;
   const int y = (int)(per_view ? blockIdx.x / per_view : blockIdx.x - item * n_views);
-  render_fwd_body<SCORE>(item, W, H, fv.work[y], fv.ckpt[y], fv.ranges[y], fv.point_list[y], fv.splat[y], fv.bg[y],
+  render_fwd_body<SCORE, KB>(item, W, H, fv.work[y], fv.ckpt[y], fv.ranges[y], fv.point_list[y], fv.splat[y], fv.bg[y],
                          fv.out_color[y], fv.out_da[y], fv.final_T[y], fv.n_contrib[y], fv.tile_depth[y], fv.score[y],
                          score_mode);
 }
@@ -913,11 +939,12 @@ k_render_fwd_tile(const int W, const int H, const FwdViews fv, const int score_m
                               fv.out_color[y], fv.out_da[y], fv.final_T[y], fv.n_contrib[y], fv.tile_depth[y],
                               fv.score[y], score_mode);
 }
+template <int KB = kBatch>
 __global__ void __launch_bounds__(256)
 k_render_bwd(const int W, const int H, const BwdViews bv, const uint32_t n_views, const uint32_t per_view) {
   const uint32_t item = per_view ? blockIdx.x % per_view : blockIdx.x / n_views;
   const int y = (int)(per_view ? blockIdx.x / per_view : blockIdx.x - item * n_views);
-  render_bwd_body(item, W, H, bv.items[y], bv.tile_depth[y], bv.ckpt[y], bv.ranges[y], bv.point_list[y], bv.splat[y], bv.bg[y],
+  render_bwd_body<KB>(item, W, H, bv.items[y], bv.tile_depth[y], bv.ckpt[y], bv.ranges[y], bv.point_list[y], bv.splat[y], bv.bg[y],
                   bv.color[y], bv.depth_alpha[y], bv.final_T[y], bv.n_contrib[y], bv.dL_dcolor[y], bv.dL_dda[y],
                   bv.partials[y], bv.reach[y]);
 }
@@ -942,6 +969,7 @@ int gsr_launch_work_order_bwd(int n, const GsrView* views, const GsrBinning* bs,
   for (int k = 0; k < n; ++k) {
     wv.tile_depth[k] = imgs[k].tile_depth; wv.items[k] = bs[k].tile_work + tiles; wv.items_cap[k] = bs[k].bwd_items_cap;
   }
+  wv.seg_len = gsr_seg_len(bs[0]);
   hipLaunchKernelGGL(k_work_order_bwd, dim3((uint32_t)n), dim3(1024), 0, stream, tiles, wv);
   GSR_HIP(hipGetLastError());
   return GSR_OK;
@@ -985,8 +1013,11 @@ int gsr_launch_render_fwd_views(int n, const GsrView* views, const GsrGeom* geom
     if (score) hipLaunchKernelGGL(k_render_fwd_tile<true>, dim3(tiles * ny), dim3(256), 0, stream, v.image_width, v.image_height, fv, v.score_mode, ny, tiles);
     else hipLaunchKernelGGL(k_render_fwd_tile<false>, dim3(tiles * ny), dim3(256), 0, stream, v.image_width, v.image_height, fv, 0, ny, tiles);
   } else {
-    if (score) hipLaunchKernelGGL(k_render_fwd<true>, dim3(tiles * 4 * ny), dim3(256), 0, stream, v.image_width, v.image_height, fv, v.score_mode, ny, 0u);
-    else hipLaunchKernelGGL(k_render_fwd<false>, dim3(tiles * 4 * ny), dim3(256), 0, stream, v.image_width, v.image_height, fv, 0, ny, 0u);
+#define GSR_LAUNCH_K6(SC, KB) hipLaunchKernelGGL((k_render_fwd<SC, KB>), dim3(tiles * 4 * ny), dim3(256), 0, stream, v.image_width, v.image_height, fv, (SC) ? v.score_mode : 0, ny, 0u)
+    const uint32_t kb = gsr_seg_len(bs[0]);
+    if (score) { if (kb == 64) GSR_LAUNCH_K6(true, 64); else if (kb == 128) GSR_LAUNCH_K6(true, 128); else GSR_LAUNCH_K6(true, 256); }
+    else { if (kb == 64) GSR_LAUNCH_K6(false, 64); else if (kb == 128) GSR_LAUNCH_K6(false, 128); else GSR_LAUNCH_K6(false, 256); }
+#undef GSR_LAUNCH_K6
   }
   GSR_HIP(hipGetLastError());
   timer.stop();
@@ -1021,8 +1052,11 @@ int gsr_launch_render_bwd_views(int n, const GsrView* views, const GsrGeom* geom
     items_cap = bs[k].bwd_items_cap > items_cap ? bs[k].bwd_items_cap : items_cap;
   }
   GsrStageTimer timer(prof, stream, GSR_STAGE_RENDER_BWD);
-  hipLaunchKernelGGL(k_render_bwd, dim3(items_cap * (uint32_t)n), dim3(256), 0, stream, v.image_width, v.image_height, bv, (uint32_t)n,
-                     bs[0].fwd_mode == 1 ? items_cap : 0u);   // same regime switch as the forward variant
+  // (per_view: the same regime switch as the forward variant)
+#define GSR_LAUNCH_K7(KB) hipLaunchKernelGGL(k_render_bwd<KB>, dim3(items_cap * (uint32_t)n), dim3(256), 0, stream, v.image_width, v.image_height, bv, (uint32_t)n, bs[0].fwd_mode == 1 ? items_cap : 0u)
+  const uint32_t kb = gsr_seg_len(bs[0]);
+  if (kb == 64) GSR_LAUNCH_K7(64); else if (kb == 128) GSR_LAUNCH_K7(128); else GSR_LAUNCH_K7(256);
+#undef GSR_LAUNCH_K7
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }

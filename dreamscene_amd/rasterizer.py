@@ -15,6 +15,8 @@ PyTorch is used for device memory, streams and autograd plumbing only; all arith
 """
 from __future__ import annotations
 
+import os
+
 import collections
 import ctypes as C
 import dataclasses
@@ -177,9 +179,9 @@ def _align(n: int, a: int = 256) -> int:
 def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
                           rotations, cov3D_precomp, want_keys: bool = False, want_aux: bool = True,
                           mode: Optional[str] = None, scene: Optional[dict] = None,
-                          rc: Optional[RasterContext] = None):
+                          rc: Optional[RasterContext] = None, seg_len: Optional[int] = None):
     gen = _forward_steps(s, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, want_keys,
-                         want_aux, mode, scene, None, rc or DEFAULT_CONTEXT)
+                         want_aux, mode, scene, None, rc or DEFAULT_CONTEXT, seg_len=seg_len)
     try:
         next(gen)
     except StopIteration as e:
@@ -187,8 +189,29 @@ def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, 
     raise RuntimeError("unreachable: a non-batched forward does not yield")
 
 
+# GsrBinning.seg_len (include/gsrast.h): list entries per forward checkpoint = per work item of the backward. A backward item
+# is a serial recurrence over its entries (~0.3 us each on MI355X), so no launch ends before its longest item has: 65-90 us
+# with 256 entries, whatever the size of the launch. Launches with little total work (one view of the reference's per-view
+# interface, small scenes) finish sooner with 128-entry items; large ones (the 4-view step at 500 k Gaussians) are bound by
+# their total work and only pay for the extra checkpoints (K6) and item prologues (K7). Measured, round 4 (K7 / K6 / GPU time
+# per step in us, seg 256 -> 128 -> 64; profiles/HISTORY.md): one view 500 k @1024^2 92 / 51 / 370 -> 83 / 54 / 364 -> 78 / 61 /
+# 370; one view 100 k @512^2 65 / 28 / 227 -> 44 / 31 / 206 -> 36 / 35 / 207; 4 views 100 k @512^2 103 / 50 / 330 -> 88 / 54 / 321 ->
+# 83 / 58 / 323; 4 views 500 k @1024^2 222 / 168 / 807 -> 239 / 180 / 833. 64 never wins (the library supports it; the policy
+# does not pick it). The threshold is the pair CAPACITY (1.5x the recent pair count) summed over the views of the launch.
+SEG_LEN_256_FROM = 8_000_000
+
+
+def pick_seg_len(cap, n_views: int = 1) -> int:
+    env = os.environ.get("GSR_SEG_LEN")       # (tools / experiments: 64, 128 or 256 for every call)
+    if env:
+        return int(env)
+    if not cap:
+        return 256
+    return 256 if int(cap) * int(n_views) >= SEG_LEN_256_FROM else 128
+
+
 def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
-                   rotations, cov3D_precomp, want_keys, want_aux, mode, scene, batch, rc: RasterContext):
+                   rotations, cov3D_precomp, want_keys, want_aux, mode, scene, batch, rc: RasterContext, seg_len=None):
     """Generator behind rasterize_forward_raw. With batch = dict(scratch=<this view's slice of the batch's projection
     scratch>, pinned=<pinned int64 [V]>, index=k, event=<Event>) it allocates and binds, YIELDS (view struct, geom struct)
     for the caller to run gsr_forward_project_batch / gsr_forward_render_batch over all views, and continues when resumed.
@@ -295,12 +318,18 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
         proj_bytes = int(lib.gsr_project_scratch_bytes(P))
         proj_scratch = batch["scratch"] if batch is not None else ws.scratch("proj_scratch", proj_bytes)
 
+        seg_req = batch.get("seg_len") if batch is not None and batch.get("seg_len") else seg_len
+
+        def seg_of(cap):
+            return int(seg_req) if seg_req else pick_seg_len(cap, 1)
+
         def alloc_state(cap):
             """One allocation for everything the backward re-reads (splat, tile counts, offsets, lists, ranges,
             final_T, n_contrib); carved by offsets, no per-tensor allocations."""
+            seg = seg_of(cap)
             sizes = dict(splat=Pm * 48, tiles_touched=Pm * 4, block_offsets=(nb + 8) * 4, point_list=max(cap, 1) * 4,
-                         ranges=tiles * 8, tile_work=(2 * tiles + 2 + 2 * (cap // 256 + tiles)) * 4 + 64,
-                         tile_depth=tiles * 4, ckpt=(cap // 256 + 1) * 6 * 256 * 4, final_T=H * W * 4,
+                         ranges=tiles * 8, tile_work=(2 * tiles + 2 + 2 * (cap // seg + tiles)) * 4 + 64,
+                         tile_depth=tiles * 4, ckpt=(cap // seg + 1) * 6 * 256 * 4, final_T=H * W * 4,
                          n_contrib=H * W * 4,
                          keys_sorted=(max(cap, 1) * 8 if want_keys else 0))
             offs, tot = {}, 0
@@ -325,7 +354,8 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
             sort_scratch = batch["sort"](sort_bytes) if (batch is not None and on_device) else \
                 ws.scratch("sort_scratch", sort_bytes)
             b.point_list, b.ranges, b.tile_work = ptrs["point_list"], ptrs["ranges"], ptrs["tile_work"]
-            b.bwd_items_cap = cap // 256 + tiles
+            b.seg_len = seg_of(cap)
+            b.bwd_items_cap = cap // b.seg_len + tiles
             b.keys_sorted = ptrs["keys_sorted"] if want_keys else None
             b.scratch, b.scratch_bytes, b.count_on_device = sort_scratch.data_ptr(), sort_scratch.numel(), int(on_device)
             # forward variant from the PREVIOUS view's statistics (complete by now; a wrong guess only costs speed):
@@ -337,6 +367,8 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                 act = int(ws.stats_pinned[0]) if last_active is None else last_active
                 b.fwd_mode = int(rc.fwd_variant if rc.fwd_variant is not None else
                                  (act >= 2048 and last_n > 0 and last_n / max(act, 1) < 1024))
+            if b.fwd_mode == 1:
+                b.seg_len = 256      # the whole-tile forward checkpoints every 256 entries (the buffers above are large enough)
             b.stats_host = ws.stats_pinned.data_ptr()
             im.final_T, im.n_contrib, im.tile_depth = ptrs["final_T"], ptrs["n_contrib"], ptrs["tile_depth"]
             im.ckpt = ptrs["ckpt"]

@@ -69,9 +69,12 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
     batched = (1 < V <= MAX_VIEWS and same and P > 0 and rc.forward_mode == "auto" and ws.hint.get((P, H, W)) is not None
                and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24))
 
+    # one segment length for all views of the call (their backward is one launch): from the capacity the batch will use
+    seg = R.pick_seg_len(ws.hint.get((P, H, W)), V)
+
     def one_by_one():
         res = [R.rasterize_forward_raw(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp,
-                                       want_aux=want_aux, rc=rc) for k, s in enumerate(settings_list)]
+                                       want_aux=want_aux, rc=rc, seg_len=seg) for k, s in enumerate(settings_list)]
         if score_sum is not None:
             for o, _ in res:
                 if int(rc.score_mode) == 2:       # raw pixel counts: u32 bit patterns in the float32 tensors
@@ -95,7 +98,8 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
         gens = [R._forward_steps(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp, False,
                                  want_aux, None, None,
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
-                                      event=ws.event, sort=sort_of(k), synced=synced, score=score_sum, score_dirty=dirty),
+                                      event=ws.event, sort=sort_of(k), synced=synced, score=score_sum, score_dirty=dirty,
+                                      seg_len=seg),
                                  rc)
                 for k, s in enumerate(settings_list)]
         results = _drive_batch(lib, ws, gens, V, dev, stream, prof)
@@ -160,8 +164,10 @@ def _views_forward_scene(lib, settings_list, scenes, want_aux, rc):
     batched = (1 < V <= MAX_VIEWS and same and P > 0 and rc.forward_mode == "auto" and ws.hint.get((P, H, W)) is not None
                and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24) and K in (1, 4, 9, 16)
                and not any(s.score_flag for s in settings_list))
+    seg = R.pick_seg_len(ws.hint.get((P, H, W)), V)       # one segment length for the views of the call
     if not batched:
-        return [R.rasterize_forward_raw(s, None, None, None, None, None, None, None, want_aux=want_aux, scene=sc, rc=rc)
+        return [R.rasterize_forward_raw(s, None, None, None, None, None, None, None, want_aux=want_aux, scene=sc, rc=rc,
+                                        seg_len=seg)
                 for s, sc in zip(settings_list, scenes)]
     prof = rc.profile.handle if rc.profile is not None else None
     stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
@@ -173,7 +179,7 @@ def _views_forward_scene(lib, settings_list, scenes, want_aux, rc):
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
         gens = [R._forward_steps(s, None, None, None, None, None, None, None, False, want_aux, None, scenes[k],
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
-                                      event=ws.event, sort=sort_of(k), synced=synced), rc)
+                                      event=ws.event, sort=sort_of(k), synced=synced, seg_len=seg), rc)
                 for k, s in enumerate(settings_list)]
         return _drive_batch(lib, ws, gens, V, dev, stream, prof)
 

@@ -146,8 +146,13 @@ typedef struct GsrBinning {
   uint32_t* tile_work;  /* [tiles + 2 + 2*bwd_items_cap] u32: forward work list (tile ids, heaviest first) followed by
                            the number of non-empty tiles, then the backward's (tile, segment) item list; written by
                            the forward and by the backward: keep it with the saved state                          */
-  uint32_t bwd_items_cap; /* capacity of the backward item list: >= n_pairs / 256 + tiles                         */
-  uint32_t reserved2_;
+  uint32_t bwd_items_cap; /* capacity of the backward item list: >= n_pairs / seg_len + tiles                     */
+  uint32_t seg_len;       /* list entries per checkpoint of the forward = per work item of the backward: 256 (also: 0), 128
+                             or 64. A backward item is a serial recurrence over its entries, so a launch cannot end before its
+                             longest item has (256 entries: 65-90 us on MI355X); a launch with little total work (one view, a
+                             small scene) finishes sooner with shorter items, a large one pays for the extra checkpoints and
+                             prologues. Same value for the forward and the backward of a view and for all
+                             views of a batched call; fwd_mode 1 requires 256. Sizes: bwd_items_cap (above), GsrImages.ckpt */
   uint64_t* keys_sorted;/* [N] optional: receives the sorted 64-bit keys (tile<<32 | depth bits); may be NULL */
   void* scratch;        /* gsr_sort_scratch_bytes(N, tiles) bytes, 256-byte aligned                   */
   size_t scratch_bytes;
@@ -171,9 +176,9 @@ typedef struct GsrImages {
   float* final_T;         /* [H,W] transmittance after the last contributor                  */
   uint32_t* n_contrib;    /* [H,W] 1-based list position of the last contributor             */
   uint32_t* tile_depth;   /* [tiles] max of n_contrib over the tile (written by forward, read by backward) */
-  float* ckpt;            /* [n_pairs/256 + 1][6][256] per-pixel prefix state (T, C rgb, depth, alpha) at the 256-entry
-                             boundaries of the tile lists (slot = absolute list position / 256), written by the
-                             forward as far as it composites, read by the backward                                 */
+  float* ckpt;            /* [n_pairs/seg_len + 1][6][256] per-pixel prefix state (T, C rgb, depth, alpha) at the
+                             seg_len-entry boundaries of the tile lists (slot = absolute list position / seg_len;
+                             GsrBinning.seg_len), written by the forward as far as it composites, read by the backward */
   float* important_score; /* [P], or NULL (score_flag False). MUST BE ALL ZERO ON ENTRY: K6 adds to it. score_mode 1: float
                              sums (several views may add into one buffer); score_mode 2: u32 pixel counts (bit patterns; several
                              views may add into one buffer, the caller converts); score_mode 0: u32 counts converted IN PLACE

@@ -19,14 +19,14 @@ def _to_dev(g):
     return {k: torch.tensor(v, device=DEV) for k, v in g.items()}
 
 
-def _run_hip(g, cam, bg, D, score=False, want_keys=True, rc=None, **over):
+def _run_hip(g, cam, bg, D, score=False, want_keys=True, rc=None, seg_len=None, **over):
     from dreamscene_amd import rasterizer as R
     s = settings_for(cam, bg, D, DEV, score_flag=score)
     t = _to_dev(g)
     kw = dict(shs=t.get("shs"), colors_precomp=t.get("colors_precomp"), scales=t.get("scales"),
               rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"))
     out, st = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], kw["shs"], kw["colors_precomp"], kw["scales"],
-                                      kw["rotations"], kw["cov3D_precomp"], want_keys=want_keys, rc=rc)
+                                      kw["rotations"], kw["cov3D_precomp"], want_keys=want_keys, rc=rc, seg_len=seg_len)
     torch.cuda.synchronize()
     return out, st
 
@@ -199,17 +199,20 @@ def test_edge_cases(built_lib, c_oracle):
     assert err(out0["color"].cpu().numpy(), np.broadcast_to(bg[:, None, None], (3, 70, 90))) == 0.0
 
 
-def test_long_lists_multi_batch(built_lib, c_oracle):
+@pytest.mark.parametrize("seg_len", [256, 128, 64])
+def test_long_lists_multi_batch(built_lib, c_oracle, seg_len):
     """Per-tile lists of thousands of entries (many 256-splat staging rounds), early termination inside deep
     lists, and the backward starting from the tile's max contributor. Integer artefacts, n_contrib and final_T
-    bit-exact (the hard gates see identical bits, SEMANTICS.md section 4/6); float outputs within 1e-5, no allowance."""
+    bit-exact (the hard gates see identical bits, SEMANTICS.md section 4/6); float outputs within 1e-5, no allowance.
+    With every distance of the forward's checkpoints = length of the backward's work items (GsrBinning.seg_len)."""
     from dreamscene_amd import rasterizer as R, synth
     P, H, W, K, D = 60000, 192, 192, 16, 3
     g = synth.g_object(P, seed=77, K=K)
     g["scales"] = (g["scales"] * 1.5).astype(np.float32)
     cam = synth.object_cameras(3, H, W, radius=3.2)[2]
     bg = np.array([1.0, 1.0, 1.0], np.float32)
-    out, st = _run_hip(g, cam, bg, D)
+    out, st = _run_hip(g, cam, bg, D, seg_len=seg_len)
+    assert int(st.binning.seg_len) == seg_len
     v = oracle_view(c_oracle, cam, P, K, D, bg)
     f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
     assert f["N"] > 300000 and (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 2000

@@ -158,3 +158,18 @@ def test_dropin_ring_bookkeeping_without_a_gpu():
     snap = rc.snapshot()
     snap.host_stats.wait_s += 1.5
     assert hs.wait_s == 1.5 and rc.snapshot().host_stats is hs
+
+
+def test_segment_length_policy(monkeypatch):
+    """GsrBinning.seg_len: 128-entry backward items for launches with little total work (one view, small scenes), 256 for
+    the large ones; all views of a call share one value; an unknown capacity means 256."""
+    from dreamscene_amd import rasterizer as R
+    monkeypatch.delenv("GSR_SEG_LEN", raising=False)
+    assert R.pick_seg_len(None) == 256 and R.pick_seg_len(0, 4) == 256
+    assert R.pick_seg_len(4_600_000, 1) == 128          # one view of C3 through the reference's interface
+    assert R.pick_seg_len(4_600_000, 4) == 256          # the 4-view step of C3
+    assert R.pick_seg_len(1_000_000, 4) == 128          # 100 k Gaussians @512^2, 4 views
+    monkeypatch.setenv("GSR_SEG_LEN", "64")
+    assert R.pick_seg_len(50_000_000, 8) == 64
+    from dreamscene_amd import _lib as L
+    assert dict(L.GsrBinning._fields_)["seg_len"] is not None and L.GsrBinning.seg_len.offset == L.GsrBinning.bwd_items_cap.offset + 4
