@@ -452,7 +452,7 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
   for (int k = 0; k < n_views; ++k) {
     const int rc = check_backward(&views[k], &gs[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k]);
     if (rc) return rc;
-    if (!same_except_scales(gs[k], gs[0]) || gsr_seg_len(bs[k]) != gsr_seg_len(bs[0])) return GSR_EINVAL;
+    if (!same_except_scales(gs[k], gs[0])) return GSR_EINVAL;
     per_view_scales = per_view_scales || gs[k].scales != gs[0].scales;
     if (views[k].P != views[0].P || views[k].image_height != views[0].image_height ||
         views[k].image_width != views[0].image_width || views[k].sh_stride != views[0].sh_stride ||
@@ -490,8 +490,14 @@ int gsr_backward_views(int32_t n_views, const GsrView* views, const GsrGaussians
         const int rc = clear_scratch(&views[k], &outs[k], stream, !contiguous);
         if (rc) return rc;
       }
-    const int rc = gsr_launch_render_bwd_views(n_views, views, geoms, bs, imgs, igs, outs, stream, prof);
-    if (rc) return rc;
+    bool one_launch = true;      // (views rendered with different item lengths / forward variants: one K7 launch per view)
+    for (int k = 1; k < n_views; ++k)
+      one_launch = one_launch && gsr_seg_len(bs[k]) == gsr_seg_len(bs[0]) && bs[k].fwd_mode == bs[0].fwd_mode;
+    for (int k = 0; k < (one_launch ? 1 : n_views); ++k) {
+      const int rc = gsr_launch_render_bwd_views(one_launch ? n_views : 1, &views[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k],
+                                                 stream, prof);
+      if (rc) return rc;
+    }
   } else {
     for (int k = 0; k < n_views; ++k) {
       const int rc = backward_render(&views[k], &geoms[k], &bs[k], &imgs[k], &igs[k], &outs[k], stream, prof, !contiguous);

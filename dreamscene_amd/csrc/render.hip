@@ -158,7 +158,7 @@ struct WorkBwdViews {
   const uint32_t* tile_depth[GSR_MAX_BATCH_VIEWS];
   uint32_t* items[GSR_MAX_BATCH_VIEWS];
   uint32_t items_cap[GSR_MAX_BATCH_VIEWS];
-  uint32_t seg_len;
+  uint32_t seg_len[GSR_MAX_BATCH_VIEWS];
 };
 
 __global__ void __launch_bounds__(1024)
@@ -202,7 +202,7 @@ k_work_order_bwd(const uint32_t n_tiles, const WorkBwdViews wv) {
   const uint32_t* __restrict__ tile_depth = wv.tile_depth[blockIdx.x];
   uint32_t* __restrict__ items = wv.items[blockIdx.x];
   const uint32_t items_cap = wv.items_cap[blockIdx.x];
-  const uint32_t kb = wv.seg_len;
+  const uint32_t kb = wv.seg_len[blockIdx.x];
   __shared__ uint32_t cnt[32], cur[32];
   const int tid = threadIdx.x;
   if (tid < 32) cnt[tid] = 0;
@@ -968,8 +968,8 @@ int gsr_launch_work_order_bwd(int n, const GsrView* views, const GsrBinning* bs,
   WorkBwdViews wv = WorkBwdViews{};
   for (int k = 0; k < n; ++k) {
     wv.tile_depth[k] = imgs[k].tile_depth; wv.items[k] = bs[k].tile_work + tiles; wv.items_cap[k] = bs[k].bwd_items_cap;
+    wv.seg_len[k] = gsr_seg_len(bs[k]);
   }
-  wv.seg_len = gsr_seg_len(bs[0]);
   hipLaunchKernelGGL(k_work_order_bwd, dim3((uint32_t)n), dim3(1024), 0, stream, tiles, wv);
   GSR_HIP(hipGetLastError());
   return GSR_OK;
@@ -1034,7 +1034,7 @@ int gsr_launch_render_fwd(const GsrView& v, const GsrGeom& geom, const GsrBinnin
   return gsr_launch_render_fwd_views(1, &v, &geom, &b, &img, stream, prof);
 }
 
-// K7 of n views in one launch (work lists built; same image size).
+// K7 of n views in one launch (work lists built; same image size and the same seg_len: the caller checks).
 int gsr_launch_render_bwd_views(int n, const GsrView* views, const GsrGeom* geoms, const GsrBinning* bs,
                                 const GsrImages* imgs, const GsrImageGrads* igs, GsrGrads* outs, hipStream_t stream,
                                 GsrProfile* prof) {

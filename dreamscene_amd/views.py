@@ -69,12 +69,16 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
     batched = (1 < V <= MAX_VIEWS and same and P > 0 and rc.forward_mode == "auto" and ws.hint.get((P, H, W)) is not None
                and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24))
 
-    # one segment length for all views of the call (their backward is one launch): from the capacity the batch will use
-    seg = R.pick_seg_len(ws.hint.get((P, H, W)), V)
+    # one segment length for all views of the call (their backward is one launch): from the capacity the batch will use --
+    # or, before any capacity is known, whatever the first view picks for its exact size
+    seg = R.pick_seg_len(ws.hint.get((P, H, W)), V) if ws.hint.get((P, H, W)) else None
 
     def one_by_one():
-        res = [R.rasterize_forward_raw(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp,
-                                       want_aux=want_aux, rc=rc, seg_len=seg) for k, s in enumerate(settings_list)]
+        res, seg_k = [], seg
+        for k, s in enumerate(settings_list):
+            res.append(R.rasterize_forward_raw(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp,
+                                               want_aux=want_aux, rc=rc, seg_len=seg_k))
+            seg_k = seg_k or int(res[-1][1].binning.seg_len)
         if score_sum is not None:
             for o, _ in res:
                 if int(rc.score_mode) == 2:       # raw pixel counts: u32 bit patterns in the float32 tensors
@@ -164,11 +168,14 @@ def _views_forward_scene(lib, settings_list, scenes, want_aux, rc):
     batched = (1 < V <= MAX_VIEWS and same and P > 0 and rc.forward_mode == "auto" and ws.hint.get((P, H, W)) is not None
                and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24) and K in (1, 4, 9, 16)
                and not any(s.score_flag for s in settings_list))
-    seg = R.pick_seg_len(ws.hint.get((P, H, W)), V)       # one segment length for the views of the call
+    seg = R.pick_seg_len(ws.hint.get((P, H, W)), V) if ws.hint.get((P, H, W)) else None   # one segment length per call
     if not batched:
-        return [R.rasterize_forward_raw(s, None, None, None, None, None, None, None, want_aux=want_aux, scene=sc, rc=rc,
-                                        seg_len=seg)
-                for s, sc in zip(settings_list, scenes)]
+        res = []
+        for s, sc in zip(settings_list, scenes):
+            res.append(R.rasterize_forward_raw(s, None, None, None, None, None, None, None, want_aux=want_aux, scene=sc,
+                                               rc=rc, seg_len=seg))
+            seg = seg or int(res[-1][1].binning.seg_len)
+        return res
     prof = rc.profile.handle if rc.profile is not None else None
     stride = R._align(int(lib.gsr_project_scratch_bytes(P)), 256)
     with torch.cuda.device(dev):

@@ -151,8 +151,9 @@ typedef struct GsrBinning {
                              or 64. A backward item is a serial recurrence over its entries, so a launch cannot end before its
                              longest item has (256 entries: 65-90 us on MI355X); a launch with little total work (one view, a
                              small scene) finishes sooner with shorter items, a large one pays for the extra checkpoints and
-                             prologues. Same value for the forward and the backward of a view and for all
-                             views of a batched call; fwd_mode 1 requires 256. Sizes: bwd_items_cap (above), GsrImages.ckpt */
+                             prologues. Same value for the forward and the backward of a view; views of one batched
+                             call that differ in it are composited by one launch each instead of one for all; fwd_mode 1
+                             requires 256. Sizes: bwd_items_cap (above), GsrImages.ckpt */
   uint64_t* keys_sorted;/* [N] optional: receives the sorted 64-bit keys (tile<<32 | depth bits); may be NULL */
   void* scratch;        /* gsr_sort_scratch_bytes(N, tiles) bytes, 256-byte aligned                   */
   size_t scratch_bytes;

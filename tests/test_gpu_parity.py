@@ -290,6 +290,40 @@ def test_device_side_accumulation_over_views(built_lib, c_oracle):
         assert err(a, r) <= TOL * max(1.0, float(np.abs(r).max())), ak
 
 
+def test_views_backward_with_mixed_segment_lengths(built_lib, c_oracle):
+    """Views whose forwards used different checkpoint distances (GsrBinning.seg_len: the host picks it per launch size) go
+    through one gsr_backward_views call: one compositing launch per view instead of one for all, one K8 pass; the sum equals
+    the sum of the per-view oracle gradients."""
+    from dreamscene_amd import rasterizer as R, synth
+    P, H, W, K, D = 4000, 96, 112, 16, 3
+    g, _ = small_scene(P=P, H=H, W=W, K=K, seed=83)
+    cams = synth.object_cameras(3, H, W, radius=3.0)
+    bg = np.array([0.0, 0.5, 1.0], np.float32)
+    t = _to_dev(g)
+    states, gis, gdas = [], [], []
+    ref = {k: 0.0 for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dshs")}
+    for j, (cam, seg) in enumerate(zip(cams, (256, 64, 128))):
+        gi, gda = synth.upstream_grads(H, W, 10 + j)
+        s = settings_for(cam, bg, D, DEV)
+        _, st = R.rasterize_forward_raw(s, t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None,
+                                        want_aux=False, seg_len=seg)
+        assert int(st.binning.seg_len) == seg
+        states.append(st)
+        gis.append(torch.tensor(gi, device=DEV))
+        gdas.append(torch.tensor(gda, device=DEV))
+        v = oracle_view(c_oracle, cam, P, K, D, bg)
+        f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        b = c_oracle.backward(v, f, gi, gda, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        for k in ref:
+            ref[k] = ref[k] + np.asarray(b[k], dtype=np.float64)
+    o = R.rasterize_backward_views_raw(states, gis, gdas)
+    torch.cuda.synchronize()
+    for hk, rk in [("dL_dmeans3D", "dL_dmeans3D"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"),
+                   ("dL_dopacities", "dL_dopacity"), ("dL_dshs", "dL_dshs")]:
+        a, r = o[hk].cpu().numpy().reshape(-1), ref[rk].reshape(-1)
+        assert err(a, r) <= TOL * max(1.0, float(np.abs(r).max())), hk
+
+
 def test_state_is_freed_without_cyclic_gc(built_lib):
     """The saved state (tens of MB per view) must be released by reference counting alone: a ctx -> state ->
     output tensor -> grad_fn -> ctx cycle would defer every free to Python's cyclic GC and bloat the allocator."""
