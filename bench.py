@@ -771,6 +771,10 @@ def main():
                        "views_per_step_per_gpu": V, "batched_call": batched, "captured_graphs": captured,
                        "batched_through": ("graph.CapturedViews (launches replayed from captured hipGraphs)" if captured else
                                            "views.GaussianRasterizerViews (launches issued from Python)") if batched else None,
+                       "seg_len": {"batched": R.pick_seg_len(int(N_pairs * 1.5) if N_pairs else None, V if batched else 1),
+                                   "one_view_per_call": R.pick_seg_len(int(N_pairs * 1.5) if N_pairs else None, 1),
+                                   "policy": "entries per forward checkpoint / backward work item: 128 when pair capacity x "
+                                             "views of the launch < 8 M, else 256 (rasterizer.pick_seg_len)"},
                        "capture_mode": cap_mode, "capture_probe": capture_probe,
                        "capture_stats": dict(rast_captured.stats) if captured else None,
                        "dropin": ("`dropin_views_per_s`: the same views through one GaussianRasterizer call per view (the "
