@@ -274,7 +274,7 @@ class CapturedViews(torch.nn.Module):
                 dict(scratch=cap.proj_scratch[k * stride:(k + 1) * stride], pinned=cap.pinned, index=k, event=None,
                      sort=(lambda nbytes, k=k: cap.sort_scratch[k * sort_bytes:(k + 1) * sort_bytes]),
                      capture=dict(cap=cap.cap, fwd_mode=int(rc.fwd_variant if rc.fwd_variant is not None else self._fwd_mode)),
-                     dynamic=cap.packed[k].data_ptr() + 40 * 4, seg_len=R.pick_seg_len(cap.cap, V)), rc) for k in range(V)]
+                     dynamic=cap.packed[k].data_ptr() + 40 * 4, seg_len=rc.seg_len or R.pick_seg_len(cap.cap, V)), rc) for k in range(V)]
             heads = [next(g) for g in gens]
             cap.views = (L.GsrView * V)(*[h[0] for h in heads])
             cap.geoms = (L.GsrGeom * V)(*[h[1] for h in heads])

@@ -72,6 +72,8 @@ class RasterContext:
                    what the environment says (GSR_DROPIN_GRAPHS=1: on; default off -- dropin.py has the measurements)
     host_stats     optional HostStats: seconds the calls made with this context spent blocked on the projection's pair
                    counts (bench.py reports it per step)
+    seg_len        entries per forward checkpoint / backward work item (GsrBinning.seg_len): None = per launch from its size
+                   (pick_seg_len); 256, 128 or 64 = that for every call made with this context
     """
     score_mode: int = 0
     profile: Optional[L.Profile] = None
@@ -83,6 +85,7 @@ class RasterContext:
     fwd_variant: Optional[int] = None
     dropin_graphs: Optional[bool] = None
     host_stats: Optional["HostStats"] = None
+    seg_len: Optional[int] = None
 
     def snapshot(self) -> "RasterContext":
         return dataclasses.replace(self)
@@ -318,7 +321,9 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
         proj_bytes = int(lib.gsr_project_scratch_bytes(P))
         proj_scratch = batch["scratch"] if batch is not None else ws.scratch("proj_scratch", proj_bytes)
 
-        seg_req = batch.get("seg_len") if batch is not None and batch.get("seg_len") else seg_len
+        seg_req = (batch.get("seg_len") if batch is not None else None) or seg_len or rc.seg_len
+        if seg_req and int(seg_req) not in (64, 128, 256):
+            raise ValueError(f"seg_len must be 64, 128 or 256, got {seg_req}")
 
         def seg_of(cap):
             return int(seg_req) if seg_req else pick_seg_len(cap, 1)

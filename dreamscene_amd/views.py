@@ -71,7 +71,7 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
 
     # one segment length for all views of the call (their backward is one launch): from the capacity the batch will use --
     # or, before any capacity is known, whatever the first view picks for its exact size
-    seg = R.pick_seg_len(int(ws.hint[(P, H, W)] * 1.5), V) if ws.hint.get((P, H, W)) else None
+    seg = rc.seg_len or (R.pick_seg_len(int(ws.hint[(P, H, W)] * 1.5), V) if ws.hint.get((P, H, W)) else None)
 
     def one_by_one():
         res, seg_k = [], seg
@@ -168,7 +168,7 @@ def _views_forward_scene(lib, settings_list, scenes, want_aux, rc):
     batched = (1 < V <= MAX_VIEWS and same and P > 0 and rc.forward_mode == "auto" and ws.hint.get((P, H, W)) is not None
                and (W + 15) // 16 <= 256 and (H + 15) // 16 <= 256 and P < (1 << 24) and K in (1, 4, 9, 16)
                and not any(s.score_flag for s in settings_list))
-    seg = R.pick_seg_len(int(ws.hint[(P, H, W)] * 1.5), V) if ws.hint.get((P, H, W)) else None   # one segment length per call
+    seg = rc.seg_len or (R.pick_seg_len(int(ws.hint[(P, H, W)] * 1.5), V) if ws.hint.get((P, H, W)) else None)   # one per call
     if not batched:
         res = []
         for s, sc in zip(settings_list, scenes):

@@ -171,5 +171,6 @@ def test_segment_length_policy(monkeypatch):
     assert R.pick_seg_len(1_000_000, 4) == 128          # 100 k Gaussians @512^2, 4 views
     monkeypatch.setenv("GSR_SEG_LEN", "64")
     assert R.pick_seg_len(50_000_000, 8) == 64
+    assert R.RasterContext().seg_len is None and R.RasterContext(seg_len=128).snapshot().seg_len == 128
     from dreamscene_amd import _lib as L
     assert dict(L.GsrBinning._fields_)["seg_len"] is not None and L.GsrBinning.seg_len.offset == L.GsrBinning.bwd_items_cap.offset + 4
