@@ -70,6 +70,36 @@ def algorithmic_bytes(stage: str, P: int, N: int, HW: int, K: int, D: int, views
     }[stage]
 
 
+def timed_kernel_name(stage: str, K: int, seg: int, batched: bool):
+    """Name (as tools/profile_digest.py shortens it) of the template instance a stage's timed launch runs."""
+    if stage == "render_bwd":
+        return f"k_render_bwd<{seg}>"
+    if stage == "render_fwd":
+        return f"k_render_fwd<false, {seg}>"
+    if stage == "preprocess":
+        return f"k_preprocess_views<{K}>" if batched else f"k_preprocess<{K},"
+    if stage == "preprocess_bwd":
+        return f"k_preprocess_bwd_views<{K},"
+    return None
+
+
+def pick_kernel(names, want, prefix, stage):
+    """The counters' entry of the kernel that was timed: the exact instance; an instance-name PREFIX (K8: the trailing template
+    arguments depend on the launch) when it is unambiguous; the stage's kernel prefix only when ONE kernel carries it. Never a
+    max over several instances (round 4 printed k_render_bwd<128>'s 485 MB for the timed k_render_bwd<256>'s 383 MB)."""
+    if want:
+        if want in names:
+            return want
+        c = [n for n in names if n.startswith(want)]
+        if len(c) == 1:
+            return c[0]
+    if prefix:
+        c = [n for n in names if n.startswith(prefix) and (stage != "preprocess" or "bwd" not in n)]
+        if len(c) == 1:
+            return c[0]
+    return None
+
+
 def self_launch_cmd(n_gpus: int, argv, port: int):
     """The command `python bench.py --gpus N ...` turns itself into when no launcher set up the ranks: the same line the
     task contract says the driver uses (one process per GPU, rendezvous on 127.0.0.1)."""
@@ -262,8 +292,10 @@ def main():
                               cov3D_precomp=None)
         (g2d,) = torch.autograd.grad([t_ for (img, _, da) in outs for t_ in (img, da)], [means2D], [gi, gda] * V)
         reduce_grads()
+        last_batched[0] = (outs, g2d)
         return outs[0], g2d[0]
 
+    last_batched = [None]          # (outputs of all views, means2D gradients [V,P,3]) of the latest batched step
     plain_rasts = [GaussianRasterizer(raster_settings=s_) for s_ in settings_list]
 
     def step_dropin():
@@ -678,20 +710,25 @@ def main():
             # HBM traffic and VALU instructions per launch of that kernel: rocprofv3 --pmc passes of this very command,
             # digested by tools/profile_digest.py into profiles/traffic.json (per launch, each pass normalised by its own
             # dispatch count); only used when they were collected for this configuration and call pattern
-            traffic, valu = None, None
+            traffic, valu, traffic_kernel = None, None, None
             tf = os.path.join(ROOT, "profiles", "traffic.json")
             key = f"{args.scene}{'-init' if args.init_opacity else ''}_{P}_{W}" + ("" if batched else "_dropin")
             if os.path.exists(tf):
                 try:
                     ent = json.load(open(tf)).get(key, {})
                     if ent.get("views_per_step") == V and bool(ent.get("batched_call")) == batched:
-                        pre = STAGE_KERNEL.get(dominant)
-                        for kn, nbytes in ent.get("per_launch_bytes", {}).items():
-                            if pre and kn.startswith(pre) and (dominant != "preprocess" or "bwd" not in kn):
-                                traffic = max(traffic or 0, nbytes)
+                        # the EXACT template instance the timed launch runs (k_render_bwd<256> and <128> both appear in a
+                        # profile of this command: the eager warm-up calls use other item lengths)
+                        seg_t = R.pick_seg_len(int(N_pairs * 1.5) if N_pairs else None, per_launch)
+                        want = timed_kernel_name(dominant, K, seg_t, batched)
+                        names_b = list(ent.get("per_launch_bytes", {}))
+                        kn_hit = pick_kernel(names_b, want, STAGE_KERNEL.get(dominant), dominant)
+                        if kn_hit is not None:
+                            traffic = ent["per_launch_bytes"][kn_hit]
+                            traffic_kernel = kn_hit
+                        kn_sq = pick_kernel(list(ent.get("sq_per_launch", {})), want, STAGE_KERNEL.get(dominant), dominant)
                         for kn, sq in ent.get("sq_per_launch", {}).items():
-                            if pre and kn.startswith(pre) and (dominant != "preprocess" or "bwd" not in kn) and \
-                                    "SQ_INSTS_VALU" in sq:
+                            if kn == kn_sq and "SQ_INSTS_VALU" in sq:
                                 n_valu = sq["SQ_INSTS_VALU"]
                                 n_salu = sq.get("SQ_INSTS_SALU", 0.0)
                                 mix = VALU_MIX.get(dominant, {"plain": 0.5, "other": 0.5, "trans": 0.0})
@@ -715,29 +752,78 @@ def main():
             # fewer bytes than their algorithmic count (early termination, L2-resident splat table); the streaming kernels
             # are HBM-bound. `achieved` / `peak` / `frac` are the HBM-roofline numbers the contract asks for in both cases.
             bound = "valu" if dominant in ("render_fwd", "render_bwd") else "hbm"
-            # the whole path's algorithmic bytes per view (848 P + 124 N + 56 HW at K=16, D=3)
+            # The whole path, three ways (per step of V views per GPU; `elapsed` is the --steps region):
+            #  * work_equivalent: SURVEY.md section 8(d)(i)'s per-VIEW contract bytes (848 P + 124 N + 56 HW at K=16, D=3) x views/s
+            #    -- what V separate per-view calls would have to move. NOT a bandwidth: the batched K1 / K8 read the parameter
+            #    rows once per launch, so the step moves fewer bytes than this (a figure above what a copy achieves, 6.3 TB/s,
+            #    is possible and means nothing about the memory system);
+            #  * launch_accurate: the sum over the step's stages of the algorithmic bytes of the launches that really run
+            #    (algorithmic_bytes(stage, views=V)) / the step time = the HBM-roofline fraction of the step;
+            #  * counters: measured HBM bytes per step (rocprofv3 --pmc, profiles/traffic.json) / the step time.
             S_ = 12 * (D + 1) ** 2
             e2e_bytes = P * (44 + S_) + P * 48 + N_pairs * 12 + N_pairs * 24 + N_pairs * 44 + H * W * 28 + \
                 N_pairs * 44 + H * W * 28 + P * 40 + P * (44 + S_ + 40) + P * (44 + 12 * K + 12)
+            step_s = elapsed / args.steps
+            stages_all = ("preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd", "render_bwd", "preprocess_bwd")
+            per_stage = {st_: algorithmic_bytes(st_, P, N_pairs, H * W, K, D, views=per_launch) *
+                         (1 if batched else V) for st_ in stages_all}
+            la_bytes = sum(per_stage.values())
+            counter_bytes = None
+            try:
+                ent_ = json.load(open(tf)).get(key, {}) if os.path.exists(tf) else {}
+                if ent_.get("views_per_step") == V and bool(ent_.get("batched_call")) == batched and ent_.get("per_step_bytes"):
+                    counter_bytes = int(sum(ent_["per_step_bytes"].values()))
+            except Exception:
+                counter_bytes = None
+            whole = {"launch_accurate_bytes_per_step": int(la_bytes),
+                     "launch_accurate_GBps": round(la_bytes / step_s / 1e9, 1),
+                     "launch_accurate_frac_of_hbm_peak": round(la_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                     "launch_accurate_bytes_by_stage": {k_: int(v_) for k_, v_ in per_stage.items()},
+                     "counter_bytes_per_step": counter_bytes,
+                     "counter_frac_of_hbm_peak": (round(counter_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4)
+                                                  if counter_bytes else None),
+                     "work_equivalent": {"contract_bytes_per_view": int(e2e_bytes),
+                                         "GBps": round(e2e_bytes * V / step_s / 1e9, 1),
+                                         "frac_of_hbm_peak": round(e2e_bytes * V / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                         "note": "per-view contract bytes x views/s: work done per second in units of the "
+                                                 "per-view byte contract, not bytes moved (the batched launches read the "
+                                                 "parameter rows once for all views)"}}
             roofline = {"bound": bound, "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu": valu,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_kernel": traffic_kernel, "valu": valu,
                         "avg_launch_us": round(avg_s * 1e6, 2), "views_per_launch": per_launch,
                         "launches_timed": int(cnt),
                         "timed_how": "HIP events around the kernel's launches on the launch stream, eager pass right after "
                                      "the timed region" + (" (the timed region replays captured graphs)" if captured else ""),
-                        "whole_path": {"algorithmic_bytes_per_view": int(e2e_bytes),
-                                       "achieved_GBps": round(e2e_bytes * world * args.steps * V / elapsed / 1e9 / world, 1),
-                                       "frac_of_hbm_peak": round(e2e_bytes * args.steps * V / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
+                        "whole_path": whole,
                         "algorithmic_bytes": int(ab),
                         "stage_us_per_view": {s: round(v * 1e3, 2) for s, v in stage_ms.items()}}
 
     cpu_baseline = None
     grad_err = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out = view0_with_own_gradients()  # one more (untimed) call keeping view 0's own gradients for the check
+        # parity ON THE TIMED PATH: one more step exactly as timed (the batched call: captured graphs or the views module,
+        # K1 / K8 of all views in one launch, K6 / K7 <seg> of the batch, gradients summed in the arena) -- every view's image
+        # and means2D gradient and the arena's SUM over the step's V views are compared with the scalar C oracle's per-view
+        # results and their float64 sum (`max_grad_err_vs_oracle.batched_sum`)
+        timed_path = None
+        if batched:
+            set_profile(None)
+            step()
+            torch.cuda.synchronize(dev)
+            outs_b, g2d_b = last_batched[0]
+            timed_path = {"through": "graph.CapturedViews" if captured else "views.GaussianRasterizerViews",
+                          "cams": my_cams,
+                          "images": [o_[0].detach().cpu().numpy() for o_ in outs_b],
+                          "depth_alphas": [o_[2].detach().cpu().numpy() for o_ in outs_b],
+                          "radii": [o_[1].detach().cpu().numpy() for o_ in outs_b],
+                          "means2D": g2d_b.detach().cpu().numpy(),
+                          "arena": {n_: arena.views[n_].detach().cpu().numpy().copy() for n_ in
+                                    ("means3D", "shs", "opacities", "scales", "rotations")}}
+        out = view0_with_own_gradients()  # (and the plain per-view module, view 0's own gradients: the drop-in path)
         torch.cuda.synchronize(dev)
         cpu_baseline, grad_err = cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, out, extra_cams=cams[1:],
-                                                  init_opacity=args.init_opacity)
+                                                  init_opacity=args.init_opacity, timed_path=timed_path)
 
     if rank == 0:
         views = world * args.steps * V
@@ -918,7 +1004,7 @@ def _run_cpu_leg(args, timeout_s):
     return res, note
 
 
-def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), init_opacity=False):
+def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), init_opacity=False, timed_path=None):
     """The CPU path timed beside the GPU numbers, on a bounded sample, host core count stated.
     The reference has NO CPU path for the rasterizer, so the baselines are this repo's CPU restatements:
       * `value`: the C port of the same algorithm (oracle/gsr_oracle.c, OpenMP build) on ALL host cores, on views of the
@@ -974,10 +1060,62 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), 
                                    note="PyTorch-CPU oracle (oracle/torch_oracle.py), fp32, fwd+bwd views/s at C1 = 10 k @256^2 "
                                         "(tried with 32 / 64 / physical-core threads: `tried`, views/s each) and at C2 = 100 k "
                                         "@512^2 with the best of them (`threads`)")
-    return base, {"bit_exact_radii": bool(np.array_equal(radii.cpu().numpy(), f["radii"])),
-                  "image_max_abs": float(d_img.max()), "image_frac_pixels_over_1e-5": float((d_img > 1e-5).mean()),
-                  "grads_max_err_over_max1": worst, "grads_max_frac_entries_over_1e-5": worst_frac,
-                  "per_tensor": per, "tol": "1e-5 * max(1, max|ref|)"}
+    err = {"bit_exact_radii": bool(np.array_equal(radii.cpu().numpy(), f["radii"])),
+           "image_max_abs": float(d_img.max()), "image_frac_pixels_over_1e-5": float((d_img > 1e-5).mean()),
+           "grads_max_err_over_max1": worst, "grads_max_frac_entries_over_1e-5": worst_frac,
+           "per_tensor": per, "tol": "1e-5 * max(1, max|ref|)",
+           "what": "view 0 through the plain per-view module (the drop-in path) against the scalar C oracle"}
+    if timed_path is not None:
+        err["batched_sum"] = timed_path_check(timed_path, (f, b), g, D, K, H, W, gi_np, gda_np)
+    return base, err
+
+
+def timed_path_check(tp, view0, g, D, K, H, W, gi_np, gda_np):
+    """The path that was TIMED against the oracle: the V views of one batched step (tp, captured by main() right after the
+    timed region). Oracle: the scalar C build per view (view 0's results are handed in, the other views run on a thread each
+    -- ctypes releases the GIL), per-view gradients summed in float64. Checked: radii bit-exact per view, every view's image /
+    depth_alpha / means2D gradient, and the arena (the SUM over the views, what the optimizer / the exchange consumes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle as CO
+    P = g["means3D"].shape[0]
+    cams = tp["cams"]
+    V = len(cams)
+
+    def one(c):
+        v = CO.make_view(P, K, D, H, W, c.tanfovx, c.tanfovy, [1.0, 1.0, 1.0], c.world_view_transform,
+                         c.full_proj_transform, c.camera_center)
+        f = CO.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        b = CO.backward(v, f, gi_np, gda_np, g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        return f, b
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, V - 1)) as ex:
+        rest = list(ex.map(one, cams[1:]))
+    res = [view0] + rest
+    dt = time.perf_counter() - t0
+    names = {"means3D": "dL_dmeans3D", "shs": "dL_dshs", "opacities": "dL_dopacity", "scales": "dL_dscales",
+             "rotations": "dL_drotations"}
+    per, worst, worst_frac = {}, 0.0, 0.0
+    for an, on in names.items():
+        ref = sum(np.asarray(b[on], dtype=np.float64).reshape(-1) for _, b in res)
+        e = np.abs(tp["arena"][an].astype(np.float64).reshape(-1) - ref)
+        scale = max(1.0, float(np.abs(ref).max()))
+        per[on] = {"max_err_over_scale": float(e.max() / scale), "frac_over_1e-5": float((e > 1e-5 * scale).mean())}
+        worst, worst_frac = max(worst, per[on]["max_err_over_scale"]), max(worst_frac, per[on]["frac_over_1e-5"])
+    img_err, da_err, m2d_err, radii_ok = 0.0, 0.0, 0.0, True
+    for k, (f, b) in enumerate(res):
+        img_err = max(img_err, float(np.abs(tp["images"][k] - f["image"]).max()))
+        da_ref = f["depth_alpha"]
+        da_err = max(da_err, float(np.abs(tp["depth_alphas"][k] - da_ref).max() / max(1.0, float(np.abs(da_ref).max()))))
+        ref = np.asarray(b["dL_dmeans2D"], dtype=np.float64)
+        m2d_err = max(m2d_err, float(np.abs(tp["means2D"][k].astype(np.float64) - ref).max() / max(1.0, float(np.abs(ref).max()))))
+        radii_ok = radii_ok and bool(np.array_equal(tp["radii"][k], f["radii"]))
+    return {"through": tp["through"], "views": V, "bit_exact_radii_all_views": radii_ok,
+            "image_max_abs_all_views": img_err, "depth_alpha_max_err_over_max1": da_err,
+            "means2D_grad_max_err_over_max1": m2d_err,
+            "arena_sum_max_err_over_max1": worst, "arena_sum_max_frac_entries_over_1e-5": worst_frac, "per_tensor": per,
+            "oracle_seconds": round(dt, 1), "tol": "1e-5 * max(1, max|ref|)",
+            "what": f"one step exactly as timed ({V} views through ONE batched call, gradients summed in the arena) against "
+                    "the scalar C oracle's per-view results and the float64 sum of its per-view gradients"}
 
 
 if __name__ == "__main__":

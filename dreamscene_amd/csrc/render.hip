@@ -670,8 +670,11 @@ __device__ __forceinline__ float reduce10(const float v[10], int lane) {
 // cond(Sigma)^2 on needle-shaped splats and dL/dopacity collects the 7e4-weighted extremal pixels of the reference's disp
 // normalisation (scene_gaussian.py:1025-1032) -- the worst dL/drotations entry of the needle case moved between 2.7e-6 and
 // 1.5e-5 from run to run, dL/dopacity of the boundary records between 1e-5 and 1e-4 (round 3). Now every wave result is
-// added in DOUBLE (global_atomic_add_f64: 29 spare mantissa bits over the fp32 addends -- the sum of a splat's <= 2^20 wave
-// results is exact, hence the same in every order) and K8 rounds the total to fp32 once: the backward is bit-reproducible.
+// added in DOUBLE (global_atomic_add_f64: 29 spare mantissa bits over the fp32 addends -- the sum of a splat's wave results is
+// exact, hence the same in every order, as long as the addends' exponents span less than 2^29; beyond that span -- the 7e4-
+// weighted extremal pixels of the disp normalisation next to a near-zero contribution -- an addend can move the double by
+// 2^-53 of the sum, visible in fp32 only on a rounding tie) and K8 rounds the total to fp32 once: the backward is
+// order-independent within that span (tests: same bits over eight runs, <= 4 one-ulp ties per tensor allowed).
 // One atomic instruction per (splat, block) as before -- 12 lanes, one 128-byte row. (Measured first: doubles for the four
 // sensitive sums only, in a second atomic instruction next to the f32 one: K7 217 -> 238 us -- two atomic instructions per
 // iteration run into the atomic issue limit of ~80 ns per instruction and SIMD, DESIGN.md "Issue costs".)

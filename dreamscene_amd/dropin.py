@@ -19,10 +19,11 @@ allow ~8 000). This module puts the launches of a view behind two graph launches
   * pair counts: checked against the slot's capacity after every replay (pinned words, polled while the graph still
     runs); an overflow makes that call run eagerly with exact sizes, like every call before a slot is warm.
   * forward-only calls (torch.no_grad(): video_inference, object_trainer.py:81-118) use the same slots without a lease.
-  * the GRADIENTS a backward returns are the slot's static tensors (as with CapturedViews): autograd consumes them in
-    stream order (the next node's kernels are enqueued before the slot can be replayed again; AccumulateGrad clones a
-    tensor somebody else holds), `retain_grad()` clones. Only the result of `torch.autograd.grad(...)` aliases a slot; it
-    stays valid until that slot's next backward -- at least one full step. INTEGRATION.md section 5c.
+  * the GRADIENTS a backward returns are the slot's static tensors (as with CapturedViews), every one of them an object the
+    slot's result dict holds as well: autograd consumes them in stream order (the next node's kernels are enqueued before
+    the slot can be replayed again) and CLONES a tensor somebody else holds before it keeps it as `.grad` or adds into it,
+    `retain_grad()` clones. Only the result of `torch.autograd.grad(...)` aliases a slot; it stays valid until that slot's
+    next backward -- at least one full step. INTEGRATION.md section 5c.
 
 Not eligible (the eager path runs, as before): colors_precomp / cov3D_precomp inputs, score_flag, camera gradients, a
 RasterContext with an arena / profile / densify_stats, non-fp32 or non-contiguous inputs, P = 0, grids beyond 256 x 256
@@ -39,6 +40,7 @@ import torch
 
 from . import rasterizer as R
 
+MAX_RINGS = 16          # (device, stream, P, K, H, W, ...) keys alive: the module's internal streams each have their own
 MAX_SLOTS = 8           # per key: views of a step in flight (C_batch_size = 4) + the ones whose graph is still alive
 # Opt-in (GSR_DROPIN_GRAPHS=1, or RasterContext(dropin_graphs=True) per module). Measured on MI355X / ROCm 7.2, round 4
 # (gpurun_out/r4d, profiles/r04_dropin_graphs.txt): a graph launch of the 17 forward nodes costs the host 10 us instead of
@@ -147,7 +149,7 @@ def _ring_for(s, means3D, shs) -> _Ring:
     with _LOCK:
         r = _RINGS.get(key)
         if r is None:
-            if len(_RINGS) >= 4:          # P changes with every densification: drop the rings of the old sizes
+            if len(_RINGS) >= MAX_RINGS:  # P changes with every densification: drop the rings of the old sizes
                 _RINGS.pop(next(iter(_RINGS)))
             r = _RINGS[key] = _Ring()
     return r
@@ -193,9 +195,17 @@ class _DropinFn(torch.autograd.Function):
         finally:
             if ctx.lease is not None:
                 ctx.lease.release()
-        m2d = o["dL_dmeans2D"]
-        return (o["dL_dmeans3D"], m2d[0] if m2d.dim() == 3 else m2d, o["dL_dshs"], o["dL_dopacities"].reshape(ctx.opac_shape),
-                o["dL_dscales"], o["dL_drotations"], None, None, None, None)
+        # Everything handed to autograd must be a tensor OBJECT somebody else holds too (the slot's result dict): autograd
+        # steals a gradient whose use count is 1 -- AccumulateGrad makes it the leaf's `.grad`, the engine's input buffers add
+        # into it in place -- and a fresh view object of the slot's static storage (m2d[0], a reshape) has use count 1: `.grad`
+        # would alias the slot, and the slot's next backward would overwrite it. The views are made once per slot
+        # and kept in the dict; a held tensor is cloned by autograd before it keeps or modifies it.
+        vw = o.get("_dropin_views")
+        if vw is None or vw[2] != tuple(ctx.opac_shape):
+            m2d = o["dL_dmeans2D"]
+            vw = o["_dropin_views"] = (m2d[0] if m2d.dim() == 3 else m2d, o["dL_dopacities"].reshape(ctx.opac_shape),
+                                       tuple(ctx.opac_shape))
+        return (o["dL_dmeans3D"], vw[0], o["dL_dshs"], vw[1], o["dL_dscales"], o["dL_drotations"], None, None, None, None)
 
 
 def ring_sig(means3D, opacities, shs, scales, rotations):

@@ -48,6 +48,7 @@ class FusedAdam(torch.optim.Optimizer):
         # parameters that share (betas, eps, step) go into one launch
         batches = {}
         keep = []
+        updated = []
         for k, (group, p) in enumerate(flat):
             gr = grads[k] if grads is not None else p.grad
             if gr is None:
@@ -75,6 +76,7 @@ class FusedAdam(torch.optim.Optimizer):
                 raise ValueError("FusedAdam tensors must be 16-byte aligned")
             batches.setdefault(key, []).append(e)
             keep.append(gr)
+            updated.append(p)
         for (dev, betas, eps, step), entries in batches.items():
             stream = torch.cuda.current_stream(dev).cuda_stream
             with torch.cuda.device(dev):
@@ -83,6 +85,10 @@ class FusedAdam(torch.optim.Optimizer):
                     arr = (L.GsrAdamGroup * len(chunk))(*chunk)
                     L.check(lib.gsr_adam_step(arr, len(chunk), step, betas[0], betas[1], eps, int(zero_grad), stream),
                             "gsr_adam_step")
+        # the launch wrote the parameters through raw pointers: tell autograd's version counters (the rasterizer's
+        # "inputs unchanged since ..." checks -- rasterizer._check_versions, _SideStreams -- rely on them)
+        for p in updated:
+            torch.autograd.graph.increment_version(p)
         if set_to_none and grads is None:
             for _, p in flat:
                 p.grad = None          # (the launch above holds its own references through `keep` until enqueued)

@@ -22,6 +22,7 @@ import ctypes as C
 import dataclasses
 import threading
 import time
+import weakref
 from typing import NamedTuple, Optional, Sequence
 
 import torch
@@ -74,6 +75,8 @@ class RasterContext:
                    counts (bench.py reports it per step)
     seg_len        entries per forward checkpoint / backward work item (GsrBinning.seg_len): None = per launch from its size
                    (pick_seg_len); 256, 128 or 64 = that for every call made with this context
+    side_streams   GaussianRasterizer only: consecutive calls rotate over this many internal HIP streams (see `_SideStreams`):
+                   None = what the environment says (GSR_SIDE_STREAMS=n; default SIDE_STREAMS_DEFAULT), 0 / 1 = the caller's stream
     """
     score_mode: int = 0
     profile: Optional[L.Profile] = None
@@ -86,6 +89,7 @@ class RasterContext:
     dropin_graphs: Optional[bool] = None
     host_stats: Optional["HostStats"] = None
     seg_len: Optional[int] = None
+    side_streams: Optional[int] = None
 
     def snapshot(self) -> "RasterContext":
         return dataclasses.replace(self)
@@ -207,6 +211,8 @@ SEG_LEN_256_FROM = 8_000_000
 def pick_seg_len(cap, n_views: int = 1) -> int:
     env = os.environ.get("GSR_SEG_LEN")       # (tools / experiments: 64, 128 or 256 for every call)
     if env:
+        if env.strip() not in ("64", "128", "256"):
+            raise ValueError(f"GSR_SEG_LEN must be 64, 128 or 256, got {env!r}")
         return int(env)
     if not cap:
         return 256
@@ -576,10 +582,14 @@ class _Scratch:
     def begin(self):
         """Exclusive use for one enqueue; re-zeroed first if a previous call failed half-way (dirty)."""
         self.lock.acquire()
-        if self.dirty:
-            self.partials.zero_()
-            self.reach.zero_()
-        self.dirty = True
+        try:
+            if self.dirty:
+                self.partials.zero_()
+                self.reach.zero_()
+            self.dirty = True
+        except BaseException:        # (a device error / OOM inside zero_(): the next backward on this stream must not deadlock)
+            self.lock.release()
+            raise
         return self
 
     def end(self, ok: bool):
@@ -590,7 +600,7 @@ class _Scratch:
 
 _SCRATCH: "collections.OrderedDict" = collections.OrderedDict()
 _SCRATCH_LOCK = threading.Lock()
-_SCRATCH_MAX = 4
+_SCRATCH_MAX = 12      # (one per internal stream of the module + the batched / captured ones)
 
 
 def _scratch_acquire(dev, V: int, P: int, private: bool = False) -> _Scratch:
@@ -605,6 +615,10 @@ def _scratch_acquire(dev, V: int, P: int, private: bool = False) -> _Scratch:
     with _SCRATCH_LOCK:
         s = _SCRATCH.get(key)
         if s is None:
+            # P changes with every densification: the buffers of this (device, stream, V) for another P are dead weight
+            # (128 B per Gaussian and view: 256 MB at 500 k x 4) -- drop them before allocating the new one
+            for old in [k for k in _SCRATCH if k[:3] == key[:3] and k[3] != P]:
+                del _SCRATCH[old]
             s = _SCRATCH[key] = _Scratch(V, P, dev)
             while len(_SCRATCH) > _SCRATCH_MAX:
                 _SCRATCH.popitem(last=False)
@@ -861,6 +875,130 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
     return o
 
 
+# ---- consecutive per-view calls on internal streams ("next round" 1a) -----------------------------------------
+# One GaussianRasterizer call is a chain of ~17 dependent launches of which the ~140 us binning part leaves the GPU idle
+# (launch / visibility latency on 12 MB of keys). The unmodified trainers make one call per view; when several calls follow
+# each other without the caller touching their results in between, view j + 1's K1 + binning can run under view j's K6 -- IF
+# the calls are not all on one stream. So the module rotates its calls over n internal streams:
+#   fork   the internal stream waits for an event recorded on the CALLER'S stream: everything the caller enqueued before the
+#          call (the producers of the inputs) is finished before K1 reads them;
+#   join   the caller's stream waits for the event recorded behind K6 on the internal stream before the call returns: whatever
+#          the caller enqueues next sees finished outputs. Nothing is deferred: stream semantics are exactly those of a call
+#          on the caller's own stream.
+# The join alone would serialise consecutive calls again: the NEXT call's fork event would sit behind this call's join on
+# the caller's stream. It does not have to: an input tensor that is the same live tensor OBJECT, at the same autograd version
+# counter, as at an earlier call of this module on this caller stream has not been written since (every in-place torch op
+# bumps the counter; raw-pointer writers -- FusedAdam -- bump it explicitly), so it was complete at THAT call's fork event,
+# which precedes the previous call's join on the caller's stream. When that holds for EVERY input of a call (the parameter
+# tensors and the camera tensors of the settings), the call forks from the older event and starts while the previous views
+# are still running; one new tensor (fresh activations, a freshly built camera) and the call forks from "now". Sound by
+# construction, and only as effective as the caller lets it be: the reference's trainers re-run the activations before every
+# call and read the outputs right behind it on the host (`disp[alpha <= 0.1]`, scene_gaussian.py:1027), so THEIR forwards
+# serialise whatever this module does; a loop over cameras against persistent tensors (bench.py's `dropin_views_per_s`, the
+# importance-score loop, video_inference) overlaps.
+# Backward: autograd runs every node on the stream its forward ran on and inserts the cross-stream syncs itself, so K7 / K8
+# of a view run on its internal stream. Memory: tensors allocated inside the call belong to the internal stream's allocator
+# pool; the ones handed to the caller are record_stream()ed on the caller's stream, the inputs on the internal one.
+SIDE_STREAMS_DEFAULT = 0
+SIDE_STREAMS_MAX = 8
+
+
+def _side_streams_wanted(context) -> int:
+    n = context.side_streams if (context is not None and context.side_streams is not None) else None
+    if n is None:
+        env = os.environ.get("GSR_SIDE_STREAMS")
+        n = int(env) if env else SIDE_STREAMS_DEFAULT
+    return max(0, min(int(n), SIDE_STREAMS_MAX))
+
+
+class _SideStreams:
+    """Per (device, caller stream): the internal streams, the latest fork event on the caller's stream and the tensors known
+    to have been complete at (or before) it."""
+    __slots__ = ("streams", "joins", "turn", "fork", "known", "stats")
+
+    def __init__(self, dev, n):
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        self.joins = [torch.cuda.Event() for _ in range(n)]
+        self.turn = 0
+        self.fork = None
+        self.known = {}          # id(tensor) -> (weakref to it, its version when it was seen complete)
+        self.stats = dict(calls=0, forks=0, reused_forks=0)
+
+    def proves_complete(self, inputs) -> bool:
+        """Every input is the same live tensor object, at the same version counter, as when it was last seen complete."""
+        known = self.known
+        for t in inputs:
+            e = known.get(id(t))
+            if e is None or e[0]() is not t or e[1] != t._version:
+                return False
+        return True
+
+    def remember(self, inputs) -> None:
+        known = self.known
+        if len(known) > 512:                     # (ids of dead tensors accumulate: start over, one serialised call)
+            known.clear()
+        for t in inputs:
+            known[id(t)] = (weakref.ref(t), t._version)
+
+    def fork_event(self, cur, inputs):
+        if self.fork is not None and self.proves_complete(inputs):
+            self.stats["reused_forks"] += 1
+        else:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.fork = ev
+            self.stats["forks"] += 1
+        # every input of this call is complete at self.fork (proved above, or because the event was recorded just now behind
+        # everything the caller enqueued); entries of earlier calls stay valid: their events precede this one on the stream
+        self.remember(inputs)
+        return self.fork
+
+
+_SIDE = {}
+_SIDE_LOCK = threading.Lock()
+
+
+def _side_for(dev, cur, n) -> _SideStreams:
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), cur.cuda_stream, n)
+    sd = _SIDE.get(key)
+    if sd is None:
+        with _SIDE_LOCK:
+            sd = _SIDE.get(key)
+            if sd is None:
+                sd = _SIDE[key] = _SideStreams(dev, n)
+    return sd
+
+
+def side_stream_stats() -> dict:
+    return {f"{k[0]}:{k[1]:#x}:{k[2]}": dict(v.stats) for k, v in _SIDE.items()}
+
+
+def _call_on_side_stream(n, call, tensors, settings):
+    """call() with an internal stream current; see the comment block above. tensors: the per-Gaussian inputs (None entries
+    skipped); the camera tensors come from `settings`."""
+    dev = tensors[0].device
+    cur = torch.cuda.current_stream(dev)
+    sd = _side_for(dev, cur, n)
+    inputs = [t for t in tensors if t is not None] + [settings.bg, settings.viewmatrix, settings.projmatrix, settings.campos]
+    k = sd.turn
+    sd.turn = (k + 1) % n
+    side = sd.streams[k]
+    sd.stats["calls"] += 1
+    side.wait_event(sd.fork_event(cur, inputs))
+    for t in inputs:
+        if t.is_cuda:
+            t.record_stream(side)         # (their memory must not be handed out again while the internal stream reads it)
+    with torch.cuda.stream(side):
+        out = call()
+    j = sd.joins[k]
+    j.record(side)
+    cur.wait_event(j)
+    for t in out:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(cur)          # allocated in the internal stream's pool, consumed on the caller's stream
+    return out
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     """viewmatrix / projmatrix / campos are the settings' own tensors, passed once more as explicit inputs so that autograd
     can deliver dL/dviewmatrix (+ projmatrix, campos) to callers that optimise the camera (BASELINE.json north_star); the
@@ -923,11 +1061,22 @@ class GaussianRasterizer(torch.nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         s = self.raster_settings
-        from . import dropin
-        if dropin.eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, self.context):
-            out = dropin.rasterize(s, means3D, means2D, opacities, shs, scales, rotations, self.context)
-            if out is not None:
-                return out
-        rc = (self.context or DEFAULT_CONTEXT).snapshot()
-        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                         cov3D_precomp, s.viewmatrix, s.projmatrix, s.campos, s, rc)
+        ctx = self.context
+
+        def call():
+            from . import dropin
+            if dropin.eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, ctx):
+                out = dropin.rasterize(s, means3D, means2D, opacities, shs, scales, rotations, ctx)
+                if out is not None:
+                    return out
+            rc = (ctx or DEFAULT_CONTEXT).snapshot()
+            return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                             cov3D_precomp, s.viewmatrix, s.projmatrix, s.campos, s, rc)
+        n = _side_streams_wanted(ctx)
+        # (an arena / statistics / a profile tie the views of a step to one stream: K8 of two views adding into one arena from
+        #  two streams would race; a stream being captured stays as it is)
+        if n > 1 and means3D.is_cuda and (ctx is None or (ctx.grad_arena is None and ctx.densify_stats is None and
+                                                          ctx.profile is None)) \
+                and not torch.cuda.is_current_stream_capturing():
+            return _call_on_side_stream(n, call, (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp), s)
+        return call()

@@ -135,8 +135,13 @@ typedef struct GsrGeom {
                               and the device-side counts (N, visible Gaussians). Must stay alive until
                               gsr_forward_render has been enqueued; not needed for backward                       */
   size_t scratch_bytes;
-  uint32_t* sorted_idx;    /* OUT (set by gsr_forward_project*): [P] Gaussian indices in (depth bits, index) order,
-                              culled ones last; points into scratch                                              */
+  uint32_t* sorted_idx;    /* OUT (set by gsr_forward_project*), OPAQUE: one of the depth sort's two value buffers inside
+                              `scratch`, handed from gsr_forward_project* to gsr_forward_render*. It holds the Gaussian
+                              indices in (depth bits, index) order ONLY when the sort's last pass moved keys; a last pass
+                              that is the identity (the top byte of one object's depths) is skipped, the order then lives
+                              in the OTHER buffer and a flag word in `scratch` says so -- the library's consumers read the
+                              flag, a caller must not read this pointer (the depth order is observable through
+                              GsrBinning.point_list, whose entries are in (tile, depth bits, index) order)           */
 } GsrGeom;
 
 /* Tile binning. point_list / ranges are saved for backward; the rest is scratch for the forward only. */
@@ -212,8 +217,11 @@ typedef struct GsrGrads {
                            sum q u, sum q v, sum q u^2, sum q u v, sum q v^2, dL/dopacity, dL/dr, dL/dg, dL/db, dL/ddepth
                            (the last two as two half-wave sums each: doubles 8-11). K7 reduces a splat's sums over the 64
                            pixels of a wave in fp32 in a fixed order and adds the wave's result ACROSS waves in double
-                           (one global_atomic_add_f64 instruction, 12 lanes, one 128-byte line): the order in which K7's
-                           workgroups arrive does not show in the gradients -- the backward is bit-reproducible       */
+                           (one global_atomic_add_f64 instruction, 12 lanes, one 128-byte line). A double holds the sum of
+                           fp32 addends exactly while their exponents span less than 2^29: within that span the order in
+                           which K7's workgroups arrive does not show in the gradients (bit-reproducible backward); an
+                           addend more than 2^29 below the running sum can move the double by one unit of its last place,
+                           which reaches the fp32 result only on a rounding tie (about one value in 10^9)            */
   int32_t accumulate;   /* 0: overwrite the parameter gradients; 1: ADD this view's gradients to what the buffers
                            hold (device-side sum over the views of one optimizer step). dL_dmeans2D is per view
                            and always overwritten; dL_dview/proj/campos always accumulate                     */

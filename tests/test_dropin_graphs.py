@@ -148,3 +148,54 @@ def test_fresh_input_tensors_every_call(built_lib):
                 same_bits(ref[k], got[k], f"step {step}: d/d{k} vs the eager path")
     st = list(dropin.stats().values())[0]
     assert st["replays"] >= 4, st
+
+
+def test_leaf_grads_do_not_alias_a_slot(built_lib):
+    """a leaf passed straight into the module (opacities [P,1], means2D) accumulates over two backward calls
+    (gradient accumulation, zero_grad(set_to_none=False)): `.grad` must be the leaf's own memory -- g1 + g2 -- not a view of
+    the slot's static gradient buffer, which the slot's next backward overwrites (2 * g2)."""
+    from dreamscene_amd import dropin
+    from dreamscene_amd.rasterizer import GaussianRasterizer, RasterContext
+    dropin.reset()
+    g, cams, ups = _scene(P=8_000, res=128, n_cams=1)
+    params = {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in g.items()}
+    s = settings_for(cams[0], np.ones(3, np.float32), 3, DEV)
+    m2d = torch.zeros_like(params["means3D"], requires_grad=True)
+    leaves = [params[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")] + [m2d]
+
+    def run(ctx, scale):
+        img, _, da = GaussianRasterizer(raster_settings=s, context=ctx)(
+            means3D=params["means3D"], means2D=m2d, shs=params["shs"], opacities=params["opacities"], scales=params["scales"],
+            rotations=params["rotations"])
+        ((img * ups[0][0]).sum() * scale + (da * ups[0][1]).sum()).backward()
+    for t in leaves:
+        t.grad = None
+    eager = RasterContext(dropin_graphs=False)
+    run(eager, 1.0)
+    run(eager, 3.0)
+    torch.cuda.synchronize()
+    ref = [t.grad.clone() for t in leaves]
+    for rep in range(4):          # warm-up (eager), capture, replay, replay: the last two accumulations are both replays
+        for t in leaves:
+            t.grad = None
+        run(None, 1.0)
+        run(None, 3.0)
+        torch.cuda.synchronize()
+        for t, r, what in zip(leaves, ref, ("means3D", "shs", "opacities", "scales", "rotations", "means2D")):
+            same_bits(t.grad, r, f"rep {rep}: accumulated .grad of {what}")
+    # a third accumulation through the replayed slot, against three eager ones
+    run(None, 7.0)
+    torch.cuda.synchronize()
+    assert st_ok(dropin)
+    run_ref = [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    run(eager, 1.0); run(eager, 3.0); run(eager, 7.0)
+    torch.cuda.synchronize()
+    for t, r, what in zip(leaves, run_ref, ("means3D", "shs", "opacities", "scales", "rotations", "means2D")):
+        same_bits(t.grad, r, f"three accumulated backwards: {what}")
+
+
+def st_ok(dropin):
+    st = list(dropin.stats().values())
+    return len(st) == 1 and st[0]["replays"] >= 2

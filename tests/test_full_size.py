@@ -299,6 +299,69 @@ def test_multi_view_sum_at_full_size_equals_the_oracle_sum(built_lib, c_oracle, 
         assert mx <= TOL and fr <= OUTLIERS, f"{name}: sum over {n_views} views of {k}: max {mx:.2e} ({fr:.1e} of the entries beyond 1e-5)"
 
 
+def test_c3_four_views_through_one_captured_call_equal_the_oracle_sum(built_lib, c_oracle):
+    """The path `python bench.py` TIMES: BASELINE.json configs[2] -- C3, 500 k Gaussians @1024^2 -- with the 4
+    views of a step through ONE `graph.CapturedViews` call: K1 / K8 of all views in one launch each, K6 / K7 of the batch (256-entry
+    items at this size), gradients summed in the GradArena, the launches REPLAYED from captured hipGraphs (the third call and
+    every later one; the first two run eagerly and learn the pair counts). Compared after a replay: every view's radii (bit-
+    exact), image and means2D gradient against the scalar C oracle, and the arena against the float64 sum of the oracle's
+    per-view gradients -- what the optimizer consumes (training/object_trainer.py:302-382)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from dreamscene_amd import multiview, synth
+    from dreamscene_amd.graph import CapturedViews
+    from dreamscene_amd.rasterizer import RasterContext
+    n_views = 4
+    cfg = dict(CONFIGS["C3"], cams=list(range(n_views)))
+    g, cams = _scene(cfg)
+    P, K, D = g["means3D"].shape[0], cfg["K"], cfg["D"]
+    bg = np.array([1.0, 1.0, 1.0], np.float32)
+    params = {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in g.items()}
+    ups = [_upstream(cfg, cam.image_height, cam.image_width, i) for i, cam in enumerate(cams)]
+    ups_dev = [(torch.tensor(a, device=DEV), torch.tensor(b, device=DEV)) for a, b in ups]
+    arena = multiview.GradArena(P, K, torch.device(DEV))
+    sl = [settings_for(cam, bg, D, DEV) for cam in cams]
+    rast = CapturedViews(context=RasterContext(grad_arena=arena))
+    for rep in range(5):
+        m2d = torch.zeros((n_views, P, 3), device=DEV, requires_grad=True)
+        outs = rast(sl, means3D=params["means3D"], means2D=m2d, opacities=params["opacities"], shs=params["shs"],
+                    scales=params["scales"], rotations=params["rotations"])
+        ts, gs = [], []
+        for (img, _, da), (gi, gda) in zip(outs, ups_dev):
+            ts += [img, da]
+            gs += [gi, gda]
+        (g2d,) = torch.autograd.grad(ts, [m2d], gs)
+        torch.cuda.synchronize()
+    assert rast.stats["replays"] >= 2 and rast.stats["overflows"] == 0, rast.stats     # the compared step WAS a graph replay
+    seg = int(rast._cap.states[0].binning.seg_len)
+    assert seg == 256, seg                                                              # the <256> kernels, as in the timed region
+
+    def one(j):          # (ctypes releases the GIL: the four scalar oracle views run side by side)
+        v = oracle_view(c_oracle, cams[j], P, K, D, bg)
+        f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        b = c_oracle.backward(v, f, ups[j][0], ups[j][1], g["means3D"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+        return f, b
+    with ThreadPoolExecutor(max_workers=n_views) as ex:
+        res = list(ex.map(one, range(n_views)))
+    ref = {k: None for k in ("dL_dmeans3D", "dL_dshs", "dL_dopacity", "dL_dscales", "dL_drotations")}
+    for j, (f, b) in enumerate(res):
+        assert np.array_equal(outs[j][1].cpu().numpy(), f["radii"]), f"view {j}: radii"
+        fr, mx = _frac_over(outs[j][0].detach().cpu().numpy(), f["image"])
+        assert mx <= TOL and fr <= OUTLIERS, f"view {j}: image {mx:.2e}"
+        fr, mx = _frac_over(outs[j][2].detach().cpu().numpy(), f["depth_alpha"])
+        assert mx <= TOL and fr <= OUTLIERS, f"view {j}: depth_alpha {mx:.2e}"
+        fr, mx = _frac_over(g2d[j].cpu().numpy(), b["dL_dmeans2D"])
+        assert mx <= TOL and fr <= OUTLIERS, f"view {j}: dL/dmeans2D {mx:.2e}"
+        for k in ref:
+            x = np.asarray(b[k], dtype=np.float64)
+            ref[k] = x if ref[k] is None else ref[k] + x
+    got = dict(dL_dmeans3D=arena.views["means3D"], dL_dshs=arena.views["shs"], dL_dopacity=arena.views["opacities"],
+               dL_dscales=arena.views["scales"], dL_drotations=arena.views["rotations"])
+    for k, r in ref.items():
+        fr, mx = _frac_over(got[k].cpu().numpy().reshape(r.shape), r)
+        print(f"[C3, 4 views, one captured call] {k}: {mx:.1e}")
+        assert mx <= TOL and fr <= OUTLIERS, f"C3 captured: sum over 4 views of {k}: max {mx:.2e} ({fr:.1e} of the entries beyond 1e-5)"
+
+
 def test_c2_vs_the_independent_float64_autograd_oracle(built_lib):
     """BASELINE.json configs[1] at its full size (100 k Gaussians @512^2) against the INDEPENDENT restatement: the vectorised
     PyTorch oracle in float64 with libm's exp and autograd's backward (oracle/torch_oracle.py) -- no expression tree, no

@@ -174,3 +174,73 @@ def test_segment_length_policy(monkeypatch):
     assert R.RasterContext().seg_len is None and R.RasterContext(seg_len=128).snapshot().seg_len == 128
     from dreamscene_amd import _lib as L
     assert dict(L.GsrBinning._fields_)["seg_len"] is not None and L.GsrBinning.seg_len.offset == L.GsrBinning.bwd_items_cap.offset + 4
+
+
+def test_side_stream_fork_proof_without_a_gpu():
+    """rasterizer._SideStreams: a call may fork from an OLDER event of the caller's stream only when every input is the same
+    live tensor object at the same autograd version as when it was last seen complete (the soundness argument of the internal
+    streams). Here: the bookkeeping alone, no device."""
+    import gc
+    from dreamscene_amd import rasterizer as R
+    sd = object.__new__(R._SideStreams)
+    sd.known, sd.fork, sd.stats = {}, None, dict(calls=0, forks=0, reused_forks=0)
+    a, b = torch.zeros(4), torch.ones(3)
+    assert not sd.proves_complete([a, b])                 # never seen
+    sd.remember([a, b])
+    assert sd.proves_complete([a, b]) and sd.proves_complete([b])
+    a.add_(1.0)                                           # an in-place write bumps the version: not proven any more
+    assert not sd.proves_complete([a, b]) and sd.proves_complete([b])
+    sd.remember([a])
+    assert sd.proves_complete([a, b])
+    c = a.detach()                                        # another OBJECT on the same storage: unknown (and shares the counter)
+    assert not sd.proves_complete([c])
+    sd.remember([c])
+    c.mul_(2.0)                                           # writing through the alias invalidates the original as well
+    assert not sd.proves_complete([a])
+    # a dead tensor's id may be reused by a new one: the weak reference tells them apart
+    t = torch.zeros(5)
+    sd.remember([t])
+    key = id(t)
+    del t
+    gc.collect()
+    assert sd.known[key][0]() is None
+    class Fake:                                           # (an object that lands on the recycled id must not be "known")
+        _version = 0
+    sd.known[id(Fake)] = sd.known[key]
+    assert not sd.proves_complete([Fake])
+    # the raw-pointer writer of this repo tells the counters (optim.FusedAdam ends with increment_version)
+    p = torch.zeros(3, requires_grad=True)
+    sd.remember([p])
+    with torch.no_grad():
+        torch.autograd.graph.increment_version(p)
+    assert not sd.proves_complete([p])
+    # policy: off unless asked for
+    assert R._side_streams_wanted(None) == R.SIDE_STREAMS_DEFAULT
+    assert R._side_streams_wanted(R.RasterContext(side_streams=3)) == 3
+    assert R._side_streams_wanted(R.RasterContext(side_streams=99)) == R.SIDE_STREAMS_MAX
+
+
+def test_bench_picks_the_timed_kernel_instance():
+    """bench.py's `roofline.traffic`: the counters of the EXACT template instance that was timed, never a max over a prefix
+    (round 4 printed k_render_bwd<128>'s bytes for the timed k_render_bwd<256>)."""
+    import bench
+    names = ["k_render_bwd<128>", "k_render_bwd<256>", "k_render_fwd<false, 128>", "k_render_fwd<false, 256>",
+             "k_preprocess<16, false, (anonymous namespace)::NoScene>", "k_preprocess_views<16>",
+             "k_preprocess_bwd_views<16, false, true, 4>"]
+    pk = lambda stage, seg, batched: bench.pick_kernel(names, bench.timed_kernel_name(stage, 16, seg, batched),
+                                                       bench.STAGE_KERNEL.get(stage), stage)
+    assert pk("render_bwd", 256, True) == "k_render_bwd<256>"
+    assert pk("render_bwd", 128, False) == "k_render_bwd<128>"
+    assert pk("render_fwd", 256, True) == "k_render_fwd<false, 256>"
+    assert pk("preprocess", 256, True) == "k_preprocess_views<16>"
+    assert pk("preprocess", 128, False) == "k_preprocess<16, false, (anonymous namespace)::NoScene>"
+    assert pk("preprocess_bwd", 256, True) == "k_preprocess_bwd_views<16, false, true, 4>"
+    # two instances and no exact match: no number rather than a wrong one
+    assert bench.pick_kernel(["k_render_bwd<64>", "k_render_bwd<128>"], "k_render_bwd<256>", "k_render_bwd", "render_bwd") is None
+    # an old profile with ONE un-templated entry still resolves
+    assert bench.pick_kernel(["k_render_bwd", "k_render_fwd<false>"], "k_render_bwd<256>", "k_render_bwd", "render_bwd") == "k_render_bwd"
+    # launch-accurate bytes: K1 / K8 read the parameter rows once per launch
+    P, N, HW, K, D = 500_000, 3_069_904, 1024 * 1024, 16, 3
+    one = bench.algorithmic_bytes("preprocess", P, N, HW, K, D, views=1)
+    four = bench.algorithmic_bytes("preprocess", P, N, HW, K, D, views=4)
+    assert four < 4 * one and four - one == 3 * P * 48
