@@ -208,6 +208,8 @@ static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geo
   if (!geom->splat || !geom->radii || !geom->tiles_touched || !geom->block_offsets || !geom->scratch) return GSR_EINVAL;
   if (!aligned16(geom->splat)) return GSR_EINVAL;
   if (geom->scratch_bytes < gsr_project_scratch_bytes(v->P)) return GSR_ESCRATCH;
+  // async: the word holds GSR_N_PENDING until a kernel has stored the count (gsrast.h: the caller may poll it)
+  if (!sync) *n_pairs_host = GSR_N_PENDING;
   hipStream_t stream = (hipStream_t)stream_;
   GsrDeviceGuard dev(geom->splat);
   {
@@ -254,6 +256,7 @@ int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGa
       return GSR_EINVAL;   // the views' projection scratch buffers must be equally spaced
   }
   if (v0.P == 0) return GSR_OK;
+  for (int k = 0; k < n_views; ++k) n_pairs_pinned[k] = GSR_N_PENDING;   // until a kernel has stored view k's count
   hipStream_t stream = (hipStream_t)stream_;
   GsrDeviceGuard dev(geoms[0].splat);
   {

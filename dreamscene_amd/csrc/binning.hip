@@ -603,7 +603,8 @@ uint64_t* gsr_pair_counts(const GsrGeom& geom, int32_t P) { return carve_project
 // After K1 (which wrote the depth keys into scratch.k0): depth sort, depth-ordered counts, scan -> N.
 // batch > 1: `batch` views whose projection scratch buffers are `bstride` bytes apart (geom = the first view's) go
 // through every launch together (blockIdx.y = view); n_pairs_all (device, may be NULL) receives the N of all views.
-// n_pairs_all may be page-locked HOST memory (device-visible): the column path's k_col_plan stores the counts there itself.
+// n_pairs_all may be page-locked HOST memory (device-visible): on the column path the first pass of the depth sort stores the
+// counts there itself (radix_sort.h, kOsEarlyN).
 int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, GsrProfile* prof, int batch,
                            size_t bstride, uint64_t* n_pairs_all) {
   const int32_t P = v.P;
@@ -625,7 +626,9 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
     //  take the order from the buffer the flag word names)
     where = radix_sort_u32<kItemsSmall, kOsItemsSmall>(s.k0, s.v0, s.k1, s.v1, nullptr, (uint64_t)P, 32, true, n_vis_dev, s.hist,
                                                        s.totals, stream, batch, bstride, /*state_cleared=*/true,
-                                                       /*last_pass_may_skip=*/columns);
+                                                       /*last_pass_may_skip=*/columns,
+                                                       /*early N (kOsEarlyN): the column path's packed rectangles*/
+                                                       columns ? s.rects : nullptr, columns ? n_pairs_all : nullptr);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }
@@ -642,8 +645,11 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
                          bstride);
       hipLaunchKernelGGL(k_radix_scan, dim3(gx, nby), dim3(256), 0, stream, s.hist1, nrun, s.totals1,
                          (const uint64_t*)n_vis_dev, (uint32_t)kColRun, bstride);
+      // (the host's copy of N was stored by the first pass of the depth sort, above: kOsEarlyN. k_col_plan must NOT store it
+      //  again -- a caller that polled the early word has moved on, and a late second store could land in the word after the
+      //  caller re-armed it for its next call on this stream)
       hipLaunchKernelGGL(k_col_plan, dim3(1, nby), dim3(256), 0, stream, s.totals1, gx, s.colstart, n_pairs_dev, bstride,
-                         n_pairs_all);
+                         (uint64_t*)nullptr);
     } else {
       hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx,
                          geom.tiles_touched, geom.block_offsets);

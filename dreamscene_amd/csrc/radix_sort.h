@@ -258,6 +258,13 @@ constexpr uint32_t kOsTableOff = kOsMaxPasses * kRadix + 16;   // u32 words: [pa
 // is copied: this word of the state is set instead and the result stays in the buffers the pass would have read (the top
 // byte of the depths of one object: 8 us of every depth sort)
 constexpr uint32_t kOsSkipFlag = kOsMaxPasses * kRadix + 8;
+// Words [kOsEarlyN, kOsEarlyN + 1] (one aligned u64): the sum of a per-key WEIGHT over the keys that survive the first
+// pass, accumulated by k_os_hist when the caller hands it a weight array -- for the depth sort the packed tile rectangle
+// of every Gaussian (w x h = its number of (tile, Gaussian) pairs), i.e. the pair count N of the view. The first tile of
+// the first pass copies it to a caller-given (page-locked host) word: N reaches the host when the depth sort has barely
+// started (K1 + one histogram launch) instead of after the whole sort + the column counts (round 5: the per-view
+// interface blocked ~100 us per call on that word).
+constexpr uint32_t kOsEarlyN = kOsMaxPasses * kRadix + 10;
 constexpr uint64_t kOsMaxN = 1ull << 28;
 
 typedef __attribute__((address_space(1))) uint32_t gsr_gu32;
@@ -273,9 +280,11 @@ __host__ inline size_t os_state_words(uint64_t n, int items) { return (size_t)kO
 template <bool DROP>
 __global__ void __launch_bounds__(kSortThreads)
 k_os_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev, uint64_t cap, int passes,
-          uint32_t* __restrict__ os, size_t bstride) {
+          uint32_t* __restrict__ os, size_t bstride, const uint32_t* __restrict__ wrect) {
   keys = batch_ptr(keys, bstride); n_dev = batch_ptr(n_dev, bstride); os = batch_ptr(os, bstride);
+  wrect = batch_ptr(wrect, bstride);
   __shared__ uint32_t h[kOsMaxPasses][kRadix];
+  __shared__ uint32_t wsum[kSortThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const uint64_t n = eff_count(n_dev, cap);
   const uint64_t base = (uint64_t)blockIdx.x * kOsHistTile;
@@ -285,10 +294,20 @@ k_os_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev,
   __syncthreads();
   constexpr int kPer = kOsHistTile / kSortThreads;
   uint32_t kk[kPer];
+  uint32_t weight = 0;          // (this thread's share of the weight sum, see kOsEarlyN)
 #pragma unroll
   for (int it = 0; it < kPer; ++it) {
     const uint64_t e = base + (uint64_t)(it * kSortThreads + tid);
     kk[it] = e < n ? keys[e] : 0xFFFFFFFFu;
+    if (wrect && e < n && (!DROP || kk[it] != 0xFFFFFFFFu)) {
+      const uint32_t r = wrect[e];                             // packed x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24
+      weight += (((r >> 16) & 255u) + 1u) * ((r >> 24) + 1u);
+    }
+  }
+  if (wrect) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) weight += (uint32_t)__shfl_xor((int)weight, o, 64);
+    if (lane == 0) wsum[tid >> 6] = weight;
   }
 #pragma unroll
   for (int it = 0; it < kPer; ++it) {
@@ -322,6 +341,10 @@ k_os_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_dev,
   for (int p = 0; p < passes; ++p) {
     const uint32_t c = h[p][tid];
     if (c) atomicAdd(&os[p * kRadix + tid], c);
+  }
+  if (wrect && tid == 0) {
+    const uint64_t w = ((uint64_t)wsum[0] + wsum[1]) + ((uint64_t)wsum[2] + wsum[3]);
+    if (w) atomicAdd(reinterpret_cast<unsigned long long*>(os + kOsEarlyN), (unsigned long long)w);
   }
 }
 
@@ -368,7 +391,8 @@ template <bool IOTA, int ITEMS, bool DROP>
 __global__ void __launch_bounds__(kSortThreads)
 k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
           uint32_t* __restrict__ vals_out, const uint64_t* __restrict__ n_dev, uint64_t cap, int pass,
-          uint32_t* __restrict__ os, uint64_t* __restrict__ n_out, size_t bstride, const int may_skip) {
+          uint32_t* __restrict__ os, uint64_t* __restrict__ n_out, size_t bstride, const int may_skip,
+          uint64_t* __restrict__ early_out) {
   keys_in = batch_ptr(keys_in, bstride); vals_in = batch_ptr(vals_in, bstride);
   keys_out = batch_ptr(keys_out, bstride); vals_out = batch_ptr(vals_out, bstride);
   n_dev = batch_ptr(n_dev, bstride); os = batch_ptr(os, bstride); n_out = batch_ptr(n_out, bstride);
@@ -409,6 +433,11 @@ k_os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ val
   for (int w = 0; w < 4; ++w) wh[w][tid] = 0;
   __syncthreads();
   const uint32_t tile = s_tile;
+  // the weight sum k_os_hist left (kOsEarlyN) -> the caller's word of this view (page-locked host memory: the pair count of
+  // the view, long before the sort is over). Ticket 0 exists in every launch (n > 0 or not).
+  if (early_out && tile == 0 && tid == 0)
+    __hip_atomic_store(early_out + blockIdx.y, *reinterpret_cast<const uint64_t*>(os + kOsEarlyN), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   if ((uint64_t)tile * T >= n) return;     // (every later ticket is beyond n as well: nobody waits for this tile)
   // exclusive scan of the pass's global digit histogram: where digit d starts in the output
   uint32_t dbase;
@@ -560,7 +589,8 @@ int radix_sort_u32_legacy(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1
 template <int ITEMS, int OS_ITEMS>
 int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const uint64_t* n_dev, uint64_t cap,
                    int bits, bool iota, uint64_t* n_compact, uint32_t* hist, uint32_t* totals, hipStream_t stream,
-                   int batch = 1, size_t bstride = 0, bool state_cleared = false, bool last_pass_may_skip = false) {
+                   int batch = 1, size_t bstride = 0, bool state_cleared = false, bool last_pass_may_skip = false,
+                   const uint32_t* early_rects = nullptr, uint64_t* early_out = nullptr) {
   const int passes = (bits + kRadixBits - 1) / kRadixBits;
   if (cap >= kOsMaxN || passes > kOsMaxPasses)
     return radix_sort_u32_legacy<ITEMS>(k0, v0, k1, v1, n_dev, cap, bits, iota, n_compact, hist, totals, stream, batch, bstride);
@@ -571,22 +601,28 @@ int radix_sort_u32(uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, const
   if (!state_cleared &&
       gsr_zero_async(hist, os_state_words(cap, OS_ITEMS) * 4, stream, bstride, (uint32_t)batch) != hipSuccess) return passes & 1;
   const bool drop = iota && n_compact;
+  // early_rects / early_out (depth sort of the column path only): see kOsEarlyN
+  if (!drop) { early_rects = nullptr; early_out = nullptr; }
+  if (!early_out) early_rects = nullptr;
   if (drop)
-    hipLaunchKernelGGL((k_os_hist<true>), grid_h, dim3(kSortThreads), 0, stream, k0, n_dev, cap, passes, hist, bstride);
+    hipLaunchKernelGGL((k_os_hist<true>), grid_h, dim3(kSortThreads), 0, stream, k0, n_dev, cap, passes, hist, bstride,
+                       early_rects);
   else
-    hipLaunchKernelGGL((k_os_hist<false>), grid_h, dim3(kSortThreads), 0, stream, k0, n_dev, cap, passes, hist, bstride);
+    hipLaunchKernelGGL((k_os_hist<false>), grid_h, dim3(kSortThreads), 0, stream, k0, n_dev, cap, passes, hist, bstride,
+                       (const uint32_t*)nullptr);
   uint32_t *ka = k0, *va = v0, *kb = k1, *vb = v1;
   for (int p = 0; p < passes; ++p) {
     if (p == 0 && drop) {
       hipLaunchKernelGGL((k_os_pass<true, OS_ITEMS, true>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap, p,
-                         hist, n_compact, bstride, 0);
+                         hist, n_compact, bstride, 0, early_rects ? early_out : (uint64_t*)nullptr);
       n_dev = n_compact;
     } else if (p == 0 && iota) {
       hipLaunchKernelGGL((k_os_pass<true, OS_ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap, p,
-                         hist, (uint64_t*)nullptr, bstride, 0);
+                         hist, (uint64_t*)nullptr, bstride, 0, (uint64_t*)nullptr);
     } else {
       hipLaunchKernelGGL((k_os_pass<false, OS_ITEMS, false>), grid, dim3(kSortThreads), 0, stream, ka, va, kb, vb, n_dev, cap, p,
-                         hist, (uint64_t*)nullptr, bstride, (last_pass_may_skip && p == passes - 1 && p > 0) ? 1 : 0);
+                         hist, (uint64_t*)nullptr, bstride, (last_pass_may_skip && p == passes - 1 && p > 0) ? 1 : 0,
+                         (uint64_t*)nullptr);
     }
     uint32_t* t = ka; ka = kb; kb = t;
     t = va; va = vb; vb = t;

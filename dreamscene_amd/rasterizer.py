@@ -150,9 +150,12 @@ class _Workspace:
     def __init__(self, dev):
         self.dev = dev
         self.n_pinned = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.n_pinned_np = self.n_pinned.numpy()       # the same page-locked word, readable without a torch call
         self.stats_pinned = torch.zeros(2, dtype=torch.int32).pin_memory()   # [0]: non-empty tiles of the last view
+        self.stats_pinned_np = self.stats_pinned.numpy()
         self.event = torch.cuda.Event()
         self.batch_pinned = None     # pinned int64 [GSR_MAX_BATCH_VIEWS]: pair counts of a batched projection
+        self.batch_pinned_np = None
         self.proj_scratch = None
         self.proj_scratch_batch = None
         self.sort_scratch_batch = None
@@ -181,6 +184,20 @@ def _workspace(dev, stream) -> _Workspace:
 
 def _align(n: int, a: int = 256) -> int:
     return (n + a - 1) // a * a
+
+
+def _wait_pair_counts(words, n: int, event) -> None:
+    """Blocks until the n page-locked pair-count words (numpy int64 view) hold counts. The library stores a count EARLY -- the
+    first workgroup of the depth sort's first pass writes it, ~40 us after K1 started (include/gsrast.h, GSR_N_PENDING = -1
+    until then) -- so the host polls the words instead of waiting ~120 us for the event behind the whole projection; when the
+    event has completed everything in front of it has run and the words are final whatever path wrote them."""
+    spins = 0
+    while True:
+        if (words[0] != -1) if n == 1 else (int(words[:n].min()) != -1):
+            return
+        spins += 1
+        if (spins & 31) == 0 and event.query():
+            return
 
 
 def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
@@ -375,7 +392,7 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                 b.fwd_mode = int(batch["capture"].get("fwd_mode", rc.fwd_variant or 0))
             else:
                 last_active, last_n = ws.last_stats.get((P, H, W), (0, 0))
-                act = int(ws.stats_pinned[0]) if last_active is None else last_active
+                act = int(ws.stats_pinned_np[0]) if last_active is None else last_active
                 b.fwd_mode = int(rc.fwd_variant if rc.fwd_variant is not None else
                                  (act >= 2048 and last_n > 0 and last_n / max(act, 1) < 1024))
             if b.fwd_mode == 1:
@@ -420,8 +437,10 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                 # the batch in one go, then resumes this generator for the bookkeeping
                 yield st.view, geom, g, b, im, cap
                 pinned, pidx, event = batch["pinned"], batch["index"], batch["event"]
+                pinned_np, n_words = batch.get("pinned_np"), int(batch.get("n_views", 1))
             else:
                 pinned, pidx, event = ws.n_pinned, 0, ws.event
+                pinned_np, n_words = ws.n_pinned_np, 1
                 L.check(lib.gsr_forward_project_async(C.byref(st.view), C.byref(g), C.byref(geom), pinned.data_ptr(),
                                                       stream, prof), "gsr_forward_project_async")
                 event.record(torch.cuda.current_stream(dev))
@@ -440,12 +459,16 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                             **{"act_" + k: v for k, v in sc_out.items()}), st
             if batch is None or not batch.get("synced", [False])[0]:
                 t_wait = time.perf_counter()
-                event.synchronize()          # (the render is already enqueued behind the projection: the GPU stays busy)
+                # (the render is already enqueued behind the projection: the GPU stays busy)
+                if pinned_np is not None:
+                    _wait_pair_counts(pinned_np, n_words, event)
+                else:
+                    event.synchronize()
                 if rc.host_stats is not None:
                     rc.host_stats.wait_s += time.perf_counter() - t_wait
                 if batch is not None and "synced" in batch:
                     batch["synced"][0] = True     # one wait covers the pair counts of all views of the batch
-            N = int(pinned[pidx].item()) if P > 0 else 0
+            N = (int(pinned_np[pidx]) if pinned_np is not None else int(pinned[pidx].item())) if P > 0 else 0
             keep_bufs = (buf,)
             view_src = {k: (buf, offs[k]) for k in offs}
             if N >= (1 << 32):

@@ -97,11 +97,13 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
         synced = [False]          # the first generator to resume waits for the projection; the others find it done
         if ws.batch_pinned is None:
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
+            ws.batch_pinned_np = ws.batch_pinned.numpy()
         dirty = [False]
         held = score_sum.clone() if score_sum is not None else None      # (restored if a view outgrows its capacity)
         gens = [R._forward_steps(s, means3D, opacities, shs, colors_precomp, sc(k), rotations, cov3D_precomp, False,
                                  want_aux, None, None,
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
+                                      pinned_np=ws.batch_pinned_np, n_views=V,
                                       event=ws.event, sort=sort_of(k), synced=synced, score=score_sum, score_dirty=dirty,
                                       seg_len=seg),
                                  rc)
@@ -184,8 +186,10 @@ def _views_forward_scene(lib, settings_list, scenes, want_aux, rc):
         synced = [False]          # the first generator to resume waits for the projection; the others find it done
         if ws.batch_pinned is None:
             ws.batch_pinned = torch.zeros(MAX_VIEWS, dtype=torch.int64).pin_memory()
+            ws.batch_pinned_np = ws.batch_pinned.numpy()
         gens = [R._forward_steps(s, None, None, None, None, None, None, None, False, want_aux, None, scenes[k],
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
+                                      pinned_np=ws.batch_pinned_np, n_views=V,
                                       event=ws.event, sort=sort_of(k), synced=synced, seg_len=seg), rc)
                 for k, s in enumerate(settings_list)]
         return _drive_batch(lib, ws, gens, V, dev, stream, prof)

@@ -287,7 +287,14 @@ int gsr_forward_project(const GsrView*, const GsrGaussians*, GsrGeom*, uint64_t*
 /* Same work, no host synchronisation: N lands in *n_pairs_pinned (must be page-locked, device-visible host memory:
  * hipHostMalloc / torch pinned; a kernel stores it there) and is valid once the caller has waited for the work enqueued
  * so far. Used with capacity mode
- * (GsrBinning.count_on_device) so that a whole forward is enqueued without draining the GPU. */
+ * (GsrBinning.count_on_device) so that a whole forward is enqueued without draining the GPU.
+ * The word holds GSR_N_PENDING from the call until a kernel has stored N (P == 0: 0 at once). On grids of at most 256 x 256
+ * tiles with P < 2^24 the count is stored EARLY -- by the first workgroup of the depth sort's first pass, i.e. after K1 and
+ * one histogram launch, long before the sort and the column counts are over (stored once per call: a caller that has
+ * read it may re-arm the word for its next call at once): a caller may poll the word (relaxed loads of page-locked memory)
+ * instead of waiting for the stream, and fall back to the stream when it still reads GSR_N_PENDING after the enqueued work
+ * has finished. */
+#define GSR_N_PENDING UINT64_MAX
 int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uint64_t* n_pairs_pinned, void* stream,
                               GsrProfile* prof);
 
@@ -300,7 +307,8 @@ int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uin
  * with a `scene`, every view has its own GsrScene holding the SAME models and its own noise samples / scales_out.
  * K1 runs once over all views (parameter rows read once) for shs or scene input with K in {1,4,9,16}.
  * No host synchronisation: n_pairs_pinned[n_views] (page-locked, device-visible) receives the counts straight from a
- * kernel and is valid once the work enqueued so far has finished.
+ * kernel and is valid once the work enqueued so far has finished (GSR_N_PENDING until then; stored early and pollable
+ * as described at gsr_forward_project_async).
  * The views then continue with gsr_forward_render_batch (or each with its own gsr_forward_render). */
 #define GSR_MAX_BATCH_VIEWS 16
 #define GSR_PARTIAL_WORDS 32   /* 32-bit words per Gaussian of GsrGrads.partials (16 doubles) */

@@ -203,35 +203,85 @@ def test_object_render_training_augmentations_match_reference(seed):
         np.testing.assert_allclose(got.numpy(), ref[k], atol=1e-5 * scale, err_msg=k)
 
 
+def _f32_case(name, dev, rasterizer_cls=None, settings_cls=None):
+    """One case of object_render_f32.npz (the reference's object_render END TO END IN FP32 over the scalar C oracle) through
+    this repo's glue: returns (fixture arrays of the case, params, out)."""
+    import random as pyrandom
+    from dreamscene_amd import render_api
+    from dreamscene_amd.render_api import GaussianParams
+    d, f = load("object_render.npz"), load("object_render_f32.npz")
+    ref = {k[len(name) + 1:]: f[k] for k in f.files if k.startswith(name + "/")}
+    t = lambda k: torch.tensor(d[k], dtype=torch.float32, device=dev, requires_grad=True)
+    p = GaussianParams(t("xyz"), t("log_scales"), t("raw_rot"), t("logit_opacity"), t("f_dc"), t("f_rest"),
+                       int(d["active_sh_degree"]))
+    cam = _cam_from_fixture(d)
+    test = name == "object_test"
+    seed = 3 if test else int(name[len("object_train"):])
+    pyrandom.seed(seed)
+    torch.manual_seed(seed)
+    kw = dict(test=test) if test else dict(test=False, host_noise=True)
+    if rasterizer_cls is not None:
+        kw.update(rasterizer_cls=rasterizer_cls, settings_cls=settings_cls)
+    out = render_api.object_render(p, cam, torch.tensor(d["bg"], dtype=torch.float32, device=dev), **kw)
+    g = lambda k: torch.tensor(ref[k], device=dev)
+    # the loss of the capture (tests/golden/make_golden.py, run_case): smooth weights + the trainers' scale term
+    ((out["image"] * g("gi")).sum() + (out["depth"] * g("gd")).sum() + (out["alpha"] * g("ga")).sum() +
+     0.01 * torch.mean(out["scales"], dim=-1).mean()).backward()
+    return ref, p, out
+
+
+F32_CASES = ["object_test", "object_train31", "object_train7", "object_train43", "object_train1"]
+
+
+@pytest.mark.parametrize("name", F32_CASES)
+def test_object_render_f32_fixture_replays_on_the_c_oracle(c_oracle, name):
+    """The fp32 end-to-end capture against this repo's glue over the SAME scalar C oracle on the CPU: the glue (activations,
+    augmentation order, disp post-processing, where .grad lands) is the reference's to fp32 rounding."""
+    ref, p, out = _f32_case(name, "cpu", rasterizer_cls=c_oracle.make_rasterizer_module(),
+                            settings_cls=None)
+    assert np.array_equal(out["radii"].numpy(), ref["radii"])
+    np.testing.assert_allclose(out["image"].detach().numpy(), ref["image"], atol=1e-6)
+    np.testing.assert_allclose(out["alpha"].detach().numpy(), ref["alpha"], atol=1e-6)
+    np.testing.assert_allclose(out["depth"].detach().numpy(), ref["depth"], atol=1e-5)
+    for k, attr in TRAIN_KEYS.items():
+        got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
+        scale = max(1.0, float(np.abs(ref[k]).max()))
+        np.testing.assert_allclose(got.numpy(), ref[k], atol=1e-5 * scale, err_msg=k)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [31, 7, 43, 1])
-def test_object_render_training_augmentations_hip(built_lib, seed):
-    """The same four training-mode cases through the HIP rasterizer (noise drawn on the host generator so that the seeded
-    draws are the captured ones)."""
+@pytest.mark.parametrize("name", F32_CASES)
+def test_object_render_f32_fixture_hip(built_lib, name):
+    """The reference's object_render -- test=True and the four training-mode cases (SH degree 0, random / black background,
+    SH noise, scale noise; noise drawn on the host generator so that the seeded draws are the captured ones) -- END TO END
+    through the HIP rasterizer and this repo's glue on the GPU, against the fp32 capture of the reference's own call
+    (object_render_f32.npz): images at 2e-5, every leaf gradient at 3e-5 of its largest entry (the float64
+    captures of rounds 1-2 needed 4e-4 here because they differ from ANY fp32 evaluation of the disp normalisation by 2e-4).
+    3e-5, not 1e-5: the disp normalisation puts |dL/d(depth, alpha)| = 7e4 on its extremal pixels (SEMANTICS.md section 6)."""
     dev = torch.device("cuda:0")
-    d, ref, p, out, rec = _train_case(seed, dev, host_noise=True)
-    assert rec["sh_degree"] == int(ref["sh_degree"])
-    np.testing.assert_allclose(rec["bg"].cpu().numpy(), ref["bg_used"], atol=0)
-    np.testing.assert_allclose(rec["shs"].cpu().numpy(), ref["shs_noisy"], rtol=2e-6, atol=1e-7)
-    np.testing.assert_allclose(rec["scales"].cpu().numpy(), ref["scales_noisy"], rtol=2e-6, atol=1e-9)
+    ref, p, out = _f32_case(name, dev)
     np.testing.assert_allclose(out["image"].detach().cpu().numpy(), ref["image"], atol=2e-5)
     np.testing.assert_allclose(out["alpha"].detach().cpu().numpy(), ref["alpha"], atol=2e-5)
     # exp() of the log-scales on the GPU differs from the CPU capture by an ulp: a radius = ceil(3 sqrt(lambda)) may move by
     # one pixel for a handful of Gaussians (the rasterizer's own radii are bit-exact GIVEN the scales: tests/test_gpu_parity.py)
     dr = np.abs(out["radii"].cpu().numpy().astype(np.int64) - ref["radii"].astype(np.int64))
     assert dr.max() <= 1 and (dr > 0).mean() <= 0.005, (dr.max(), (dr > 0).mean())
+    worst = {}
     for k, attr in TRAIN_KEYS.items():
         got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
         scale = max(1.0, float(np.abs(ref[k]).max()))
-        # (the fixture was captured with the glue AND the rasterizer in float64; here the glue -- activations, noise, the disp
-        #  normalisation with its division by (max - min) -- runs in fp32 torch ops on the GPU: measured <= 2e-4 on g_xyz, <= 7e-5
-        #  elsewhere. The rasterizer itself is pinned at 1e-5 / 3e-5 by the fp32 boundary records, tests/test_boundary_fixture.py)
-        np.testing.assert_allclose(got.cpu().numpy(), ref[k], atol=4e-4 * scale, err_msg=k)
+        worst[k] = float(np.abs(got.cpu().numpy() - ref[k]).max() / scale)
+    print(f"[{name}] worst gradient error / max|ref|: {worst}")
+    for k, e in worst.items():
+        assert e <= 3e-5, f"{name}: {k} {e:.2e} of max|ref| (bar 3e-5)"
 
 
 @pytest.mark.gpu
 def test_object_render_plumbing_hip_vs_reference_fixture(built_lib):
-    """Same fixture, HIP path: the drop-in boundary under the reference's glue semantics."""
+    """The float64-captured fixture, HIP path: the drop-in boundary under the reference's glue semantics -- output dict, images,
+    radii, where .grad lands. (The GRADIENT bar of the HIP path under the glue is test_object_render_f32_fixture_hip, 3e-5
+    against the fp32 capture; against this float64 capture the fp32 disp normalisation alone differs by up to 2e-4, so only the
+    landing sites and magnitudes are checked here.)"""
     from dreamscene_amd import render_api
     d = load("object_render.npz")
     dev = torch.device("cuda:0")
@@ -241,6 +291,7 @@ def test_object_render_plumbing_hip_vs_reference_fixture(built_lib):
                        int(d["active_sh_degree"]))
     cam = _cam_from_fixture(d)
     out = render_api.object_render(p, cam, torch.tensor(d["bg"], device=dev))
+    assert sorted(out.keys()) == list(d["keys"])
     np.testing.assert_allclose(out["image"].detach().cpu().numpy(), d["image"], atol=1e-5)
     np.testing.assert_allclose(out["alpha"].detach().cpu().numpy(), d["alpha"], atol=1e-5)
     np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), d["depth"], atol=2e-4)   # disp: normalised ratio
@@ -252,8 +303,6 @@ def test_object_render_plumbing_hip_vs_reference_fixture(built_lib):
                g_rotation=p._rotation.grad, g_opacity=p._opacity.grad, g_f_dc=p._features_dc.grad,
                g_f_rest=p._features_rest.grad)
     for k, gr in ref.items():
+        assert gr is not None and tuple(gr.shape) == tuple(d[k].shape), k
         scale = max(1.0, float(np.abs(d[k]).max()))
-        # the disp post-processing divides by (depth + 10 alpha + 1e-5) and by (max - min): the fp32 glue vs the float64
-        # capture differs by <= 1.7e-4 of the largest entry (g_xyz; <= 4e-5 elsewhere) -- the rasterizer's own bar is
-        # tests/test_boundary_fixture.py
-        np.testing.assert_allclose(gr.cpu().numpy(), d[k], atol=4e-4 * scale, err_msg=k)
+        np.testing.assert_allclose(gr.cpu().numpy(), d[k], atol=4e-4 * scale, err_msg=k)       # (landing sites; bar: the f32 test)
