@@ -645,6 +645,51 @@ def main():
             forward_only["batched_views_per_s"] = round(n_ * V / dt_, 3)
         forward_only["what"] = "forward only under no_grad (video_inference, object_trainer.py:81-118): one GaussianRasterizer " \
                                "call per view / the same views through one GaussianRasterizerViews call"
+        # importance scoring (prune_list, scene_gaussian.py:1063-1079: 48 sphere cameras, one score_render each, scores summed):
+        # the reference's per-camera loop through the drop-in module against views.importance_scores (cameras 16 at a time
+        # through the batched forward, every view's per-splat pixel counts added to ONE buffer by the kernel's integer atomics)
+        from dreamscene_amd import views as VW_
+        sph = synth.sphere_cameras(48, H, W)
+        sl_sc = [GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=white, scale_modifier=1.0,
+            viewmatrix=t(c.world_view_transform), projmatrix=t(c.full_proj_transform), sh_degree=D, campos=t(c.camera_center),
+            prefiltered=False, score_flag=True) for c in sph]
+        sc_rasts = [GaussianRasterizer(raster_settings=s_) for s_ in sl_sc]
+        m2d_sc = torch.zeros_like(params["means3D"])
+
+        def score_loop():
+            imp = None
+            with torch.no_grad():
+                for r_ in sc_rasts:
+                    sc_ = r_(means3D=params["means3D"], means2D=m2d_sc, shs=params["shs"], colors_precomp=None,
+                             opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"],
+                             cov3D_precomp=None)[0]
+                    imp = sc_ if imp is None else imp.add_(sc_)
+            return imp
+
+        def score_batched():
+            return VW_.importance_scores(sl_sc, params["means3D"].detach(), params["opacities"].detach(),
+                                         shs=params["shs"].detach(), scales=params["scales"].detach(),
+                                         rotations=params["rotations"].detach())
+
+        def reps(fn, n_rep=3):
+            fn(); fn()
+            sync()
+            t_ = time.perf_counter()
+            for _ in range(n_rep):
+                r_ = fn()
+            sync()
+            return (time.perf_counter() - t_) / n_rep, r_
+        dt_loop, imp_a = reps(score_loop)
+        dt_b, imp_b = reps(score_batched)
+        den = float(imp_a.abs().max().clamp_min(1.0))
+        forward_only["score_views"] = {
+            "cameras": 48, "per_camera_loop_views_per_s": round(48 / dt_loop, 1), "batched_views_per_s": round(48 / dt_b, 1),
+            "speedup": round(dt_loop / dt_b, 2), "max_abs_diff_over_max": float((imp_a - imp_b).abs().max()) / den,
+            "what": "the 48-camera importance-score sum of prune_list (scene_gaussian.py:1063-1079), score weight = opacity per "
+                    "contributing (pixel, splat): one score_flag GaussianRasterizer call per camera + imp_list += score / "
+                    "views.importance_scores (16 cameras per batched forward, integer pixel counts in one buffer)"}
+        del sc_rasts, sl_sc, imp_a, imp_b
 
     # the drop-in figure: the same views through one GaussianRasterizer call per view (untimed w.r.t. `value`)
     dropin = None

@@ -87,6 +87,17 @@ def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group) -> None:
         dist.all_gather_into_tensor(out, inp, group=group)
 
 
+def _all_to_all_single(out: torch.Tensor, inp: torch.Tensor, group, output_split_sizes=None, input_split_sizes=None) -> None:
+    if _host_staged(group, out, inp):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, inp.cpu(), output_split_sizes=output_split_sizes,
+                               input_split_sizes=input_split_sizes, group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes,
+                               group=group)
+
+
 def _all_gather_list(outs, inp: torch.Tensor, group) -> None:
     if _host_staged(group, inp):
         parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in outs]
@@ -251,11 +262,11 @@ class GradExchange:
             per = (n + W - 1) // W
             send = wire if per * W == n else torch.cat([wire, wire.new_zeros(per * W - n)])
             recv = torch.empty_like(send)
-            dist.all_to_all_single(recv, send, group=self.group)              # slice r of every rank -> rank r
+            _all_to_all_single(recv, send, self.group)                        # slice r of every rank -> rank r
             mine = recv.view(W, per)[0].clone()
             for r in range(1, W):                                             # rank order: identical sums everywhere
                 mine.add_(recv.view(W, per)[r])
-            dist.all_gather_into_tensor(send, mine, group=self.group)
+            _all_gather_into(send, mine, self.group)
             if send is not wire:
                 wire.copy_(send[:n])
             self._unpack(wire)
@@ -300,14 +311,14 @@ class GradExchange:
         bounds = torch.searchsorted(idx, torch.arange(0, W + 1, device=dev, dtype=idx.dtype) * per)
         send_counts = (bounds[1:] - bounds[:-1]).to(torch.int64)
         recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        _all_to_all_single(recv_counts, send_counts, self.group)
         sc, rc = [int(x) for x in send_counts.tolist()], [int(x) for x in recv_counts.tolist()]      # host read 1
         rows = self._rows_of(idx) if idx.numel() else torch.zeros((0, F), dtype=dt, device=dev)
         idx32 = idx.to(torch.int32)
         got_idx = torch.empty(sum(rc), dtype=torch.int32, device=dev)
         got_rows = torch.empty((sum(rc), F), dtype=dt, device=dev)
-        dist.all_to_all_single(got_idx, idx32, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
-        dist.all_to_all_single(got_rows, rows, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+        _all_to_all_single(got_idx, idx32, self.group, output_split_sizes=rc, input_split_sizes=sc)
+        _all_to_all_single(got_rows, rows, self.group, output_split_sizes=rc, input_split_sizes=sc)
         # owner: add the contributions in rank order (got_* are ordered by source rank) into the owned slice
         lo = r * per
         n_own = max(0, min(per, P - lo))
@@ -322,7 +333,7 @@ class GradExchange:
             off += rc[src]
         own_idx = torch.nonzero(touched[:n_own]).reshape(-1) if n_own else torch.zeros(0, dtype=torch.int64, device=dev)
         cnt = torch.empty(W, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(cnt, torch.tensor([own_idx.numel()], dtype=torch.int64, device=dev), group=self.group)
+        _all_gather_into(cnt, torch.tensor([own_idx.numel()], dtype=torch.int64, device=dev), self.group)
         counts = [int(c) for c in cnt.tolist()]                           # host read 2 (own_idx.numel() was the third)
         nmax = max(max(counts), 1)
         my_idx = torch.zeros(nmax, dtype=torch.int32, device=dev)
@@ -332,8 +343,8 @@ class GradExchange:
             my_rows[:own_idx.numel()] = mine[own_idx]
         all_idx = torch.empty(W * nmax, dtype=torch.int32, device=dev)
         all_rows = torch.empty((W * nmax, F), dtype=dt, device=dev)
-        dist.all_gather_into_tensor(all_idx, my_idx, group=self.group)
-        dist.all_gather_into_tensor(all_rows, my_rows, group=self.group)
+        _all_gather_into(all_idx, my_idx, self.group)
+        _all_gather_into(all_rows, my_rows, self.group)
         self.arena.flat.zero_()
         for o in range(W):                                                # disjoint row ranges: plain stores
             if counts[o]:

@@ -92,7 +92,10 @@ class RasterContext:
     side_streams: Optional[int] = None
 
     def snapshot(self) -> "RasterContext":
-        return dataclasses.replace(self)
+        # (a plain field-for-field copy: dataclasses.replace() re-runs __init__ through a keyword dict, ~3 us per call)
+        c = object.__new__(RasterContext)
+        c.__dict__.update(self.__dict__)
+        return c
 
 
 class HostStats:
@@ -172,6 +175,7 @@ class _Workspace:
 
 
 _WORKSPACES = {}
+_STATE_LAYOUTS = {}     # (sizes of a call) -> (offsets of the regions of its state buffer, total bytes)
 
 
 def _workspace(dev, stream) -> _Workspace:
@@ -297,10 +301,13 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     shs, colors_precomp = _prep(shs, "shs", dev), _prep(colors_precomp, "colors_precomp", dev)
     scales, rotations = _prep(scales, "scales", dev, align=4), _prep(rotations, "rotations", dev)
     cov3D_precomp = _prep(cov3D_precomp, "cov3D_precomp", dev)
-    bg = _prep(s.bg.reshape(-1), "bg", dev, align=4)
-    vm = _prep(s.viewmatrix.reshape(-1), "viewmatrix", dev, align=4)
-    pm = _prep(s.projmatrix.reshape(-1), "projmatrix", dev, align=4)
-    cp = _prep(s.campos.reshape(-1), "campos", dev, align=4)
+    # (contiguous [4,4] / [3] tensors are read through their data pointers as they are: no reshape, which is a view op)
+    bg = _prep(s.bg, "bg", dev, align=4)
+    vm = _prep(s.viewmatrix, "viewmatrix", dev, align=4)
+    pm = _prep(s.projmatrix, "projmatrix", dev, align=4)
+    cp = _prep(s.campos, "campos", dev, align=4)
+    if bg.numel() != 3 or vm.numel() != 16 or pm.numel() != 16 or cp.numel() != 3:
+        raise ValueError("raster settings: bg [3], viewmatrix [4,4], projmatrix [4,4], campos [3] expected")
     K = int(shs.shape[1]) if shs is not None else (K_scene if scene is not None else 0)
     if shs is not None and (shs.dim() != 3 or shs.shape[0] != P or shs.shape[2] != 3):
         raise ValueError(f"shs must be [P,K,3], got {tuple(shs.shape)}")
@@ -355,15 +362,22 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
             """One allocation for everything the backward re-reads (splat, tile counts, offsets, lists, ranges,
             final_T, n_contrib); carved by offsets, no per-tensor allocations."""
             seg = seg_of(cap)
-            sizes = dict(splat=Pm * 48, tiles_touched=Pm * 4, block_offsets=(nb + 8) * 4, point_list=max(cap, 1) * 4,
-                         ranges=tiles * 8, tile_work=(2 * tiles + 2 + 2 * (cap // seg + tiles)) * 4 + 64,
-                         tile_depth=tiles * 4, ckpt=(cap // seg + 1) * 6 * 256 * 4, final_T=H * W * 4,
-                         n_contrib=H * W * 4,
-                         keys_sorted=(max(cap, 1) * 8 if want_keys else 0))
-            offs, tot = {}, 0
-            for k, sz in sizes.items():
-                offs[k] = tot
-                tot += _align(sz)
+            lkey = (Pm, nb, tiles, H, W, cap, seg, bool(want_keys))
+            lay = _STATE_LAYOUTS.get(lkey)
+            if lay is None:
+                sizes = dict(splat=Pm * 48, tiles_touched=Pm * 4, block_offsets=(nb + 8) * 4, point_list=max(cap, 1) * 4,
+                             ranges=tiles * 8, tile_work=(2 * tiles + 2 + 2 * (cap // seg + tiles)) * 4 + 64,
+                             tile_depth=tiles * 4, ckpt=(cap // seg + 1) * 6 * 256 * 4, final_T=H * W * 4,
+                             n_contrib=H * W * 4,
+                             keys_sorted=(max(cap, 1) * 8 if want_keys else 0))
+                offs, tot = {}, 0
+                for k, sz in sizes.items():
+                    offs[k] = tot
+                    tot += _align(sz)
+                if len(_STATE_LAYOUTS) > 64:
+                    _STATE_LAYOUTS.clear()
+                lay = _STATE_LAYOUTS[lkey] = (offs, tot)
+            offs, tot = lay
             buf = torch.empty(tot, dtype=torch.uint8, device=dev)
             base = buf.data_ptr()
             return buf, {k: base + o for k, o in offs.items()}, offs
@@ -455,7 +469,7 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                 st.keep = (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, bg, vm, pm, cp, radii,
                            (buf,), color_alias, da_alias, sc_keep, sc_out)
                 st.versions = []
-                return dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, N=None, cap=cap,
+                return dict(color=color, radii=(radii if P == Pm else radii[:P]), depth_alpha=depth_alpha, score=score, N=None, cap=cap,
                             **{"act_" + k: v for k, v in sc_out.items()}), st
             if batch is None or not batch.get("synced", [False])[0]:
                 t_wait = time.perf_counter()
@@ -508,7 +522,8 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     # ^ backward re-reads the output image (suffix sums from checkpoints). DETACHED aliases on purpose: the objects
     #   returned to autograd acquire grad_fn -> ctx -> this state; keeping them here would close a reference cycle
     #   and defer every free to Python's cyclic GC (measured: memory bloat and 5x slowdown after ~500 views).
-    out = dict(color=color, radii=radii[:P], depth_alpha=depth_alpha, score=score, N=N, **{"act_" + k: v for k, v in sc_out.items()})
+    out = dict(color=color, radii=(radii if P == Pm else radii[:P]), depth_alpha=depth_alpha, score=score, N=N,
+               **{"act_" + k: v for k, v in sc_out.items()})
     if want_aux:
         def view(name, dtype, count, shape=None):
             bufk, off = view_src[name]
@@ -919,9 +934,16 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
 # call and read the outputs right behind it on the host (`disp[alpha <= 0.1]`, scene_gaussian.py:1027), so THEIR forwards
 # serialise whatever this module does; a loop over cameras against persistent tensors (bench.py's `dropin_views_per_s`, the
 # importance-score loop, video_inference) overlaps.
-# Backward: autograd runs every node on the stream its forward ran on and inserts the cross-stream syncs itself, so K7 / K8
-# of a view run on its internal stream. Memory: tensors allocated inside the call belong to the internal stream's allocator
-# pool; the ones handed to the caller are record_stream()ed on the caller's stream, the inputs on the internal one.
+# Forward only: the internal stream is made current INSIDE the autograd Function's forward and left again before it returns,
+# so autograd records the caller's stream for the node and the backward (K7 / K8) runs on the caller's stream as always.
+# (Round 5 measured the other way first -- the whole call under the internal stream, autograd running every backward node on
+# it with its own cross-stream syncs: forward-only 4 480 -> 6 120 views/s at C3, but four forwards + four backwards 2 715 ->
+# 2 580: every backward paid two cross-stream hand-offs and won nothing, the next view's upstream gradient sits behind this
+# view's results on the caller's stream anyway.)
+# Memory: tensors allocated inside the forward belong to the internal stream's allocator pool -- which is what makes the early
+# fork safe (a block of the CALLER'S pool may still be read by kernels the caller enqueued after the old fork event) -- and
+# everything the caller's stream will touch (the outputs, the state the backward re-reads) is record_stream()ed on it; the
+# inputs are record_stream()ed on the internal stream.
 SIDE_STREAMS_DEFAULT = 0
 SIDE_STREAMS_MAX = 8
 
@@ -1011,14 +1033,10 @@ def _call_on_side_stream(n, call, tensors, settings):
     for t in inputs:
         if t.is_cuda:
             t.record_stream(side)         # (their memory must not be handed out again while the internal stream reads it)
-    with torch.cuda.stream(side):
-        out = call()
+    out = call(side)                      # (the Function's forward makes `side` current around its launches and allocations)
     j = sd.joins[k]
     j.record(side)
     cur.wait_event(j)
-    for t in out:
-        if isinstance(t, torch.Tensor) and t.is_cuda:
-            t.record_stream(cur)          # allocated in the internal stream's pool, consumed on the caller's stream
     return out
 
 
@@ -1030,8 +1048,19 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
                 projmatrix, campos, settings, rc):
-        out, st = rasterize_forward_raw(settings, means3D, opacities, shs, colors_precomp, scales, rotations,
-                                        cov3D_precomp, want_aux=False, rc=rc)
+        side = getattr(rc, "_side", None)
+        if side is None:
+            out, st = rasterize_forward_raw(settings, means3D, opacities, shs, colors_precomp, scales, rotations,
+                                            cov3D_precomp, want_aux=False, rc=rc)
+        else:
+            # an internal stream of the module (_SideStreams): current for the launches and allocations of the forward only
+            cur = torch.cuda.current_stream(means3D.device)
+            with torch.cuda.stream(side):
+                out, st = rasterize_forward_raw(settings, means3D, opacities, shs, colors_precomp, scales, rotations,
+                                                cov3D_precomp, want_aux=False, rc=rc)
+            for t_ in (out["color"], out["radii"], out["depth_alpha"], out["score"]) + tuple(st.keep[12]):
+                if t_ is not None:
+                    t_.record_stream(cur)     # allocated in the internal stream's pool; read by the caller / the backward
         ctx.st, ctx.rc = st, rc
         ctx.opac_shape = opacities.shape
         ctx.cam_shapes = (viewmatrix.shape, projmatrix.shape, campos.shape)
@@ -1085,21 +1114,23 @@ class GaussianRasterizer(torch.nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         s = self.raster_settings
         ctx = self.context
+        from . import dropin
+        if dropin.eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, ctx):
+            out = dropin.rasterize(s, means3D, means2D, opacities, shs, scales, rotations, ctx)
+            if out is not None:
+                return out
 
-        def call():
-            from . import dropin
-            if dropin.eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, ctx):
-                out = dropin.rasterize(s, means3D, means2D, opacities, shs, scales, rotations, ctx)
-                if out is not None:
-                    return out
+        def call(side=None):
             rc = (ctx or DEFAULT_CONTEXT).snapshot()
+            rc._side = side
             return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                              cov3D_precomp, s.viewmatrix, s.projmatrix, s.campos, s, rc)
         n = _side_streams_wanted(ctx)
-        # (an arena / statistics / a profile tie the views of a step to one stream: K8 of two views adding into one arena from
-        #  two streams would race; a stream being captured stays as it is)
-        if n > 1 and means3D.is_cuda and (ctx is None or (ctx.grad_arena is None and ctx.densify_stats is None and
-                                                          ctx.profile is None)) \
+        # (a profile times stages with events on ONE stream; a stream being captured stays as it is; the captured ring above has
+        #  its own way of cutting the host's share and is not combined with the internal streams: measured slower together,
+        #  profiles/HISTORY.md round 5. An arena / densification statistics are written by the BACKWARD, which stays on the
+        #  caller's stream: no restriction.)
+        if n > 1 and means3D.is_cuda and (ctx is None or ctx.profile is None) \
                 and not torch.cuda.is_current_stream_capturing():
             return _call_on_side_stream(n, call, (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp), s)
         return call()

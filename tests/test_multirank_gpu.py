@@ -82,8 +82,11 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["dense", "rows"])
+@pytest.mark.parametrize("mode", ["dense", "rows", "direct", "sparse_rs"])
 def test_two_ranks_share_the_gpu(built_lib, tmp_path, mode):
+    """Every wire format of GradExchange with the arena ON THE DEVICE (round 5: `direct` and `sparse_rs` too -- their device
+    halves, searchsorted / index_add_ / the strided packs on GPU tensors, ran on CPU tensors only until now; the collectives
+    themselves are staged through the host under gloo)."""
     from dreamscene_amd import multiview
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)

@@ -2,7 +2,8 @@
 GSR_SIDE_STREAMS). The reference's trainers call the module once per view (scene_gaussian.py:966-1021, loop
 training/object_trainer.py:302-382); with internal streams the results must be exactly those of the same calls on the caller's
 stream -- same bits for outputs and gradients -- whatever the caller does between the calls: persistent inputs (calls may
-overlap), in-place edits, fresh tensors, one backward over all views or one per view, with and without the captured ring."""
+overlap), in-place edits, fresh tensors, one backward over all views or one per view, with and without the captured ring.
+The forward runs on an internal stream; the backward on the caller's (autograd sees the caller's stream for the node)."""
 import numpy as np
 import pytest
 import torch
@@ -78,9 +79,13 @@ def test_internal_streams_change_nothing(built_lib, monkeypatch, one_backward, g
     st = R.side_stream_stats()
     calls = sum(v["calls"] - before.get(k, {}).get("calls", 0) for k, v in st.items())
     reused = sum(v["reused_forks"] - before.get(k, {}).get("reused_forks", 0) for k, v in st.items())
-    assert calls == 5 * len(cams)
-    # persistent inputs: within a step every call after the first is proven unchanged and forks from the older event
-    assert reused >= 5 * (len(cams) - 1) - 1, (calls, reused)
+    if graphs:
+        # the captured ring takes eligible calls first and is not combined with the internal streams (measured slower together)
+        assert calls <= 2 * len(cams), calls          # (only the ring's eager warm-up calls may have passed through the streams)
+    else:
+        assert calls == 5 * len(cams)
+        # persistent inputs: within a step every call after the first is proven unchanged and forks from the older event
+        assert reused >= 5 * (len(cams) - 1) - 1, (calls, reused)
     dropin.reset()
 
 

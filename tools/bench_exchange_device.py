@@ -1,0 +1,132 @@
+"""The DEVICE-side halves of multiview.GradExchange's wire formats, timed on one GPU: everything a format
+does besides the collective itself -- finding the non-zero rows (K8's reached bitmap -> indices), gathering them into
+(index, row) messages, the strided pack / unpack of the active SH columns at D < 3, adding / storing received rows, the local
+sum of `direct`, clearing the arena, and the host reads each format needs. The arena is a REAL one: the sum of a rank's 4 views
+of the configuration (K8 accumulate), so the row sets are what an exchange would see. W = 8 ranks are emulated by applying this
+rank's own message W times (same sizes, same kernels). Prints one JSON object; times in microseconds (CUDA events, median of
+`reps`). usage: python tools/bench_exchange_device.py [--gaussians P] [--res R] [--init-opacity]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dreamscene_amd import _lib, multiview, synth  # noqa: E402
+from dreamscene_amd.rasterizer import GaussianRasterizationSettings, RasterContext  # noqa: E402
+from dreamscene_amd.views import GaussianRasterizerViews  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--gaussians", type=int, default=500_000)
+ap.add_argument("--res", type=int, default=1024)
+ap.add_argument("--views", type=int, default=4)
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--reps", type=int, default=9)
+ap.add_argument("--init-opacity", action="store_true")
+args = ap.parse_args()
+P, res, V, W, K, D = args.gaussians, args.res, args.views, args.world, 16, 3
+dev = torch.device("cuda", 0)
+_lib.load()
+g = synth.g_object(P, seed=0, K=K, init_opacity=args.init_opacity)
+cams = synth.object_cameras(8, res, res)[:V]
+params = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items()}
+gi, gda = (torch.tensor(x, device=dev) for x in synth.upstream_grads(res, res, seed=0))
+t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)
+sl = [GaussianRasterizationSettings(image_height=res, image_width=res, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=t([1, 1, 1]),
+                                    scale_modifier=1.0, viewmatrix=t(c.world_view_transform),
+                                    projmatrix=t(c.full_proj_transform), sh_degree=D, campos=t(c.camera_center),
+                                    prefiltered=False, score_flag=False) for c in cams]
+arena = multiview.GradArena(P, K, dev)
+rast = GaussianRasterizerViews(sl, context=RasterContext(grad_arena=arena))
+for _ in range(3):
+    m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+    outs = rast(means3D=params["means3D"], means2D=m2d, opacities=params["opacities"], shs=params["shs"], scales=params["scales"],
+                rotations=params["rotations"])
+    torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], [m2d], [gi, gda] * V)
+torch.cuda.synchronize()
+snapshot = arena.flat.clone()
+
+
+def timed(fn, reps=args.reps, restore=False):
+    """median GPU time (events) and median host wall time (incl. any host read inside fn) in us"""
+    gpu, wall = [], []
+    for _ in range(reps + 2):
+        if restore:
+            arena.flat.copy_(snapshot)
+            arena.reached_valid = True
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        r = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        wall.append((time.perf_counter() - t0) * 1e6)
+        gpu.append(e0.elapsed_time(e1) * 1e3)
+    gpu, wall = sorted(gpu[2:]), sorted(wall[2:])
+    return {"gpu_us": round(gpu[len(gpu) // 2], 1), "wall_us": round(wall[len(wall) // 2], 1)}, r
+
+
+res_ = {"P": P, "res": res, "views_per_rank": V, "world_emulated": W, "init_opacity": bool(args.init_opacity)}
+out = {}
+for deg in (3, 2, 1, 0):
+    ex = multiview.GradExchange(arena, sh_degree=deg, mode="dense")
+    F = ex.row_floats
+    d = {"row_floats": F}
+    arena.reached_valid = True
+    d["nonzero_rows (bitmap -> indices, one host read inside torch.nonzero)"], idx = timed(ex.nonzero_rows)
+    n = int(idx.numel())
+    d["rows"] = n
+    d["row_frac"] = round(n / P, 4)
+    d["_rows_of (gather index+row message)"], rows = timed(lambda: ex._rows_of(idx))
+    d["message_bytes"] = int(n * (4 + 4 * F))
+    d["_add_rows x1 (scatter-add of one rank's message)"], _ = timed(lambda: ex._add_rows(idx, rows), restore=True)
+    d["_set_rows x1 (sparse_rs: store an owner's reduced rows)"], _ = timed(lambda: ex._set_rows(idx, rows), restore=True)
+    d["arena.flat.zero_()"], _ = timed(lambda: arena.flat.zero_(), restore=True)
+    d["wire_buffer() (dense/direct pack; the arena itself at D = 3)"], wire = timed(ex.wire_buffer, restore=True)
+    d["wire_bytes"] = int(wire.numel() * 4)
+    d["_unpack"], _ = timed(lambda: ex._unpack(wire), restore=True)
+    # direct: local sum of W slices of 1/W of the wire buffer, rank order
+    per = (wire.numel() + W - 1) // W
+    recv = torch.zeros(per * W, device=dev)
+
+    def local_sum():
+        mine = recv.view(W, per)[0].clone()
+        for r in range(1, W):
+            mine.add_(recv.view(W, per)[r])
+        return mine
+    d["direct: local sum of W slices"], _ = timed(local_sum)
+    # sparse_rs owner side: bounds by searchsorted + W index_add_ of 1/W of the rows each
+    bper = (P + W - 1) // W
+
+    def rs_owner():
+        bounds = torch.searchsorted(idx, torch.arange(0, W + 1, device=dev, dtype=idx.dtype) * bper)
+        sc = (bounds[1:] - bounds[:-1]).tolist()        # host read
+        mine = torch.zeros((max(bper, 1), F), device=dev)
+        touched = torch.zeros(max(bper, 1), dtype=torch.bool, device=dev)
+        lo, hi = int(bounds[0]), int(bounds[1])
+        li = idx[lo:hi]
+        for _ in range(W):
+            mine.index_add_(0, li, rows[lo:hi])
+            touched[li] = True
+        own = torch.nonzero(touched).reshape(-1)         # host read
+        return sc, own
+    d["sparse_rs: owner side (bounds + W index_add_ + union, 2 host reads)"], _ = timed(rs_owner)
+    # totals per format at W ranks (device side only; what has to be added to the wire time)
+    g_ = lambda k: d[k]["gpu_us"]
+    w_ = lambda k: d[k]["wall_us"]
+    nz, ro, ad, st, ze = (next(k for k in d if k.startswith(p_)) for p_ in ("nonzero_rows", "_rows_of", "_add_rows", "_set_rows", "arena.flat"))
+    pk, up, ls, rs = (next(k for k in d if k.startswith(p_)) for p_ in ("wire_buffer", "_unpack", "direct:", "sparse_rs:"))
+    d["device_side_total_us"] = {
+        "dense": round((g_(pk) + g_(up)) if deg < 3 else 0.0, 1),
+        "direct": round(((g_(pk) + g_(up)) if deg < 3 else 0.0) + g_(ls), 1),
+        "rows": round(w_(nz) + g_(ro) + g_(ze) + W * g_(ad), 1),
+        # (the owners' reduced rows are the UNION over the ranks' views: ~2x one rank's rows at C3 -> two messages' worth of stores)
+        "sparse_rs": round(w_(nz) + g_(ro) + w_(rs) + g_(ze) + 2.0 * g_(st), 1)}
+    out[f"D{deg}"] = d
+res_["by_degree"] = out
+print(json.dumps(res_))
