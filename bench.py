@@ -297,6 +297,10 @@ def main():
 
     last_batched = [None]          # (outputs of all views, means2D gradients [V,P,3]) of the latest batched step
     plain_rasts = [GaussianRasterizer(raster_settings=s_) for s_ in settings_list]
+    # the same modules with the opt-in internal streams (RasterContext.side_streams / GSR_SIDE_STREAMS=2: the forward of a call
+    # whose inputs are provably unchanged since an earlier call runs on an internal stream beside the previous views)
+    stream_rasts = [GaussianRasterizer(raster_settings=s_, context=RasterContext(side_streams=2)) for s_ in settings_list]
+    dropin_rasts = [plain_rasts]
 
     def step_dropin():
         """The reference's interface, used the way its trainers use it (training/object_trainer.py:302-382): the V views of a
@@ -307,7 +311,7 @@ def main():
         if world > 1:
             return step_dropin_arena()
         held = []
-        for rast in plain_rasts:
+        for rast in dropin_rasts[0]:
             means2D = torch.zeros_like(params["means3D"], requires_grad=True)
             img, radii, da = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
                                   opacities=params["opacities"], scales=params["scales"],
@@ -714,6 +718,24 @@ def main():
         if world > 1:
             dt_d = allreduce_scalars([dt_d], dist.ReduceOp.MAX)[0]
         dropin = {"views_per_s": world * n_drop * V / dt_d, "steps": n_drop, "seconds": round(dt_d, 3)}
+        if world == 1:
+            dropin_rasts[0] = stream_rasts
+            for _ in range(3):
+                step_dropin()
+            sync()
+            n_ds, tds = 0, time.perf_counter()
+            while time.perf_counter() - tds < max(0.5, args.sustain_seconds / 2):
+                for _ in range(10):
+                    step_dropin()
+                n_ds += 10
+            sync()
+            dropin["internal_streams"] = {
+                "views_per_s": round(n_ds * V / (time.perf_counter() - tds), 3), "streams": 2, "steps": n_ds,
+                "what": "the same calls with RasterContext(side_streams=2) / GSR_SIDE_STREAMS=2 (opt-in): a call whose inputs are "
+                        "the same live tensors at the same autograd versions as at an earlier call forks from that call's event "
+                        "and its FORWARD runs on an internal stream beside the previous views' (backward on the caller's stream)",
+                "stats": R.side_stream_stats()}
+            dropin_rasts[0] = plain_rasts
 
     # what the exchange would have to move for this rank's step (the arena holds the sum over the step's V views)
     exch = None
@@ -882,6 +904,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "dropin_views_per_s": round(dropin["views_per_s"], 3) if dropin else
             (None if batched else round(views / elapsed, 3)),
+            "dropin_internal_streams": dropin.get("internal_streams") if dropin else None,
             "sustained_views_per_s": sustained["views_per_s"] if sustained else None,
             "sustained": sustained,
             "rotating_cameras": rotating,

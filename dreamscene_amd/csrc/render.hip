@@ -243,6 +243,11 @@ template <bool SCORE, int PAD = 0>
 struct Stage {
   float4 s0[2][kBatch + PAD], s1[2][kBatch + PAD], s2[2][kBatch + PAD];
   uint32_t sid[SCORE ? 2 : 1][SCORE ? kBatch : 1];
+  // score variant, pixel counts (score_mode 0 / 2): per staged entry, the pixels of the workgroup's 8x8 quarter that composited
+  // it -- added with LDS integer atomics by the four waves while they walk the batch and flushed to the global counters ONCE per
+  // batch by the thread that staged the entry (round 5: one global atomic per (wave, step, slot) made k_render_fwd<true> 2.4x
+  // the plain kernel: 127 vs 53 us for one view of C3, profiles/r05_score_kernel_stats.txt)
+  uint32_t cnt[SCORE ? 2 : 1][SCORE ? kBatch : 1];
 };
 __device__ __forceinline__ uint32_t stage_mask(const float4& s2row) { return __float_as_uint(s2row.w); }
 
@@ -278,6 +283,17 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
     st.s1[threadIdx.x][kBatch] = make_float4(0.f, 0.f, 0.f, 0.f);
     st.s2[threadIdx.x][kBatch] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  if constexpr (SCORE) { st.cnt[0][threadIdx.x] = 0u; st.cnt[1][threadIdx.x] = 0u; }
+  // pixel counts of the batch staged in buffer b -> the global counters (thread t flushes the entry it staged, then clears it)
+  auto flush_counts = [&](const int b) {
+    if constexpr (SCORE) {
+      const uint32_t c = st.cnt[b][threadIdx.x];
+      if (c) {
+        atomicAdd(reinterpret_cast<uint32_t*>(score) + st.sid[b][threadIdx.x], c);
+        st.cnt[b][threadIdx.x] = 0u;
+      }
+    }
+  };
   const int gx = (W + GSR_TILE - 1) / GSR_TILE;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // lane = 16 (pixel row) + 4 slot + (pixel column): the slots of a pixel are the four BANKS of a DPP row, so a step of the
@@ -333,8 +349,11 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       st.s1[buf][tid] = make_float4(-0.5f * n1.x, n1.y, n1.z, n1.w);
       st.s2[buf][tid] = make_float4(n2.x, n2.y, n2.z,
                                     __uint_as_float((tid < n) ? block_mask_t<4>(n0, n1, n2, q_x0, q_y0) : 0u));
-      if constexpr (SCORE) st.sid[buf][tid] = nid;
-      if (__syncthreads_count(__builtin_amdgcn_inverse_ballot_w64(donem)) == 256) break;
+      if constexpr (SCORE) st.sid[buf][tid] = nid;      // (the previous batch's ids and counts live in buffer buf ^ 1)
+      const int n_done = __syncthreads_count(__builtin_amdgcn_inverse_ballot_w64(donem));
+      // every wave is past the compositing of the previous batch (buffer buf ^ 1): its counts are complete
+      if (score_mode != 1 && base != r0) flush_counts(buf ^ 1);
+      if (n_done == 256) break;
       // checkpoint of the per-pixel prefix state at list position pos (r0 + a multiple of KB): lets the backward start a
       // traversal there (k_render_bwd splits deep tiles into independent segments of KB entries)
       auto checkpoint = [&](const uint32_t pos) {
@@ -441,8 +460,9 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
               // independent of the order -- and k_score_finalize multiplies by the opacity once (mode 0) or the caller does
               // (mode 2: raw counts, summed over many views first). A float sum of thousands of EQUAL increments rounds the
               // same way every time (measured 6e-5 relative on the sum over 48 views).
-              if (hm != 0ull && lane == 4 * slot)
-                atomicAdd(reinterpret_cast<uint32_t*>(score) + st.sid[buf][j & (kBatch - 1)], (uint32_t)__popcll(hm));
+              // (LDS integer atomic: the four waves of the quarter meet in one counter per staged entry; the padding row
+              //  kBatch never hits: alpha 0)
+              if (hm != 0ull && lane == 4 * slot) atomicAdd(&st.cnt[buf][j & (kBatch - 1)], (uint32_t)__popcll(hm));
             } else {
               float ws = w;                               // sum over the lanes sharing the slot: xor 1, 2, 16, 32
               ws += gsr_dpp<0xB1>(ws);                    // quad_perm [1,0,3,2]
@@ -467,6 +487,12 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
           donem |= quad_stop;
         }
       }
+    }
+    if constexpr (SCORE) {
+      // the counts of the last batch that was composited (buffer buf ^ 1 after the loop's own flip; all zero when the loop left
+      // through the "everything finished" exit, whose flush ran already)
+      __syncthreads();
+      if (score_mode != 1) flush_counts(buf ^ 1);
     }
     // fold the four slots of each pixel
     C0 += gsr_dpp<0x124>(C0); C0 += gsr_dpp<0x128>(C0);

@@ -249,6 +249,47 @@ def test_object_render_f32_fixture_replays_on_the_c_oracle(c_oracle, name):
         np.testing.assert_allclose(got.numpy(), ref[k], atol=1e-5 * scale, err_msg=k)
 
 
+def test_disp_postprocessing_turns_one_ulp_into_1e_4_of_the_gradients(c_oracle):
+    """WHY the end-to-end gradient tests below cannot be held to the rasterizer's own 3e-5 (VERDICT r4 item 9 asked for it; this
+    is the measured answer, on the CPU, with ONE rasterizer). The reference post-processes the rasterizer's depth / alpha into
+    `disp = clamp((f / (depth + 10 alpha + 1e-5) - min) / (max - min))` with `min` taken over the pixels whose alpha <= 0.1
+    (scene_gaussian.py:1023-1032): a mask, a min and a max -- three pixel SELECTIONS -- sit between the rasterizer and the loss,
+    and the whole gradient of the normalisation lands on the selected pixels with weight ~7e4. Here the scalar C oracle renders
+    every case of object_render_f32.npz twice: as captured, and with its forward outputs multiplied by 1 + 1.2e-7 * N(0,1)
+    (one fp32 ulp: what ANY other order of the fp32 blend sums does). The leaf gradients of the two runs differ by 2e-5 ... 1e-3
+    of their largest entry -- the conditioning of the reference's own function. An implementation whose images agree with the
+    capture to 1e-6 (the HIP path: 7e-7) therefore lands at 1e-4 here whatever its backward does; the rasterizer's backward is
+    pinned where the upstream gradient is FIXED (tests/test_boundary_fixture.py: 3e-5 as recorded, 1e-5 clipped)."""
+    Base = c_oracle.make_rasterizer_module()
+
+    def perturbed(eps, seed):
+        class Rast:
+            def __init__(self, raster_settings):
+                self.r = Base(raster_settings)
+
+            def __call__(self, **kw):
+                img, radii, da = self.r(**kw)
+                g = torch.Generator().manual_seed(seed)
+                return (img * (1 + eps * torch.randn(img.shape, generator=g)), radii,
+                        da * (1 + eps * torch.randn(da.shape, generator=g)))
+        return Rast
+    worst_over_cases = 0.0
+    for name in F32_CASES:
+        ref, p, out = _f32_case(name, "cpu", rasterizer_cls=perturbed(1.2e-7, 1), settings_cls=None)
+        np.testing.assert_allclose(out["image"].detach().numpy(), ref["image"], atol=1e-6)          # images: unchanged at 1e-6
+        worst = 0.0
+        for k, attr in TRAIN_KEYS.items():
+            got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
+            worst = max(worst, float(np.abs(got.numpy() - ref[k]).max() / max(1.0, float(np.abs(ref[k]).max()))))
+        print(f"[{name}] one-ulp forward perturbation -> worst leaf-gradient change {worst:.1e} of max|ref|")
+        assert worst <= 5e-3, (name, worst)
+        worst_over_cases = max(worst_over_cases, worst)
+    assert worst_over_cases >= 1e-4, f"the disp post-processing is better conditioned than documented: {worst_over_cases:.1e}"
+
+
+E2E_GRAD_TOL = 4e-4      # see test_disp_postprocessing_turns_one_ulp_into_1e_4_of_the_gradients
+
+
 def _hip_behind_cpu_glue(dev):
     """A rasterizer class for render_api.object_render whose GLUE stays on the CPU (torch's CPU kernels: the very ops the
     capture ran) while the rasterizer call itself goes to the HIP library: inputs moved to the device (differentiably), outputs
@@ -271,10 +312,11 @@ def _hip_behind_cpu_glue(dev):
 @pytest.mark.parametrize("name", F32_CASES)
 def test_object_render_f32_fixture_hip_behind_the_reference_glue(built_lib, name):
     """The reference's object_render -- test=True and the four training-mode cases (SH degree 0, random / black background, SH
-    noise, scale noise) -- END TO END with the HIP rasterizer behind the CPU glue (the ops the fp32 capture ran,
-    object_render_f32.npz; only the native rasterizer is replaced): images at 2e-5, radii bit-exact, every leaf gradient at 3e-5
-    of its largest entry. 3e-5, not 1e-5: the disp normalisation puts |dL/d(depth, alpha)| = 7e4 on its
-    extremal pixels (SEMANTICS.md section 6)."""
+    noise, scale noise) -- END TO END in fp32 with the HIP rasterizer behind the CPU glue (the very ops the capture ran,
+    object_render_f32.npz; only the native rasterizer is replaced): radii bit-exact, images at 2e-5, leaf gradients at
+    E2E_GRAD_TOL of their largest entry. Measured on one MI355X (round 5): 1e-5 ... 1.3e-4 -- inside what ONE ulp of the forward
+    outputs does to these gradients through the reference's disp post-processing (2e-5 ... 1e-3: the CPU test above), so the
+    bar here is the function's conditioning; the rasterizer's own gradient bar (3e-5 / 1e-5) is the boundary-record test."""
     dev = torch.device("cuda:0")
     ref, p, out = _f32_case(name, "cpu", rasterizer_cls=_hip_behind_cpu_glue(dev), settings_cls=None)
     np.testing.assert_allclose(out["image"].detach().numpy(), ref["image"], atol=2e-5)
@@ -287,7 +329,7 @@ def test_object_render_f32_fixture_hip_behind_the_reference_glue(built_lib, name
         worst[k] = float(np.abs(got.numpy() - ref[k]).max() / scale)
     print(f"[{name}, CPU glue] worst gradient error / max|ref|: {worst}")
     for k, e in worst.items():
-        assert e <= 3e-5, f"{name}: {k} {e:.2e} of max|ref| (bar 3e-5)"
+        assert e <= E2E_GRAD_TOL, f"{name}: {k} {e:.2e} of max|ref| (bar {E2E_GRAD_TOL})"
 
 
 @pytest.mark.gpu
@@ -295,10 +337,7 @@ def test_object_render_f32_fixture_hip_behind_the_reference_glue(built_lib, name
 def test_object_render_f32_fixture_hip_gpu_glue(built_lib, name):
     """The same cases with the glue ON THE GPU as well (activations, noise, disp post-processing in torch's CUDA kernels; noise
     drawn on the host generator so that the seeded draws are the captured ones). torch's GPU exp / sigmoid differ from the CPU's
-    by an ulp, a radius = ceil(3 sqrt(lambda)) may move by one pixel for a handful of Gaussians, and the disp normalisation
-    -- (disp - min) / (max - min) with its whole gradient on the two extremal pixels -- turns a 1e-7 change of its input into a
-    1e-4 change of the gradients: measured 3e-5 ... 1.3e-4 of max|ref| (round 5, one MI355X). The bar is the conditioning of the
-    reference's own function, 2e-4; the rasterizer's bar is the test above (same inputs in: 3e-5)."""
+    by an ulp (a radius = ceil(3 sqrt(lambda)) may move by one pixel for a handful of Gaussians); gradients as above."""
     dev = torch.device("cuda:0")
     ref, p, out = _f32_case(name, dev)
     np.testing.assert_allclose(out["image"].detach().cpu().numpy(), ref["image"], atol=2e-5)
@@ -308,15 +347,14 @@ def test_object_render_f32_fixture_hip_gpu_glue(built_lib, name):
     for k, attr in TRAIN_KEYS.items():
         got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
         scale = max(1.0, float(np.abs(ref[k]).max()))
-        np.testing.assert_allclose(got.cpu().numpy(), ref[k], atol=2e-4 * scale, err_msg=f"{name}: {k}")
+        np.testing.assert_allclose(got.cpu().numpy(), ref[k], atol=E2E_GRAD_TOL * scale, err_msg=f"{name}: {k}")
 
 
 @pytest.mark.gpu
 def test_object_render_plumbing_hip_vs_reference_fixture(built_lib):
     """The float64-captured fixture, HIP path: the drop-in boundary under the reference's glue semantics -- output dict, images,
-    radii, where .grad lands. (The GRADIENT bar of the HIP path under the glue is test_object_render_f32_fixture_hip, 3e-5
-    against the fp32 capture; against this float64 capture the fp32 disp normalisation alone differs by up to 2e-4, so only the
-    landing sites and magnitudes are checked here.)"""
+    radii, where .grad lands; gradients at E2E_GRAD_TOL (the conditioning of the reference's disp post-processing:
+    test_disp_postprocessing_turns_one_ulp_into_1e_4_of_the_gradients)."""
     from dreamscene_amd import render_api
     d = load("object_render.npz")
     dev = torch.device("cuda:0")
@@ -340,4 +378,4 @@ def test_object_render_plumbing_hip_vs_reference_fixture(built_lib):
     for k, gr in ref.items():
         assert gr is not None and tuple(gr.shape) == tuple(d[k].shape), k
         scale = max(1.0, float(np.abs(d[k]).max()))
-        np.testing.assert_allclose(gr.cpu().numpy(), d[k], atol=4e-4 * scale, err_msg=k)       # (landing sites; bar: the f32 test)
+        np.testing.assert_allclose(gr.cpu().numpy(), d[k], atol=E2E_GRAD_TOL * scale, err_msg=k)
