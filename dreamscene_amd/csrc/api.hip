@@ -12,7 +12,7 @@ bool gsr_preprocess_bwd_views_supported(const GsrView&, const GsrGaussians&, con
 int gsr_launch_preprocess_bwd_views(int n_views, const GsrView* views, const GsrGaussians* gs, const GsrGeom* geoms,
                                     const GsrGrads* outs, hipStream_t);
 int gsr_launch_depth_order(GsrGeom&, const GsrView&, hipStream_t, GsrProfile*, int batch, size_t bstride,
-                           uint64_t* n_pairs_all);
+                           uint64_t* n_pairs_all, bool early);
 uint64_t* gsr_pair_counts(const GsrGeom&, int32_t P);
 bool gsr_uses_columns(const GsrView&);
 int gsr_launch_binning(const GsrView&, const GsrGeom&, uint64_t cap, const uint64_t* n_dev, const uint64_t* n_dev_vis,
@@ -220,7 +220,7 @@ static int forward_project(const GsrView* v, const GsrGaussians* g, GsrGeom* geo
   uint64_t* n_dev = n_pairs_device(geom, v->P);
   // async + column path: n_pairs_host is page-locked and k_col_plan stores N there itself (no copy operation)
   const bool direct = !sync && gsr_uses_columns(*v);
-  rc = gsr_launch_depth_order(*geom, *v, stream, prof, 1, 0, direct ? n_pairs_host : nullptr);
+  rc = gsr_launch_depth_order(*geom, *v, stream, prof, 1, 0, direct ? n_pairs_host : nullptr, /*early=*/true);
   if (rc) return rc;
   if (!direct) GSR_HIP(hipMemcpyAsync(n_pairs_host, n_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   if (sync) {
@@ -275,7 +275,7 @@ int gsr_forward_project_batch(int32_t n_views, const GsrView* views, const GsrGa
     }
   }
   // k_col_plan stores the views' counts straight into the caller's page-locked array (no copy operation)
-  int rc = gsr_launch_depth_order(geoms[0], v0, stream, prof, n_views, bstride, n_pairs_pinned);
+  int rc = gsr_launch_depth_order(geoms[0], v0, stream, prof, n_views, bstride, n_pairs_pinned, /*early=*/false);
   if (rc) return rc;
   for (int k = 1; k < n_views; ++k)
     geoms[k].sorted_idx = reinterpret_cast<uint32_t*>((char*)geoms[0].sorted_idx + (size_t)k * bstride);

@@ -605,8 +605,12 @@ uint64_t* gsr_pair_counts(const GsrGeom& geom, int32_t P) { return carve_project
 // through every launch together (blockIdx.y = view); n_pairs_all (device, may be NULL) receives the N of all views.
 // n_pairs_all may be page-locked HOST memory (device-visible): on the column path the first pass of the depth sort stores the
 // counts there itself (radix_sort.h, kOsEarlyN).
+// early: store N into n_pairs_all from the first pass of the depth sort (radix_sort.h, kOsEarlyN; column path only) instead of
+// from k_col_plan. It costs the histogram kernel one more word per key (k_os_hist 17.5 -> 21.9 us per 4-view launch at C3) and
+// buys a caller that blocks on the word ~80 us per view: the single-view entry point asks for it, the batched one (whose callers
+// are GPU-bound and wait for all views anyway) does not.
 int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, GsrProfile* prof, int batch,
-                           size_t bstride, uint64_t* n_pairs_all) {
+                           size_t bstride, uint64_t* n_pairs_all, bool early) {
   const int32_t P = v.P;
   if (geom.scratch_bytes < gsr_project_scratch_bytes(P) || !geom.scratch) return GSR_ESCRATCH;
   ProjectScratch s = carve_project(geom.scratch, P);
@@ -628,7 +632,8 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
                                                        s.totals, stream, batch, bstride, /*state_cleared=*/true,
                                                        /*last_pass_may_skip=*/columns,
                                                        /*early N (kOsEarlyN): the column path's packed rectangles*/
-                                                       columns ? s.rects : nullptr, columns ? n_pairs_all : nullptr);
+                                                       (columns && early) ? s.rects : nullptr,
+                                                       (columns && early) ? n_pairs_all : nullptr);
     geom.sorted_idx = where ? s.v1 : s.v0;
     GSR_HIP(hipGetLastError());
   }
@@ -645,11 +650,11 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
                          bstride);
       hipLaunchKernelGGL(k_radix_scan, dim3(gx, nby), dim3(256), 0, stream, s.hist1, nrun, s.totals1,
                          (const uint64_t*)n_vis_dev, (uint32_t)kColRun, bstride);
-      // (the host's copy of N was stored by the first pass of the depth sort, above: kOsEarlyN. k_col_plan must NOT store it
+      // (early: the host's copy of N was stored by the first pass of the depth sort, above. k_col_plan must then NOT store it
       //  again -- a caller that polled the early word has moved on, and a late second store could land in the word after the
-      //  caller re-armed it for its next call on this stream)
+      //  caller re-armed it for its next call on this stream. ONE store per call, here or there.)
       hipLaunchKernelGGL(k_col_plan, dim3(1, nby), dim3(256), 0, stream, s.totals1, gx, s.colstart, n_pairs_dev, bstride,
-                         (uint64_t*)nullptr);
+                         early ? (uint64_t*)nullptr : n_pairs_all);
     } else {
       hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx,
                          geom.tiles_touched, geom.block_offsets);

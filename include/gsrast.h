@@ -307,8 +307,9 @@ int gsr_forward_project_async(const GsrView*, const GsrGaussians*, GsrGeom*, uin
  * with a `scene`, every view has its own GsrScene holding the SAME models and its own noise samples / scales_out.
  * K1 runs once over all views (parameter rows read once) for shs or scene input with K in {1,4,9,16}.
  * No host synchronisation: n_pairs_pinned[n_views] (page-locked, device-visible) receives the counts straight from a
- * kernel and is valid once the work enqueued so far has finished (GSR_N_PENDING until then; stored early and pollable
- * as described at gsr_forward_project_async).
+ * kernel and is valid once the work enqueued so far has finished (GSR_N_PENDING until then; pollable as described at
+ * gsr_forward_project_async, but stored at the END of the projection here -- the early store costs the batched launches
+ * more than their GPU-bound callers gain).
  * The views then continue with gsr_forward_render_batch (or each with its own gsr_forward_render). */
 #define GSR_MAX_BATCH_VIEWS 16
 #define GSR_PARTIAL_WORDS 32   /* 32-bit words per Gaussian of GsrGrads.partials (16 doubles) */
