@@ -716,7 +716,10 @@ __device__ __forceinline__ void k1_clear_sort_state(const K1Views& vb) {
 
 template <int KT>
 // (4 waves per SIMD: 128 VGPRs instead of 131 at K = 16, no spills -- the kernel is latency-bound on its division chains)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef GSR_K1_WAVES
+#define GSR_K1_WAVES 4
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES, GSR_K1_WAVES)))
 k_preprocess_views(const GsrView v, const GsrGaussians g, const K1Views vb) {
   constexpr int F = 3 * KT;
   const int P = v.P, W = v.image_width, H = v.image_height;
