@@ -32,6 +32,7 @@ from __future__ import annotations
 
 import ctypes as C
 import time
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -64,12 +65,30 @@ def _sig(settings_list, tensors, rc, per_view, by_ptr=True):
             tuple(rc.stats_views) if isinstance(rc.stats_views, (list, tuple)) else rc.stats_views)
 
 
+class _Pending:
+    """Lives as long as the autograd graph of a differentiable captured forward whose backward has not run: while one is alive,
+    forward-only calls of the same CapturedViews (an eval render between a step's forward and its backward) take the eager
+    path and leave the capture's static state and outputs alone."""
+    __slots__ = ("done", "__weakref__")
+
+    def __init__(self):
+        self.done = False
+
+
 class _CapturedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, owner, settings_list, rc):
-        outs, cap_state, eager_states = owner._forward(settings_list, means3D, opacities, shs, scales, rotations, rc)
+    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, owner, settings_list, rc, differentiable):
+        forward_only_beside = (not differentiable) and owner._backward_pending()
+        if forward_only_beside:
+            outs, cap_state, eager_states = owner._eager_forward(settings_list, means3D, opacities, shs, scales, rotations, rc)
+        else:
+            outs, cap_state, eager_states = owner._forward(settings_list, means3D, opacities, shs, scales, rotations, rc)
         ctx.owner, ctx.rc, ctx.cap_state, ctx.eager_states = owner, rc, cap_state, eager_states
         ctx.generation = cap_state.generation if cap_state is not None else -1
+        ctx.pending = None
+        if differentiable and cap_state is not None:
+            ctx.pending = _Pending()
+            owner._pending = weakref.ref(ctx.pending)
         ctx.opac_shape = opacities.shape
         ctx.per_view_scales = scales.dim() == 3
         ctx.set_materialize_grads(False)
@@ -90,16 +109,20 @@ class _CapturedFn(torch.autograd.Function):
             # gradient would be computed from the wrong image. So: refuse. Callers with this pattern use the module whose
             # outputs are the caller's own -- GaussianRasterizerViews, or GaussianRasterizer with GSR_DROPIN_GRAPHS=1
             # (dropin.py: outputs copied out, state leased until the backward) -- INTEGRATION.md section 5b.
+            # (A FORWARD-ONLY call in between -- torch.no_grad(), an eval render -- does not get here: while a differentiable
+            #  forward waits for its backward such calls run eagerly and leave the capture alone, _Pending.)
             raise RuntimeError(
                 "CapturedViews: backward of a forward whose captured state has been overwritten by a later forward "
                 f"(replay {ctx.generation}, now {cap.generation}); run backward before the next forward of the same "
                 "CapturedViews, or use GaussianRasterizerViews for calls whose graphs must stay alive")
         o = ctx.owner._backward(ctx.cap_state, ctx.eager_states, grads, ctx.rc, ctx.per_view_scales)
+        if ctx.pending is not None:
+            ctx.pending.done = True
         if ctx.rc.grad_arena is not None:
             return (None, o["dL_dmeans2D"], None, None, o["dL_dscales"] if ctx.per_view_scales else None, None,
-                    None, None, None)
+                    None, None, None, None)
         return (o["dL_dmeans3D"], o["dL_dmeans2D"], o["dL_dshs"], o["dL_dopacities"].reshape(ctx.opac_shape),
-                o["dL_dscales"], o["dL_drotations"], None, None, None)
+                o["dL_dscales"], o["dL_drotations"], None, None, None, None)
 
 
 class CapturedViews(torch.nn.Module):
@@ -117,7 +140,12 @@ class CapturedViews(torch.nn.Module):
         self._ptr_repeats, self._last_ptr_sig = 0, None
         self._peak_n = 0
         self._fwd_mode = 0
+        self._pending = None        # weak reference to the _Pending of the latest differentiable captured forward
         self.stats = dict(captures=0, replays=0, eager_steps=0, overflows=0, staged_inputs=False)
+
+    def _backward_pending(self) -> bool:
+        p = self._pending() if self._pending is not None else None
+        return p is not None and not p.done
 
     # ------------------------------------------------------------------------------------------------ public
     def forward(self, raster_settings_list: Sequence, means3D, means2D, opacities, shs, scales, rotations) -> List[tuple]:
@@ -132,7 +160,9 @@ class CapturedViews(torch.nn.Module):
         if means2D.shape[0] != V:
             raise ValueError(f"means2D must be [V,P,3] with V = {V} views")
         rc = (self.context or R.DEFAULT_CONTEXT).snapshot()
-        flat = _CapturedFn.apply(means3D, means2D, shs, opacities, scales, rotations, self, settings_list, rc)
+        differentiable = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (means3D, means2D, shs, opacities, scales, rotations))
+        flat = _CapturedFn.apply(means3D, means2D, shs, opacities, scales, rotations, self, settings_list, rc, differentiable)
         return [tuple(flat[3 * k:3 * k + 3]) for k in range(V)]
 
     # ------------------------------------------------------------------------------------------------ internals

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import settings_for, small_scene, tol_ok
+from tests.util import same_bits, settings_for, small_scene, tol_ok
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -202,6 +202,56 @@ def test_backward_of_an_overwritten_replay_is_refused(built_lib):
         loss_first.backward()
     sum(img.sum() for img, _, _ in second).backward()       # the latest forward still differentiates
     assert rast.stats["captures"] == 1
+
+
+def test_an_eval_render_between_forward_and_backward_leaves_the_capture_alone(built_lib):
+    """a trainer that renders an eval view (torch.no_grad()) between a step's forward and its backward. While a
+    differentiable captured forward waits for its backward, forward-only calls of the same CapturedViews run eagerly: the step's
+    backward still differentiates ITS forward (same gradients as without the eval render), the eval render is the eager one's."""
+    from dreamscene_amd import synth
+    from dreamscene_amd.graph import CapturedViews, WARM_CALLS
+    from dreamscene_amd.views import GaussianRasterizerViews
+    V, P, H, W, K, D = 2, 2500, 96, 128, 4, 1
+    g, t = _setup(P, H, W, K, seed=37)
+    cams = synth.object_cameras(6, H, W, radius=3.0)
+    rast = CapturedViews()
+    leaves = [t[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+
+    def sets_of(step):
+        return [settings_for(cams[(step + k) % 6], [0.2, 0.3, 0.4], D, DEV) for k in range(V)]
+
+    def fwd(step):
+        m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+        return rast(sets_of(step), means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                    rotations=t["rotations"])
+    for step in range(WARM_CALLS + 2):          # warm-up, capture, one replay -- each with its own backward
+        sum(img.sum() + da.sum() for img, _, da in fwd(step)).backward()
+    for x in leaves:
+        x.grad = None
+    sum(img.sum() + da.sum() for img, _, da in fwd(20)).backward()          # reference: step 20 without anything in between
+    ref = [x.grad.clone() for x in leaves]
+    for x in leaves:
+        x.grad = None
+    outs = fwd(20)
+    loss = sum(img.sum() + da.sum() for img, _, da in outs)
+    replays = rast.stats["replays"]
+    with torch.no_grad():                        # the eval render: other cameras, forward only
+        ev = rast(sets_of(3), means3D=t["means3D"], means2D=torch.zeros((V, P, 3), device=DEV), opacities=t["opacities"],
+                  shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        ev_ref = GaussianRasterizerViews(sets_of(3))(means3D=t["means3D"], means2D=torch.zeros((V, P, 3), device=DEV),
+                                                     opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                                                     rotations=t["rotations"])
+    assert rast.stats["replays"] == replays, "the forward-only call replayed the capture whose backward is pending"
+    for (a, _, b), (c, _, d) in zip(ev, ev_ref):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    loss.backward()                              # no "overwritten by a later forward"
+    torch.cuda.synchronize()
+    for x, r, n in zip(leaves, ref, ("means3D", "shs", "opacities", "scales", "rotations")):
+        same_bits(x.grad, r, f"dL/d{n} with an eval render in between")
+    with torch.no_grad():                        # nothing pending any more: forward-only calls replay again
+        rast(sets_of(4), means3D=t["means3D"], means2D=torch.zeros((V, P, 3), device=DEV), opacities=t["opacities"],
+             shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    assert rast.stats["replays"] == replays + 1
 
 
 def test_staged_inputs_go_back_to_zero_copy_when_addresses_settle(built_lib):
