@@ -648,8 +648,13 @@ int gsr_launch_depth_order(GsrGeom& geom, const GsrView& v, hipStream_t stream, 
       hipLaunchKernelGGL(k_col_hist, dim3((nb + 7u) / 8u * 8u, nby), dim3(256), 0, stream, n_vis_dev, geom.sorted_idx,
                          (const uint32_t*)(where ? s.v0 : s.v1), (const uint32_t*)s.hist, s.rects, rect_sorted, gx, nrun, s.hist1,
                          bstride);
-      hipLaunchKernelGGL(k_radix_scan, dim3(gx, nby), dim3(256), 0, stream, s.hist1, nrun, s.totals1,
-                         (const uint64_t*)n_vis_dev, (uint32_t)kColRun, bstride);
+      // (rows of one entry per run of 64 Gaussians: the wide scan walks them in a quarter of the chunks)
+      if (nrun > 1024u)
+        hipLaunchKernelGGL(k_radix_scan_wide, dim3(gx, nby), dim3(1024), 0, stream, s.hist1, nrun, s.totals1,
+                           (const uint64_t*)n_vis_dev, (uint32_t)kColRun, bstride);
+      else
+        hipLaunchKernelGGL(k_radix_scan, dim3(gx, nby), dim3(256), 0, stream, s.hist1, nrun, s.totals1,
+                           (const uint64_t*)n_vis_dev, (uint32_t)kColRun, bstride);
       // (early: the host's copy of N was stored by the first pass of the depth sort, above. k_col_plan must then NOT store it
       //  again -- a caller that polled the early word has moved on, and a late second store could land in the word after the
       //  caller re-armed it for its next call on this stream. ONE store per call, here or there.)
@@ -702,8 +707,12 @@ static int launch_binning_columns(int n, const GsrView& v, const GsrGeom* geoms,
     GsrStageTimer t(prof, stream, GSR_STAGE_SORT);
     hipLaunchKernelGGL(k_row_hist, dim3((nblk + 7u) / 8u * 8u, ny), dim3(kSortThreads), 0, stream, vals1, s.colstart, gx, cap, nbits, nblk,
                        hist, ps, ss);
-    hipLaunchKernelGGL(k_radix_scan, dim3(kRadix, ny), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr,
-                       1u, ss);
+    if (nblk > 1024u)
+      hipLaunchKernelGGL(k_radix_scan_wide, dim3(kRadix, ny), dim3(1024), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr,
+                         1u, ss);
+    else
+      hipLaunchKernelGGL(k_radix_scan, dim3(kRadix, ny), dim3(256), 0, stream, hist, nblk, totals, (const uint64_t*)nullptr,
+                         1u, ss);
     hipLaunchKernelGGL(k_row_scatter, dim3((nblk + 7u) / 8u * 8u, ny), dim3(kSortThreads), 0, stream, vals1, ro, s.colstart, gx, gy, cap,
                        nbits, nblk, hist, totals, ps, ss);
     GSR_HIP(hipGetLastError());

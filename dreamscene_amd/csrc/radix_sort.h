@@ -82,24 +82,27 @@ k_radix_hist(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ n_d
 
 // Workgroup d scans row d of hist[256][nblk] in place (exclusive) and writes the row total to totals[d].
 // n_items (device, may be NULL): only the first ceil(*n_items / per_block) entries of a row are in use.
-__global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblk_stride,
-                                                    uint32_t* __restrict__ totals,
-                                                    const uint64_t* __restrict__ n_items, uint32_t per_block,
-                                                    size_t bstride) {
+// THREADS per workgroup: a row is walked in chunks of 4 THREADS entries, three barriers each -- the column path's rows are
+// 7 813 entries long at 500 k Gaussians (one per run of 64), 8 chunks with 256 threads, 2 with 1 024 (round 5: 8.8 us per
+// 4-view launch with 256; the kernel is a serial chain of chunks, nothing else).
+template <int THREADS>
+__device__ __forceinline__ void radix_scan_body(uint32_t* __restrict__ hist, uint32_t nblk_stride, uint32_t* __restrict__ totals,
+                                                const uint64_t* __restrict__ n_items, uint32_t per_block, size_t bstride) {
   hist = batch_ptr(hist, bstride); totals = batch_ptr(totals, bstride); n_items = batch_ptr(n_items, bstride);
   uint32_t nblk = nblk_stride;
   if (n_items) {
     const uint64_t used = (*n_items + per_block - 1) / per_block;
     if (used < nblk) nblk = (uint32_t)used;
   }
-  __shared__ uint32_t wave_tot[4];
+  constexpr int NW = THREADS / 64;
+  __shared__ uint32_t wave_tot[NW];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t* row = hist + (uint64_t)blockIdx.x * nblk_stride;
   if (tid == 0) carry_s = 0;
   __syncthreads();
   constexpr uint32_t kPer = 4;
-  for (uint32_t base = 0; base < nblk; base += 256 * kPer) {
+  for (uint32_t base = 0; base < nblk; base += THREADS * kPer) {
     uint32_t x[kPer];
     uint32_t s = 0;
     const uint32_t first = base + tid * kPer;
@@ -117,7 +120,8 @@ __global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist,
     if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
     uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) woff += (w < wave) ? wave_tot[w] : 0u;
     const uint32_t carry = carry_s;
     uint32_t run = carry + woff + inc - s;
 #pragma unroll
@@ -126,10 +130,22 @@ __global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist,
       run += x[k];
     }
     __syncthreads();
-    if (tid == 255) carry_s = carry + woff + inc;
+    if (tid == THREADS - 1) carry_s = carry + woff + inc;
     __syncthreads();
   }
   if (tid == 0) totals[blockIdx.x] = carry_s;
+}
+__global__ void __launch_bounds__(256) k_radix_scan(uint32_t* __restrict__ hist, uint32_t nblk_stride,
+                                                    uint32_t* __restrict__ totals,
+                                                    const uint64_t* __restrict__ n_items, uint32_t per_block,
+                                                    size_t bstride) {
+  radix_scan_body<256>(hist, nblk_stride, totals, n_items, per_block, bstride);
+}
+__global__ void __launch_bounds__(1024) k_radix_scan_wide(uint32_t* __restrict__ hist, uint32_t nblk_stride,
+                                                          uint32_t* __restrict__ totals,
+                                                          const uint64_t* __restrict__ n_items, uint32_t per_block,
+                                                          size_t bstride) {
+  radix_scan_body<1024>(hist, nblk_stride, totals, n_items, per_block, bstride);
 }
 
 // IOTA: values are the element indices themselves (first pass of the depth sort), vals_in unused.
