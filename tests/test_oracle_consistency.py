@@ -8,7 +8,7 @@ import torch
 from tests.util import err, oracle_view, small_scene
 
 
-def _torch_run(g, cam, bg, D, dt=torch.float64, score=False, score_mode=0, cam_grad=True, gi=None, gda=None):
+def _torch_run(g, cam, bg, D, dt=torch.float64, score=False, score_mode=0, cam_grad=True, gi=None, gda=None, tile_window=None):
     from oracle import torch_oracle as TO
     P = g["means3D"].shape[0]
     t = {k: torch.tensor(v, dtype=dt, requires_grad=True) for k, v in g.items()}
@@ -20,7 +20,7 @@ def _torch_run(g, cam, bg, D, dt=torch.float64, score=False, score_mode=0, cam_g
                     D, cp, False, score)
     res, aux = TO.rasterize(t["means3D"], m2d, t["opacities"], shs=t.get("shs"), colors_precomp=t.get("colors_precomp"),
                             scales=t.get("scales"), rotations=t.get("rotations"), cov3D_precomp=t.get("cov3D_precomp"),
-                            settings=s, score_mode=score_mode, return_aux=True)
+                            settings=s, score_mode=score_mode, return_aux=True, tile_window=tile_window)
     sc = None
     if score:
         sc, img, radii, da = res
