@@ -298,7 +298,7 @@ static int check_render(const GsrView* v, const GsrGeom* geom, uint64_t n_pairs,
   if (rc) return rc;
   if (!geom || !b || !img) return GSR_EINVAL;
   if (!b->ranges || !img->color || !img->depth_alpha || !img->final_T || !img->n_contrib) return GSR_EINVAL;
-  if (!b->tile_work || !img->tile_depth || !img->ckpt) return GSR_EINVAL;
+  if (!b->tile_work || !img->tile_depth) return GSR_EINVAL;      // (img->ckpt may be NULL: forward only, gsrast.h)
   if (b->seg_len != 0u && b->seg_len != 64u && b->seg_len != 128u && b->seg_len != 256u) return GSR_EINVAL;
   if (b->fwd_mode == 1 && gsr_seg_len(*b) != 256u) return GSR_EINVAL;     // the whole-tile forward checkpoints every 256 entries
   if ((uint64_t)b->bwd_items_cap < n_pairs / gsr_seg_len(*b) + gsr_num_tiles(v->image_height, v->image_width)) return GSR_EINVAL;

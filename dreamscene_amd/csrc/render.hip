@@ -361,6 +361,7 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
       // checkpoint of the per-pixel prefix state at list position pos (r0 + a multiple of KB): lets the backward start a
       // traversal there (k_render_bwd splits deep tiles into independent segments of KB entries)
       auto checkpoint = [&](const uint32_t pos) {
+        if (ckpt == nullptr) return;     // forward only (GsrImages.ckpt NULL): nobody will start a backward traversal here
         float f0 = C0, f1 = C1, f2 = C2, f3 = Dp, f4 = Wt;       // folds over the slots (row_ror:4, :8): all lanes take part
         f0 += gsr_dpp<0x124>(f0); f0 += gsr_dpp<0x128>(f0);
         f1 += gsr_dpp<0x124>(f1); f1 += gsr_dpp<0x128>(f1);
@@ -566,7 +567,7 @@ render_fwd_tile_body(const uint32_t item, const int W, const int H, const uint32
                                   __uint_as_float((tid < n) ? block_mask_t<8>(n0, n1, n2, tile_x0, tile_y0) : 0u));
     if constexpr (SCORE) st.sid[buf][tid] = nid;
     if (__syncthreads_count(__builtin_amdgcn_inverse_ballot_w64(donem)) == 256) break;
-    if (base != r0 && p.inside) {
+    if (base != r0 && p.inside && ckpt != nullptr) {
       float* ck = ckpt + (size_t)(base / kBatch) * (6 * 256) + ((p.py - tile_y0) * GSR_TILE + (p.px - tile_x0));
       ck[0] = T; ck[256] = C0; ck[512] = C1; ck[768] = C2; ck[1024] = Dp; ck[1280] = Wt;
     }

@@ -351,6 +351,9 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
         proj_bytes = int(lib.gsr_project_scratch_bytes(P))
         proj_scratch = batch["scratch"] if batch is not None else ws.scratch("proj_scratch", proj_bytes)
 
+        # forward only (the caller knows no backward can follow: torch.no_grad() / nothing requires a gradient): K6 writes no
+        # checkpoints (GsrImages.ckpt = NULL) and their region of the state buffer -- the largest -- is not allocated
+        fwd_only = bool(getattr(rc, "_forward_only", False)) and not capture
         seg_req = (batch.get("seg_len") if batch is not None else None) or seg_len or rc.seg_len
         if seg_req and int(seg_req) not in (64, 128, 256):
             raise ValueError(f"seg_len must be 64, 128 or 256, got {seg_req}")
@@ -362,12 +365,12 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
             """One allocation for everything the backward re-reads (splat, tile counts, offsets, lists, ranges,
             final_T, n_contrib); carved by offsets, no per-tensor allocations."""
             seg = seg_of(cap)
-            lkey = (Pm, nb, tiles, H, W, cap, seg, bool(want_keys))
+            lkey = (Pm, nb, tiles, H, W, cap, seg, bool(want_keys), fwd_only)
             lay = _STATE_LAYOUTS.get(lkey)
             if lay is None:
                 sizes = dict(splat=Pm * 48, tiles_touched=Pm * 4, block_offsets=(nb + 8) * 4, point_list=max(cap, 1) * 4,
                              ranges=tiles * 8, tile_work=(2 * tiles + 2 + 2 * (cap // seg + tiles)) * 4 + 64,
-                             tile_depth=tiles * 4, ckpt=(cap // seg + 1) * 6 * 256 * 4, final_T=H * W * 4,
+                             tile_depth=tiles * 4, ckpt=(0 if fwd_only else (cap // seg + 1) * 6 * 256 * 4), final_T=H * W * 4,
                              n_contrib=H * W * 4,
                              keys_sorted=(max(cap, 1) * 8 if want_keys else 0))
                 offs, tot = {}, 0
@@ -413,7 +416,7 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
                 b.seg_len = 256      # the whole-tile forward checkpoints every 256 entries (the buffers above are large enough)
             b.stats_host = ws.stats_pinned.data_ptr()
             im.final_T, im.n_contrib, im.tile_depth = ptrs["final_T"], ptrs["n_contrib"], ptrs["tile_depth"]
-            im.ckpt = ptrs["ckpt"]
+            im.ckpt = None if fwd_only else ptrs["ckpt"]     # (forward only: no checkpoints written, none allocated)
 
         NSIZED = ("point_list", "ranges", "tile_work", "tile_depth", "ckpt", "final_T", "n_contrib", "keys_sorted")
         n_pairs = C.c_uint64(0)
@@ -1120,9 +1123,15 @@ class GaussianRasterizer(torch.nn.Module):
             if out is not None:
                 return out
 
+        # no backward can follow (torch.no_grad(), or nothing that requires a gradient): the forward writes no checkpoints
+        forward_only = not (torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
+                                                        cov3D_precomp, s.viewmatrix, s.projmatrix, s.campos)))
+
         def call(side=None):
             rc = (ctx or DEFAULT_CONTEXT).snapshot()
             rc._side = side
+            rc._forward_only = forward_only
             return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                              cov3D_precomp, s.viewmatrix, s.projmatrix, s.campos, s, rc)
         n = _side_streams_wanted(ctx)

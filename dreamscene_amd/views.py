@@ -262,10 +262,15 @@ class GaussianRasterizerViews(torch.nn.Module):
             if not all(s.score_flag for s in self.raster_settings_list):
                 raise ValueError("the views of one call must all have score_flag set, or none of them")
             with torch.no_grad():
+                rc_s = (self.context or R.DEFAULT_CONTEXT).snapshot()
+                rc_s._forward_only = True
                 res = rasterize_views_forward_raw(self.raster_settings_list, means3D, opacities, shs, colors_precomp, scales,
-                                                  rotations, cov3D_precomp, rc=(self.context or R.DEFAULT_CONTEXT).snapshot())
+                                                  rotations, cov3D_precomp, rc=rc_s)
             return [(o["score"], o["color"], o["radii"], o["depth_alpha"]) for o, _ in res]
         rc = (self.context or R.DEFAULT_CONTEXT).snapshot()
+        rc._forward_only = not (torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                                        cov3D_precomp)))
         flat = _RasterizeViews.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                      tuple(self.raster_settings_list), rc)
         return [tuple(flat[3 * k:3 * k + 3]) for k in range(V)]
@@ -283,6 +288,7 @@ def importance_scores(settings_list: Sequence, means3D, opacities, shs=None, col
     if not settings_list or not all(s.score_flag for s in settings_list):
         raise ValueError("importance_scores needs at least one view, all with score_flag=True")
     rc = (context or R.DEFAULT_CONTEXT).snapshot()
+    rc._forward_only = True
     P = int(means3D.shape[0])
     dev = means3D.device
     chunk = max(1, min(int(chunk), MAX_VIEWS))

@@ -184,7 +184,10 @@ typedef struct GsrImages {
   uint32_t* tile_depth;   /* [tiles] max of n_contrib over the tile (written by forward, read by backward) */
   float* ckpt;            /* [n_pairs/seg_len + 1][6][256] per-pixel prefix state (T, C rgb, depth, alpha) at the
                              seg_len-entry boundaries of the tile lists (slot = absolute list position / seg_len;
-                             GsrBinning.seg_len), written by the forward as far as it composites, read by the backward */
+                             GsrBinning.seg_len), written by the forward as far as it composites, read by the backward.
+                             NULL = FORWARD ONLY: the forward writes no checkpoints (inference renders, importance
+                             scores: ~5 % of K6 and the largest region of the saved state); gsr_backward* then refuses
+                             the view with GSR_EINVAL */
   float* important_score; /* [P], or NULL (score_flag False). MUST BE ALL ZERO ON ENTRY: K6 adds to it. score_mode 1: float
                              sums (several views may add into one buffer); score_mode 2: u32 pixel counts (bit patterns; several
                              views may add into one buffer, the caller converts); score_mode 0: u32 counts converted IN PLACE
