@@ -87,6 +87,16 @@ class GsrAdamGroup(C.Structure):
 
 
 GSR_MAX_ADAM_GROUPS = 32
+GSR_ROWSET_MAX_REGIONS = 8
+
+
+class GsrRowRegion(C.Structure):
+    _fields_ = [("ptr", _f), ("width", C.c_int32), ("stride", C.c_int32)]
+
+
+class GsrRowSet(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("n_regions", C.c_int32), ("regions", GsrRowRegion * GSR_ROWSET_MAX_REGIONS)]
+
 
 # every symbol include/gsrast.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -118,6 +128,11 @@ SYMBOLS = [
                                      C.POINTER(GsrGrads), C.c_void_p, C.c_void_p]),
     ("gsr_forward_render_batch", C.c_int, [C.c_int32, C.POINTER(GsrView), C.POINTER(GsrGeom), C.c_uint64,
                                            C.POINTER(GsrBinning), C.POINTER(GsrImages), C.c_void_p, C.c_void_p]),
+    ("gsr_rows_scratch_bytes", C.c_size_t, [C.c_int32]),
+    ("gsr_rows_pack", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                C.c_size_t, C.c_void_p]),
+    ("gsr_rows_unpack", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_int32, C.c_void_p,
+                                  C.c_void_p]),
     ("gsr_knn_scratch_bytes", C.c_size_t, [C.c_int32]),
     ("gsr_knn_mean_dist2", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("gsr_backward", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom), C.POINTER(GsrBinning),

@@ -22,6 +22,7 @@ SOURCES = {
     "render.hip": ["-fno-slp-vectorize"],
     "knn.hip": ["-ffp-contract=off"],
     "optim.hip": ["-ffp-contract=off"],
+    "exchange.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-fno-gpu-rdc",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,175 @@
+// exchange.hip -- device side of the sparse gradient-exchange formats (include/gsrast.h, GsrRowSet).
+//
+// Views are sharded one per GPU and the only exchange of a step is the sum of the per-rank parameter gradients
+// (training/object_trainer.py:302-382 sums the C_batch_size views of a step in one process). Behind the opaque front layers of
+// an object nothing receives a gradient: 16 % of a rank's rows are non-zero at C3 (K8 leaves them as a bitmap,
+// GsrGrads.reached_mask), so the row formats of multiview.GradExchange move (index, row) messages instead of the whole arena.
+// Their device side was torch index arithmetic over five tensors: 0.5 - 0.7 ms per step at C3 for 18 MB of rows
+// (profiles/r05_exchange_device_c3.json) -- as much as the step itself. These three kernels are that device side at memory speed:
+//   gsr_rows_pack    bitmap -> ascending row indices + the rows, gathered from the planar regions into one [n, F] message
+//   gsr_rows_unpack  message -> regions: add (rank-order accumulation) or store (disjoint owners), optionally marking a bitmap
+// A "row set" is any table whose logical row i is the concatenation of slices of up to 8 strided regions: the planar gradient
+// arena (means3D | scales | rotations | opacities | the ACTIVE SH columns of shs) as well as a plain row-major buffer.
+#include "gsr_common.h"
+
+namespace {
+
+struct Regions {
+  float* ptr[GSR_ROWSET_MAX_REGIONS];
+  int32_t width[GSR_ROWSET_MAX_REGIONS], stride[GSR_ROWSET_MAX_REGIONS], first[GSR_ROWSET_MAX_REGIONS + 1];
+  int32_t n, F;
+};
+
+__host__ inline int make_regions(const GsrRowSet* rs, Regions& r) {
+  if (!rs || rs->n_regions < 1 || rs->n_regions > GSR_ROWSET_MAX_REGIONS || rs->rows < 0) return GSR_EINVAL;
+  r.n = rs->n_regions;
+  int f = 0;
+  for (int k = 0; k < r.n; ++k) {
+    const GsrRowRegion& g = rs->regions[k];
+    if (!g.ptr || g.width < 1 || g.stride < g.width) return GSR_EINVAL;
+    r.ptr[k] = g.ptr; r.width[k] = g.width; r.stride[k] = g.stride; r.first[k] = f;
+    f += g.width;
+  }
+  r.first[r.n] = f;
+  r.F = f;
+  return f <= 1024 ? GSR_OK : GSR_EINVAL;
+}
+
+// address of element f of logical row i
+__device__ __forceinline__ float* row_elem(const Regions& r, int64_t i, int f) {
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < GSR_ROWSET_MAX_REGIONS; ++j) k += (j < r.n && f >= r.first[j]) ? 1 : 0;
+  return r.ptr[k] + i * (int64_t)r.stride[k] + (f - r.first[k]);
+}
+
+// per 64-row word: number of set bits in front of it (exclusive scan), total -> *count. One workgroup.
+__global__ void __launch_bounds__(1024)
+k_rows_offsets(const unsigned long long* __restrict__ mask, const int32_t n_words, const int32_t rows, uint32_t* __restrict__ offs,
+               uint32_t* __restrict__ count) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_words; base += 1024) {
+    const int w = base + tid;
+    unsigned long long m = w < n_words ? mask[w] : 0ull;
+    if (w == n_words - 1 && (rows & 63)) m &= (1ull << (rows & 63)) - 1ull;      // bits beyond the last row do not count
+    const uint32_t x = (uint32_t)__popcll(m);
+    uint32_t inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) woff += (k < wave) ? wave_tot[k] : 0u;
+    const uint32_t carry = carry_s;
+    if (w < n_words) offs[w] = carry + woff + inc - x;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (tid == 0) *count = carry_s;
+}
+
+// One wave per word of 64 rows: the set rows' indices in ascending order, then every set row copied into the message by
+// the whole wave (lane f copies element f: a row of <= 64 floats per step; wider rows in chunks of 64).
+__global__ void __launch_bounds__(256)
+k_rows_pack(const Regions r, const unsigned long long* __restrict__ mask, const int32_t n_words, const int32_t rows,
+            const uint32_t* __restrict__ offs, uint32_t* __restrict__ idx, float* __restrict__ out, const uint32_t cap) {
+  const int lane = threadIdx.x & 63;
+  const int w = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
+  if (w >= n_words) return;
+  unsigned long long m = mask[w];
+  if (w == n_words - 1 && (rows & 63)) m &= (1ull << (rows & 63)) - 1ull;
+  if (m == 0ull) return;
+  const uint32_t o0 = offs[w];
+  if ((m >> lane) & 1ull) {
+    const uint32_t pos = o0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (pos < cap) idx[pos] = (uint32_t)(w * 64 + lane);
+  }
+  uint32_t pos = o0;
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1ull;
+    if (pos < cap) {
+      const int64_t i = (int64_t)w * 64 + b;
+      for (int f = lane; f < r.F; f += 64) out[(size_t)pos * r.F + f] = *row_elem(r, i, f);
+    }
+    ++pos;
+  }
+}
+
+// message -> regions. MODE 0: add, 1: store. One thread per (message row, element).
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_rows_unpack(const Regions r, const uint32_t* __restrict__ idx, const float* __restrict__ in, const uint32_t n,
+              const int64_t row_base, unsigned long long* __restrict__ touched) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  const uint32_t j = (uint32_t)(t / (uint32_t)r.F);
+  if (j >= n) return;
+  const int f = (int)(t - (uint64_t)j * (uint32_t)r.F);
+  const int64_t i = (int64_t)idx[j] - row_base;
+  float* p = row_elem(r, i, f);
+  const float v = in[(size_t)j * r.F + f];
+  if (MODE == 0) *p += v; else *p = v;
+  if (touched && f == 0) atomicOr(touched + (i >> 6), 1ull << (i & 63));
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gsr_rows_scratch_bytes(int32_t rows) {
+  const size_t words = ((size_t)(rows > 0 ? rows : 1) + 63) / 64;
+  return ((words * 4 + 255) & ~(size_t)255) + 256;
+}
+
+int gsr_rows_pack(const GsrRowSet* rs, const uint64_t* mask, uint32_t* idx, float* rows_out, uint32_t cap, uint32_t* count,
+                  void* scratch, size_t scratch_bytes, void* stream_) {
+  Regions r;
+  const int rc = make_regions(rs, r);
+  if (rc) return rc;
+  if (!mask || !idx || !rows_out || !count || !scratch || (reinterpret_cast<uintptr_t>(mask) & 7u)) return GSR_EINVAL;
+  if (scratch_bytes < gsr_rows_scratch_bytes(rs->rows)) return GSR_ESCRATCH;
+  hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(idx);
+  const int32_t n_words = (rs->rows + 63) / 64;
+  uint32_t* offs = reinterpret_cast<uint32_t*>(scratch);
+  if (n_words == 0) return gsr_zero_async(count, sizeof(uint32_t), stream) == hipSuccess ? GSR_OK : GSR_EHIP;
+  hipLaunchKernelGGL(k_rows_offsets, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const unsigned long long*>(mask), n_words,
+                     rs->rows, offs, count);
+  hipLaunchKernelGGL(k_rows_pack, dim3((uint32_t)(n_words + 3) / 4u), dim3(256), 0, stream, r,
+                     reinterpret_cast<const unsigned long long*>(mask), n_words, rs->rows, (const uint32_t*)offs, idx, rows_out, cap);
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_rows_unpack(const GsrRowSet* rs, const uint32_t* idx, const float* rows_in, uint32_t n, int64_t row_base, int32_t mode,
+                    uint64_t* touched, void* stream_) {
+  Regions r;
+  const int rc = make_regions(rs, r);
+  if (rc) return rc;
+  if (mode != 0 && mode != 1) return GSR_EINVAL;
+  if (n == 0) return GSR_OK;
+  if (!idx || !rows_in || (touched && (reinterpret_cast<uintptr_t>(touched) & 7u))) return GSR_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(idx);
+  const uint64_t total = (uint64_t)n * (uint32_t)r.F;
+  const dim3 grid((uint32_t)((total + 255) / 256));
+  if (mode == 0)
+    hipLaunchKernelGGL(k_rows_unpack<0>, grid, dim3(256), 0, stream, r, idx, rows_in, n, row_base,
+                       reinterpret_cast<unsigned long long*>(touched));
+  else
+    hipLaunchKernelGGL(k_rows_unpack<1>, grid, dim3(256), 0, stream, r, idx, rows_in, n, row_base,
+                       reinterpret_cast<unsigned long long*>(touched));
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
+
+}  // extern "C"

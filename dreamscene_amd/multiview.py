@@ -108,6 +108,64 @@ def _all_gather_list(outs, inp: torch.Tensor, group) -> None:
         dist.all_gather(outs, inp, group=group)
 
 
+class _DeviceRows:
+    """(index, row) messages of a row set packed / applied by the HIP library (csrc/exchange.hip: gsr_rows_pack /
+    gsr_rows_unpack) instead of torch index arithmetic over five tensors -- measured at C3 (15.7 % non-zero rows): bitmap ->
+    indices 81 us + gather 78 us + 41 us per applied message in torch (profiles/r05_exchange_device_c3.json). Only for cuda
+    tensors; the CPU (gloo) tests keep the torch path, which is also the reference the kernels are tested against."""
+
+    def __init__(self, device):
+        from . import _lib as L
+        self.L, self.lib, self.dev = L, L.load(), device
+        self.cap = 0
+        self.idx = self.rows = self.scratch = None
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def rowset(self, regions, n_rows):
+        """regions: [(tensor whose row i starts at element i * stride, width, stride)]"""
+        rs = self.L.GsrRowSet()
+        rs.rows, rs.n_regions = int(n_rows), len(regions)
+        for k, (t, width, stride) in enumerate(regions):
+            rs.regions[k].ptr, rs.regions[k].width, rs.regions[k].stride = t.data_ptr(), int(width), int(stride)
+        rs._keep = [t for t, _, _ in regions]
+        return rs
+
+    def pack(self, rs, mask: torch.Tensor, F: int, guess: int):
+        """-> (idx int32 [n], rows [n, F]): the rows of `rs` whose bit is set in `mask`, ascending. One host read (n)."""
+        n_rows = int(rs.rows)
+        sb = int(self.lib.gsr_rows_scratch_bytes(n_rows))
+        if self.scratch is None or self.scratch.numel() < sb:
+            self.scratch = torch.empty(sb + 256, dtype=torch.uint8, device=self.dev)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        cap = max(self.cap, int(guess), 1024)
+        while True:
+            if self.idx is None or self.idx.numel() < cap or self.rows.shape[1] != F or self.rows.shape[0] < cap:
+                self.idx = torch.empty(cap, dtype=torch.int32, device=self.dev)
+                self.rows = torch.empty((cap, F), dtype=torch.float32, device=self.dev)
+            with torch.cuda.device(self.dev):
+                self.L.check(self.lib.gsr_rows_pack(rs, mask.data_ptr(), self.idx.data_ptr(), self.rows.data_ptr(), cap,
+                                                    self.count.data_ptr(), self.scratch.data_ptr(), self.scratch.numel(),
+                                                    stream), "gsr_rows_pack")
+            n = int(self.count.item())              # (the host read every row format needs: it sizes the wire buffers)
+            if n <= cap:
+                self.cap = max(self.cap, int(n * 1.25) + 1024)
+                return self.idx[:n], self.rows[:n]
+            cap = int(n * 1.25) + 1024
+
+    def unpack(self, rs, idx: torch.Tensor, rows: torch.Tensor, mode: int, row_base: int = 0, touched=None):
+        n = int(idx.numel())
+        if n == 0:
+            return
+        if idx.dtype != torch.int32:
+            idx = idx.to(torch.int32)
+        rows = rows.contiguous()
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        with torch.cuda.device(self.dev):
+            self.L.check(self.lib.gsr_rows_unpack(rs, idx.data_ptr(), rows.data_ptr(), n, int(row_base), int(mode),
+                                                  touched.data_ptr() if touched is not None else None, stream),
+                         "gsr_rows_unpack")
+
+
 class GradExchange:
     """Sum of the arena over the ranks of a step, moving only what can be non-zero.
 
@@ -149,6 +207,7 @@ class GradExchange:
         self.sh_degree = None
         self.set_sh_degree(sh_degree)
         self.last = {}          # what the last reduce() did (format, bytes): for logs / bench lines
+        self._dev_rows = _DeviceRows(arena.flat.device) if arena.flat.is_cuda else None
 
     # ---- layout
     def set_sh_degree(self, sh_degree: Optional[int]) -> None:
@@ -198,6 +257,24 @@ class GradExchange:
             (v["opacities"].reshape(P) != 0) | (v["shs"][:, :nb, :].reshape(P, nb * 3) != 0).any(1)
         return torch.nonzero(m).reshape(-1)
 
+    def _arena_rowset(self):
+        v, P, K, nb = self.arena.views, self.arena.P, self.arena.K, self.nb
+        return self._dev_rows.rowset([(v["means3D"], 3, 3), (v["scales"], 3, 3), (v["rotations"], 4, 4), (v["opacities"], 1, 1),
+                                      (v["shs"], 3 * nb, 3 * K)], P)
+
+    def _message(self):
+        """(idx, rows): this rank's non-zero rows as a message, indices ascending. On a cuda arena whose reached bitmap K8 left
+        is valid: ONE pack through the HIP library (idx int32); otherwise the torch path (idx int64)."""
+        a = self.arena
+        if self._dev_rows is not None and getattr(a, "reached_valid", False):
+            guess = getattr(self, "_last_n", 0)
+            idx, rows = self._dev_rows.pack(self._arena_rowset(), a.reached, self.row_floats, int(guess * 1.25))
+            self._last_n = int(idx.numel())
+            return idx, rows
+        idx = self.nonzero_rows()
+        rows = self._rows_of(idx) if idx.numel() else torch.zeros((0, self.row_floats), dtype=a.flat.dtype, device=a.flat.device)
+        return idx, rows
+
     def _rows_of(self, idx: torch.Tensor) -> torch.Tensor:
         v = self.arena.views
         n, nb = idx.numel(), self.nb
@@ -205,6 +282,10 @@ class GradExchange:
                           v["shs"][idx, :nb, :].reshape(n, nb * 3)], dim=1)
 
     def _add_rows(self, idx: torch.Tensor, rows: torch.Tensor) -> None:
+        if self._dev_rows is not None:
+            self._dev_rows.unpack(self._arena_rowset(), idx, rows, mode=0)
+            return
+        idx = idx.to(torch.int64)
         v = self.arena.views
         n, nb = idx.numel(), self.nb
         v["means3D"].index_add_(0, idx, rows[:, 0:3])
@@ -231,8 +312,9 @@ class GradExchange:
         P, F = self.arena.P, self.row_floats
         mode = self.mode
         idx = counts = None
+        msg_rows = None
         if mode in ("auto", "rows"):      # ("sparse_rs" counts per owner itself)
-            idx = self.nonzero_rows()
+            idx, msg_rows = self._message()
             cnt = torch.empty(W, dtype=torch.int64, device=idx.device)
             _all_gather_into(cnt, torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device), self.group)
             counts = [int(c) for c in cnt.tolist()]           # (the one host read of the exchange)
@@ -277,12 +359,12 @@ class GradExchange:
             return
         nmax = max(counts)
         dev, dt = self.arena.flat.device, self.arena.flat.dtype
-        my_idx = torch.zeros(max(nmax, 1), dtype=torch.int64, device=dev)
+        my_idx = torch.zeros(max(nmax, 1), dtype=torch.int32, device=dev)       # (4-byte indices on the wire: P < 2^31)
         my_rows = torch.zeros((max(nmax, 1), F), dtype=dt, device=dev)
         n = idx.numel()
         my_idx[:n] = idx
         if n:
-            my_rows[:n] = self._rows_of(idx)
+            my_rows[:n] = msg_rows
         all_idx = [torch.empty_like(my_idx) for _ in range(W)]
         all_rows = [torch.empty_like(my_rows) for _ in range(W)]
         _all_gather_list(all_idx, my_idx, self.group)
@@ -294,6 +376,10 @@ class GradExchange:
         self.last = dict(format="rows", row_floats=F, rows=counts, bytes_per_rank=int(sum(counts) * (4 + 4 * F)))
 
     def _set_rows(self, idx: torch.Tensor, rows: torch.Tensor) -> None:
+        if self._dev_rows is not None:
+            self._dev_rows.unpack(self._arena_rowset(), idx, rows, mode=1)
+            return
+        idx = idx.to(torch.int64)
         v = self.arena.views
         n, nb = idx.numel(), self.nb
         v["means3D"][idx] = rows[:, 0:3]
@@ -307,13 +393,13 @@ class GradExchange:
         dev, dt = self.arena.flat.device, self.arena.flat.dtype
         r = dist.get_rank(self.group)
         per = (P + W - 1) // W
-        idx = self.nonzero_rows()                                         # ascending: contiguous per owner
-        bounds = torch.searchsorted(idx, torch.arange(0, W + 1, device=dev, dtype=idx.dtype) * per)
+        idx, rows = self._message()                                       # ascending: contiguous per owner
+        bounds = torch.searchsorted(idx, (torch.arange(0, W + 1, device=dev, dtype=torch.int64) * per).to(idx.dtype))
         send_counts = (bounds[1:] - bounds[:-1]).to(torch.int64)
         recv_counts = torch.empty_like(send_counts)
         _all_to_all_single(recv_counts, send_counts, self.group)
         sc, rc = [int(x) for x in send_counts.tolist()], [int(x) for x in recv_counts.tolist()]      # host read 1
-        rows = self._rows_of(idx) if idx.numel() else torch.zeros((0, F), dtype=dt, device=dev)
+        rows = rows.contiguous()
         idx32 = idx.to(torch.int32)
         got_idx = torch.empty(sum(rc), dtype=torch.int32, device=dev)
         got_rows = torch.empty((sum(rc), F), dtype=dt, device=dev)
@@ -323,15 +409,33 @@ class GradExchange:
         lo = r * per
         n_own = max(0, min(per, P - lo))
         mine = torch.zeros((max(n_own, 1), F), dtype=dt, device=dev)
-        touched = torch.zeros(max(n_own, 1), dtype=torch.bool, device=dev)
-        off = 0
-        for src in range(W):
-            if rc[src]:
-                li = got_idx[off:off + rc[src]].to(torch.int64) - lo
-                mine.index_add_(0, li, got_rows[off:off + rc[src]])
-                touched[li] = True
-            off += rc[src]
-        own_idx = torch.nonzero(touched[:n_own]).reshape(-1) if n_own else torch.zeros(0, dtype=torch.int64, device=dev)
+        if self._dev_rows is not None:
+            # the owned slice as a row-major row set: messages applied in rank order by the library, the rows they touched
+            # collected as a bitmap and packed again (csrc/exchange.hip)
+            dr = self._dev_rows
+            own_set = dr.rowset([(mine, F, F)], max(n_own, 1))
+            touched_bits = torch.zeros((max(n_own, 1) + 63) // 64, dtype=torch.int64, device=dev)
+            off = 0
+            for src in range(W):
+                if rc[src]:
+                    dr.unpack(own_set, got_idx[off:off + rc[src]], got_rows[off:off + rc[src]], mode=0, row_base=lo,
+                              touched=touched_bits)
+                off += rc[src]
+            if not hasattr(self, "_own_rows"):
+                self._own_rows = _DeviceRows(dev)
+            own_local, own_rows = self._own_rows.pack(own_set, touched_bits, F, 0)
+            own_idx = own_local.to(torch.int64)
+        else:
+            touched = torch.zeros(max(n_own, 1), dtype=torch.bool, device=dev)
+            off = 0
+            for src in range(W):
+                if rc[src]:
+                    li = got_idx[off:off + rc[src]].to(torch.int64) - lo
+                    mine.index_add_(0, li, got_rows[off:off + rc[src]])
+                    touched[li] = True
+                off += rc[src]
+            own_idx = torch.nonzero(touched[:n_own]).reshape(-1) if n_own else torch.zeros(0, dtype=torch.int64, device=dev)
+            own_rows = mine[own_idx] if own_idx.numel() else None
         cnt = torch.empty(W, dtype=torch.int64, device=dev)
         _all_gather_into(cnt, torch.tensor([own_idx.numel()], dtype=torch.int64, device=dev), self.group)
         counts = [int(c) for c in cnt.tolist()]                           # host read 2 (own_idx.numel() was the third)
@@ -340,7 +444,7 @@ class GradExchange:
         my_rows = torch.zeros((nmax, F), dtype=dt, device=dev)
         my_idx[:own_idx.numel()] = (own_idx + lo).to(torch.int32)
         if own_idx.numel():
-            my_rows[:own_idx.numel()] = mine[own_idx]
+            my_rows[:own_idx.numel()] = own_rows
         all_idx = torch.empty(W * nmax, dtype=torch.int32, device=dev)
         all_rows = torch.empty((W * nmax, F), dtype=dt, device=dev)
         _all_gather_into(all_idx, my_idx, self.group)
@@ -348,7 +452,7 @@ class GradExchange:
         self.arena.flat.zero_()
         for o in range(W):                                                # disjoint row ranges: plain stores
             if counts[o]:
-                self._set_rows(all_idx[o * nmax:o * nmax + counts[o]].to(torch.int64), all_rows[o * nmax:o * nmax + counts[o]])
+                self._set_rows(all_idx[o * nmax:o * nmax + counts[o]], all_rows[o * nmax:o * nmax + counts[o]])
         self.last = dict(format="sparse_rs", row_floats=F, rows_sent=sum(sc) - sc[r], rows_reduced=counts,
                          bytes_per_rank=int((sum(sc) - sc[r]) * (4 + 4 * F) + (sum(counts) - counts[r]) * (4 + 4 * F)))
 

@@ -382,6 +382,38 @@ typedef struct GsrAdamGroup {
 int gsr_adam_step(const GsrAdamGroup* groups, int32_t n_groups, int32_t step, double beta1, double beta2, double eps,
                   int32_t zero_grad, void* stream);
 
+/* ---- device side of the sparse gradient-exchange formats -------------------------------------
+ * One view per GPU, the only exchange of a step is the sum of the ranks' parameter gradients (the reference sums the
+ * C_batch_size views of a step in one process, training/object_trainer.py:302-382). K8 leaves the rows that can be non-zero
+ * as a bitmap (GsrGrads.reached_mask: 16 % of the rows at 500 k Gaussians @1024^2); the row formats of the exchange move
+ * (row index, row) messages. A ROW SET is a table whose logical row i is the concatenation of slices of up to
+ * GSR_ROWSET_MAX_REGIONS strided regions -- element f of row i, in region k, lives at regions[k].ptr[i * stride + (f - first_k)]:
+ * the planar gradient arena (means3D [P,3] | scales [P,3] | rotations [P,4] | opacities [P,1] | the active SH columns of shs
+ * [P,K,3]: width 3 (D+1)^2, stride 3 K) as well as a plain row-major buffer (one region). All device pointers, fp32. */
+#define GSR_ROWSET_MAX_REGIONS 8
+typedef struct GsrRowRegion {
+  float* ptr;
+  int32_t width;    /* floats of a logical row that live in this region          */
+  int32_t stride;   /* floats between consecutive rows of this region (>= width) */
+} GsrRowRegion;
+typedef struct GsrRowSet {
+  int32_t rows;       /* logical rows */
+  int32_t n_regions;  /* 1..GSR_ROWSET_MAX_REGIONS */
+  GsrRowRegion regions[GSR_ROWSET_MAX_REGIONS];
+} GsrRowSet;
+size_t gsr_rows_scratch_bytes(int32_t rows);
+/* The rows whose bit is set in mask (u64[(rows + 63) / 64], bit i % 64 of word i / 64; bits beyond `rows` ignored) as a message:
+ * idx[n] = their indices in ascending order, rows_out[n][F] = the rows (F = sum of the region widths), *count = n (device u32;
+ * the caller reads it to size its wire buffers). At most `cap` rows are written; n may exceed cap (then re-run with more room).
+ * scratch: gsr_rows_scratch_bytes(rows) bytes, 256-byte aligned. Two launches, no host synchronisation. */
+int gsr_rows_pack(const GsrRowSet* set, const uint64_t* mask, uint32_t* idx, float* rows_out, uint32_t cap, uint32_t* count,
+                  void* scratch, size_t scratch_bytes, void* stream);
+/* The reverse: row idx[j] - row_base of the set receives rows_in[j] (mode 1: stored, mode 0: ADDED -- one message per launch
+ * and the indices of a message distinct, so messages applied in rank order give every rank the same sums); touched (NULL or
+ * u64[(rows + 63) / 64]): the bits of the rows written are OR-ed in (the owner side of a sparse reduce-scatter). */
+int gsr_rows_unpack(const GsrRowSet* set, const uint32_t* idx, const float* rows_in, uint32_t n, int64_t row_base, int32_t mode,
+                    uint64_t* touched, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

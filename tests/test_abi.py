@@ -56,8 +56,9 @@ def test_struct_layouts_match_header(built_lib):
     src = r'''
     #include <stdio.h>
     #include "gsrast.h"
-    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(GsrView), sizeof(GsrGaussians), sizeof(GsrGeom),
-                       sizeof(GsrBinning), sizeof(GsrImages), sizeof(GsrImageGrads), sizeof(GsrGrads)); return 0; }
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(GsrView), sizeof(GsrGaussians), sizeof(GsrGeom),
+                       sizeof(GsrBinning), sizeof(GsrImages), sizeof(GsrImageGrads), sizeof(GsrGrads), sizeof(GsrRowRegion),
+                       sizeof(GsrRowSet)); return 0; }
     '''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -67,7 +68,7 @@ def test_struct_layouts_match_header(built_lib):
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     mine = [ctypes.sizeof(t) for t in (_lib.GsrView, _lib.GsrGaussians, _lib.GsrGeom, _lib.GsrBinning, _lib.GsrImages,
-                                       _lib.GsrImageGrads, _lib.GsrGrads)]
+                                       _lib.GsrImageGrads, _lib.GsrGrads, _lib.GsrRowRegion, _lib.GsrRowSet)]
     assert sizes == mine
 
 

@@ -73,8 +73,41 @@ def timed(fn, reps=args.reps, restore=False):
 
 res_ = {"P": P, "res": res, "views_per_rank": V, "world_emulated": W, "init_opacity": bool(args.init_opacity)}
 out = {}
+# ---- the HIP library's pack / unpack (csrc/exchange.hip), what GradExchange uses on a cuda arena
+hip = {}
+for deg in (3, 0):
+    ex = multiview.GradExchange(arena, sh_degree=deg, mode="rows")
+    F = ex.row_floats
+    arena.reached_valid = True
+    h = {"row_floats": F}
+    h["_message (bitmap -> indices + rows, one host read)"], (idx_h, rows_h) = timed(ex._message, restore=True)
+    h["rows"] = int(idx_h.numel())
+    idx_h, rows_h = idx_h.clone(), rows_h.clone()
+    h["_add_rows x1"], _ = timed(lambda: ex._add_rows(idx_h, rows_h), restore=True)
+    h["_set_rows x1"], _ = timed(lambda: ex._set_rows(idx_h, rows_h), restore=True)
+    bper = (P + W - 1) // W
+    lo_n = int((idx_h < bper).sum())
+
+    def owner():
+        mine = torch.zeros((bper, F), device=dev)
+        own_set = ex._dev_rows.rowset([(mine, F, F)], bper)
+        bits = torch.zeros((bper + 63) // 64, dtype=torch.int64, device=dev)
+        for _ in range(W):
+            ex._dev_rows.unpack(own_set, idx_h[:lo_n], rows_h[:lo_n], mode=0, row_base=0, touched=bits)
+        return multiview._DeviceRows(dev).pack(own_set, bits, F, lo_n)
+    h["sparse_rs owner side (W messages added into the owned slice, touched rows packed; one host read)"], _ = timed(owner)
+    g_ = lambda k: h[k]["gpu_us"]
+    w_ = lambda k: h[k]["wall_us"]
+    km, ka, ks, ko = (next(k for k in h if k.startswith(p_)) for p_ in ("_message", "_add_rows", "_set_rows", "sparse_rs owner"))
+    zero_us = 18.4
+    h["device_side_total_us"] = {"rows": round(w_(km) + zero_us + W * g_(ka), 1),
+                                 "sparse_rs": round(w_(km) + w_(ko) + zero_us + 2.0 * g_(ks), 1)}
+    hip[f"D{deg}"] = h
+res_["hip_kernels"] = hip
+# ---- the torch index arithmetic they replace (the reference of tests/test_exchange_rows.py)
 for deg in (3, 2, 1, 0):
     ex = multiview.GradExchange(arena, sh_degree=deg, mode="dense")
+    ex._dev_rows = None
     F = ex.row_floats
     d = {"row_floats": F}
     arena.reached_valid = True
@@ -128,5 +161,5 @@ for deg in (3, 2, 1, 0):
         # (the owners' reduced rows are the UNION over the ranks' views: ~2x one rank's rows at C3 -> two messages' worth of stores)
         "sparse_rs": round(w_(nz) + g_(ro) + w_(rs) + g_(ze) + 2.0 * g_(st), 1)}
     out[f"D{deg}"] = d
-res_["by_degree"] = out
+res_["torch_ops_by_degree"] = out
 print(json.dumps(res_))
