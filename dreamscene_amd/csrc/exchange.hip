@@ -35,12 +35,19 @@ __host__ inline int make_regions(const GsrRowSet* rs, Regions& r) {
   return f <= 1024 ? GSR_OK : GSR_EINVAL;
 }
 
-// address of element f of logical row i
+// address of element f of logical row i. (A chain of selects over compile-time indices: a run-time index into the by-value
+// table would send it through scratch memory -- the first build did, and packed 18 MB in 85 us.)
 __device__ __forceinline__ float* row_elem(const Regions& r, int64_t i, int f) {
-  int k = 0;
+  float* p = r.ptr[0];
+  int st = r.stride[0], f0 = 0;
 #pragma unroll
-  for (int j = 1; j < GSR_ROWSET_MAX_REGIONS; ++j) k += (j < r.n && f >= r.first[j]) ? 1 : 0;
-  return r.ptr[k] + i * (int64_t)r.stride[k] + (f - r.first[k]);
+  for (int j = 1; j < GSR_ROWSET_MAX_REGIONS; ++j) {
+    const bool in = (j < r.n) && (f >= r.first[j]);
+    p = in ? r.ptr[j] : p;
+    st = in ? r.stride[j] : st;
+    f0 = in ? r.first[j] : f0;
+  }
+  return p + i * (int64_t)st + (f - f0);
 }
 
 // per 64-row word: number of set bits in front of it (exclusive scan), total -> *count. One workgroup.
@@ -89,19 +96,21 @@ k_rows_pack(const Regions r, const unsigned long long* __restrict__ mask, const 
   if (w == n_words - 1 && (rows & 63)) m &= (1ull << (rows & 63)) - 1ull;
   if (m == 0ull) return;
   const uint32_t o0 = offs[w];
+  __shared__ uint8_t bitpos[4][64];         // per wave: the set rows of its word, in order
+  uint8_t* mybits = bitpos[threadIdx.x >> 6];
   if ((m >> lane) & 1ull) {
-    const uint32_t pos = o0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (pos < cap) idx[pos] = (uint32_t)(w * 64 + lane);
+    const uint32_t k = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    mybits[k] = (uint8_t)lane;
+    if (o0 + k < cap) idx[o0 + k] = (uint32_t)(w * 64 + lane);
   }
-  uint32_t pos = o0;
-  while (m) {
-    const int b = __ffsll((long long)m) - 1;
-    m &= m - 1ull;
-    if (pos < cap) {
-      const int64_t i = (int64_t)w * 64 + b;
-      for (int f = lane; f < r.F; f += 64) out[(size_t)pos * r.F + f] = *row_elem(r, i, f);
-    }
-    ++pos;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // the word's nset x F elements dealt to the 64 lanes: every load instruction has all lanes busy on independent addresses
+  const int nset = (int)__popcll(m), total = nset * r.F;
+  for (int e = lane; e < total; e += 64) {
+    const int k = e / r.F, f = e - k * r.F;
+    const uint32_t pos = o0 + (uint32_t)k;
+    if (pos < cap) out[(size_t)pos * r.F + f] = *row_elem(r, (int64_t)w * 64 + mybits[k], f);
   }
 }
 
