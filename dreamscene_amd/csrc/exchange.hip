@@ -132,7 +132,45 @@ k_rows_unpack(const Regions r, const uint32_t* __restrict__ idx, const float* __
 
 }  // namespace
 
+// out[i] = ((s_0[i] + s_1[i]) + s_2[i]) + ... : the local sum of the `direct` exchange, slices in rank order (the association every
+// rank uses for its slice, so the replicas stay bit-identical), one pass over the W slices instead of W - 1 read-modify-writes.
+template <typename V>
+__global__ void __launch_bounds__(256) k_sum_slices(const V* in, int W, size_t stride, size_t n, V* out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    V a = in[i];
+    for (int w = 1; w < W; ++w) {
+      const V b = in[(size_t)w * stride + i];
+      if constexpr (sizeof(V) == 16) {
+        a.x = __fadd_rn(a.x, b.x); a.y = __fadd_rn(a.y, b.y); a.z = __fadd_rn(a.z, b.z); a.w = __fadd_rn(a.w, b.w);
+      } else {
+        a = __fadd_rn(a, b);
+      }
+    }
+    out[i] = a;
+  }
+}
+
 extern "C" {
+
+int gsr_sum_slices(const float* slices, int32_t n_slices, uint64_t slice_floats, uint64_t stride_floats, float* out,
+                   void* stream_) {
+  if (!slices || !out || n_slices < 1 || stride_floats < slice_floats) return GSR_EINVAL;
+  if (slice_floats == 0) return GSR_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(out);
+  const bool vec = ((reinterpret_cast<uintptr_t>(slices) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0 &&
+                   (slice_floats & 3u) == 0 && (stride_floats & 3u) == 0;
+  const uint64_t n = vec ? slice_floats / 4 : slice_floats;
+  const uint64_t blocks = (n + 255) / 256;
+  const dim3 grid((uint32_t)(blocks < 16384 ? blocks : 16384));
+  if (vec)
+    hipLaunchKernelGGL(k_sum_slices<float4>, grid, dim3(256), 0, stream, reinterpret_cast<const float4*>(slices), n_slices,
+                       (size_t)(stride_floats / 4), (size_t)n, reinterpret_cast<float4*>(out));
+  else
+    hipLaunchKernelGGL(k_sum_slices<float>, grid, dim3(256), 0, stream, slices, n_slices, (size_t)stride_floats, (size_t)n, out);
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
 
 size_t gsr_rows_scratch_bytes(int32_t rows) {
   const size_t words = ((size_t)(rows > 0 ? rows : 1) + 63) / 64;

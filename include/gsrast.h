@@ -413,6 +413,10 @@ int gsr_rows_pack(const GsrRowSet* set, const uint64_t* mask, uint32_t* idx, flo
  * u64[(rows + 63) / 64]): the bits of the rows written are OR-ed in (the owner side of a sparse reduce-scatter). */
 int gsr_rows_unpack(const GsrRowSet* set, const uint32_t* idx, const float* rows_in, uint32_t n, int64_t row_base, int32_t mode,
                     uint64_t* touched, void* stream);
+/* The local sum of the `direct` exchange (multiview.GradExchange: one all-to-all, THIS, one all-gather): out[i] =
+ * ((s_0[i] + s_1[i]) + s_2[i]) + ... over n_slices slices of slice_floats floats, slice w at slices + w * stride_floats -- rank
+ * order, the association every rank applies to the slice it owns. out may be slice 0 (in place). One launch. */
+int gsr_sum_slices(const float* slices, int32_t n_slices, uint64_t slice_floats, uint64_t stride_floats, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -99,3 +99,26 @@ def test_owner_side_of_sparse_rs_on_a_row_major_slice(built_lib):
     idx, got = multiview._DeviceRows(torch.device(DEV)).pack(rs, touched, F, 0)
     assert torch.equal(idx.cpu().to(torch.int64), torch.nonzero(seen).reshape(-1))
     assert torch.equal(got.cpu(), ref[seen])
+
+
+@pytest.mark.parametrize("W,per", [(8, 3_687_500), (2, 1000), (5, 1003), (1, 77), (3, 4)])
+def test_slice_sum_of_the_direct_format_equals_the_rank_order_adds(built_lib, W, per):
+    """multiview._sum_slices on a GPU (gsr_sum_slices) against the W - 1 in-place torch adds it replaces: same association
+    (((s0 + s1) + s2) + ...), hence the same bits -- every rank applies it to the slice it owns."""
+    from dreamscene_amd import multiview
+    g = torch.Generator(device="cpu").manual_seed(W * 1000 + per % 997)
+    recv = (torch.randn(W * per, generator=g) * torch.exp(4.0 * torch.randn(W * per, generator=g))).to(DEV)
+    want = recv.view(W, per)[0].clone()
+    for r in range(1, W):
+        want.add_(recv.view(W, per)[r])
+    got = multiview._sum_slices(recv, W, per)
+    assert got.data_ptr() != recv.data_ptr() and torch.equal(got, want)
+    # misaligned slices take the scalar form
+    off = recv[1:1 + (W * per - 1) // W * W]
+    per2 = off.numel() // W
+    if per2:
+        off = off.contiguous() if not off.is_contiguous() else off
+        want2 = off.view(W, per2)[0].clone()
+        for r in range(1, W):
+            want2.add_(off.view(W, per2)[r])
+        assert torch.equal(multiview._sum_slices(off, W, per2), want2)

@@ -132,7 +132,11 @@ for deg in (3, 2, 1, 0):
         for r in range(1, W):
             mine.add_(recv.view(W, per)[r])
         return mine
-    d["direct: local sum of W slices"], _ = timed(local_sum)
+    if hip:
+        d["direct: local sum of W slices"], _ = timed(lambda: multiview._sum_slices(recv, W, per))
+        d["direct: local sum, W - 1 torch adds (before)"], _ = timed(local_sum)
+    else:
+        d["direct: local sum of W slices"], _ = timed(local_sum)
     # sparse_rs owner side: bounds by searchsorted + W index_add_ of 1/W of the rows each
     bper = (P + W - 1) // W
 
