@@ -17,12 +17,13 @@ namespace {
 struct Regions {
   float* ptr[GSR_ROWSET_MAX_REGIONS];
   int32_t width[GSR_ROWSET_MAX_REGIONS], stride[GSR_ROWSET_MAX_REGIONS], first[GSR_ROWSET_MAX_REGIONS + 1];
-  int32_t n, F;
+  int32_t n, F, rows;
 };
 
 __host__ inline int make_regions(const GsrRowSet* rs, Regions& r) {
   if (!rs || rs->n_regions < 1 || rs->n_regions > GSR_ROWSET_MAX_REGIONS || rs->rows < 0) return GSR_EINVAL;
   r.n = rs->n_regions;
+  r.rows = rs->rows;
   int f = 0;
   for (int k = 0; k < r.n; ++k) {
     const GsrRowRegion& g = rs->regions[k];
@@ -124,6 +125,7 @@ k_rows_unpack(const Regions r, const uint32_t* __restrict__ idx, const float* __
   if (j >= n) return;
   const int f = (int)(t - (uint64_t)j * (uint32_t)r.F);
   const int64_t i = (int64_t)idx[j] - row_base;
+  if (i < 0 || i >= (int64_t)r.rows) return;      // (an index outside the set is dropped, never written through)
   float* p = row_elem(r, i, f);
   const float v = in[(size_t)j * r.F + f];
   if (MODE == 0) *p += v; else *p = v;

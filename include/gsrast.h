@@ -410,7 +410,8 @@ int gsr_rows_pack(const GsrRowSet* set, const uint64_t* mask, uint32_t* idx, flo
                   void* scratch, size_t scratch_bytes, void* stream);
 /* The reverse: row idx[j] - row_base of the set receives rows_in[j] (mode 1: stored, mode 0: ADDED -- one message per launch
  * and the indices of a message distinct, so messages applied in rank order give every rank the same sums); touched (NULL or
- * u64[(rows + 63) / 64]): the bits of the rows written are OR-ed in (the owner side of a sparse reduce-scatter). */
+ * u64[(rows + 63) / 64]): the bits of the rows written are OR-ed in (the owner side of a sparse reduce-scatter). Entries whose
+ * idx[j] - row_base falls outside [0, set->rows) are skipped. */
 int gsr_rows_unpack(const GsrRowSet* set, const uint32_t* idx, const float* rows_in, uint32_t n, int64_t row_base, int32_t mode,
                     uint64_t* touched, void* stream);
 /* The local sum of the `direct` exchange (multiview.GradExchange: one all-to-all, THIS, one all-gather): out[i] =
