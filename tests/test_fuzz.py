@@ -35,7 +35,17 @@ def _random_config(seed):
     return g, cam, bg, P, K, D
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+def _seeds():
+    """24 seeds in the suite; GSR_FUZZ_SEEDS="lo-hi" widens a one-off run (tools/r05_calls/r5_r.sh ran 24-400)."""
+    import os
+    extra = os.environ.get("GSR_FUZZ_SEEDS", "")
+    if "-" in extra:
+        lo, hi = (int(x) for x in extra.split("-", 1))
+        return list(range(24)) + list(range(max(lo, 24), hi))
+    return list(range(24))
+
+
+@pytest.mark.parametrize("seed", _seeds())
 def test_random_configuration(built_lib, c_oracle, seed):
     g, cam, bg, P, K, D = _random_config(seed)
     out, _ = _run_hip(g, cam, bg, D)

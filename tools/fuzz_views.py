@@ -1,0 +1,124 @@
+"""One-off widening of tests/test_views.py / tests/test_graph.py on the GPU box: random (P, K, D, H, W, V, scale range, camera
+radius, per-view backgrounds / degrees / scale noise) through
+  (a) one GaussianRasterizer call per view (the reference's interface),
+  (b) ONE GaussianRasterizerViews call,
+  (c) ONE CapturedViews call (twice: eager warm-up steps, then replays),
+outputs of (b), (c) bit-equal to (a); parameter gradients (sum over the views) within 2e-6 x max(1, max|ref|) of (a)'s sum in
+float64 -- (b) and (c) add the views' gradients on the device in fp32, (a) leaves the sum to the caller.
+usage: python tools/fuzz_views.py [n_configs] [first_seed]   -> prints one line per failure and a summary; exit code 1 on failure"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dreamscene_amd import multiview, rasterizer as R, synth  # noqa: E402
+from dreamscene_amd.graph import CapturedViews  # noqa: E402
+from dreamscene_amd.rasterizer import GaussianRasterizer  # noqa: E402
+from dreamscene_amd.views import GaussianRasterizerViews  # noqa: E402
+from tests.util import settings_for  # noqa: E402
+
+DEV = torch.device("cuda:0")
+NAMES = ("means3D", "shs", "opacities", "scales", "rotations")
+
+
+def config(seed):
+    rng = np.random.default_rng(77_000 + seed)
+    P = int(rng.choice([1, 5, 64, 65, 300, 1000, 2500, 6000, 20_000]))
+    K = int(rng.choice([1, 4, 9, 16]))
+    D = int(rng.integers(0, int(np.sqrt(K))))
+    H, W = int(rng.integers(8, 300)), int(rng.integers(8, 300))
+    V = int(rng.integers(1, 9))
+    g = synth.g_object(max(P, 64), seed=seed, K=K)
+    g = {k: np.ascontiguousarray(v[:P]) for k, v in g.items()}
+    g["scales"] = (g["scales"] * float(rng.choice([0.5, 2.0, 6.0, 15.0]))).astype(np.float32)
+    if rng.random() < 0.2:
+        g["opacities"][:] = rng.choice([0.999, 0.1, 0.004])
+    radius = float(rng.choice([0.9, 2.0, 3.5, 8.0]))
+    cams = synth.object_cameras(V + 1, H, W, radius=radius)[1:]
+    sets = [settings_for(c, rng.random(3).astype(np.float32), int(rng.integers(0, D + 1)) if rng.random() < 0.3 else D, DEV)
+            for c in cams]
+    noisy = bool(rng.random() < 0.3)
+    arena = bool(rng.random() < 0.5)
+    return dict(P=P, K=K, D=D, H=H, W=W, V=V, g=g, sets=sets, noisy=noisy, arena=arena, radius=radius, seed=seed)
+
+
+def run(cfg):
+    P, K, V, H, W = cfg["P"], cfg["K"], cfg["V"], cfg["H"], cfg["W"]
+    t = {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in cfg["g"].items()}
+    leaves = [t[k] for k in NAMES]
+    gen = torch.Generator().manual_seed(cfg["seed"])
+    noise = torch.randn((V, P, 3), generator=gen).to(DEV)
+
+    def view_scales():
+        return torch.clamp(t["scales"][None] + noise * ((0.2 ** 0.5) * t["scales"][None] / 4), 0.0) if cfg["noisy"] else t["scales"]
+    ups = [tuple(torch.tensor(x, device=DEV) for x in synth.upstream_grads(H, W, seed=k)) for k in range(V)]
+    # (a) one call per view
+    outs_a, tot, m2d_a = [], None, []
+    for k, s in enumerate(cfg["sets"]):
+        m2d = torch.zeros((P, 3), device=DEV, requires_grad=True)
+        sc = view_scales()
+        img, radii, da = GaussianRasterizer(s)(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"],
+                                                scales=sc[k] if cfg["noisy"] else sc, rotations=t["rotations"])
+        gr = torch.autograd.grad([img, da], leaves + [m2d], list(ups[k]))
+        outs_a.append((img, radii, da))
+        m2d_a.append(gr[-1])
+        tot = [a.double() for a in gr[:-1]] if tot is None else [a + b.double() for a, b in zip(tot, gr[:-1])]
+    fails = []
+
+    def compare(tag, outs, grads, m2d_g, arena):
+        for k, ((img, radii, da), (rimg, rradii, rda)) in enumerate(zip(outs, outs_a)):
+            if not (torch.equal(radii, rradii) and torch.equal(img, rimg) and torch.equal(da, rda)):
+                fails.append(f"{tag}: outputs of view {k} differ from the per-view call")
+        got = [arena.views[n] for n in NAMES] if arena is not None else grads
+        for n, a, b in zip(NAMES, got, tot):
+            a = a.reshape(b.shape).double()
+            scale = max(1.0, float(b.abs().max()) if b.numel() else 1.0)
+            e = float((a - b).abs().max()) if b.numel() else 0.0
+            if not e <= 2e-6 * scale:
+                fails.append(f"{tag}: dL/d{n} off by {e / scale:.2e} of its scale")
+        ref = torch.stack(m2d_a).double()
+        e = float((m2d_g.double() - ref).abs().max()) if ref.numel() else 0.0
+        if not e <= 2e-6 * max(1.0, float(ref.abs().max()) if ref.numel() else 1.0):
+            fails.append(f"{tag}: dL/dmeans2D off by {e:.2e}")
+
+    def batched(rast, tag, reps):
+        arena = multiview.GradArena(P, K, DEV) if cfg["arena"] else None
+        ctx = R.RasterContext(grad_arena=arena)
+        r_ = rast(ctx)
+        for rep in range(reps):
+            m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+            kw = dict(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"], scales=view_scales(),
+                      rotations=t["rotations"])
+            outs = r_(**kw) if not isinstance(r_, CapturedViews) else r_(cfg["sets"], **kw)
+            grads = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves + [m2d],
+                                        [y for k in range(V) for y in ups[k]], allow_unused=arena is not None)
+            compare(f"{tag} rep {rep}", outs, grads[:-1], grads[-1], arena)
+    batched(lambda ctx: GaussianRasterizerViews(cfg["sets"], context=ctx), "views", 2)
+    batched(lambda ctx: CapturedViews(context=ctx), "captured", 5)
+    torch.cuda.synchronize()
+    return fails
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    for seed in range(first, first + n):
+        cfg = config(seed)
+        try:
+            fails = run(cfg)
+        except Exception as e:       # an exception is a failure of the configuration, not of the run
+            fails = [f"exception {e!r}"]
+        if fails:
+            bad += 1
+            print(f"seed {seed} P={cfg['P']} K={cfg['K']} D={cfg['D']} {cfg['H']}x{cfg['W']} V={cfg['V']} noisy={cfg['noisy']} "
+                  f"arena={cfg['arena']} radius={cfg['radius']}: " + "; ".join(fails[:4]), flush=True)
+    print(f"fuzz_views: {n - bad} of {n} configurations clean (seeds {first}..{first + n - 1})")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
