@@ -202,6 +202,7 @@ class _RasterizeViews(torch.autograd.Function):
                                           cov3D_precomp, rc=rc)
         ctx.states, ctx.rc = [st for _, st in res], rc
         ctx.opac_shape = opacities.shape
+        ctx.has_means2D = means2D is not None
         ctx.per_view_scales = scales is not None and scales.dim() == 3      # [V,P,3]: every view its own scales
         ctx.set_materialize_grads(False)       # no zero tensors for outputs nobody differentiates (radii is [P] int32)
         outs = []
@@ -223,6 +224,8 @@ class _RasterizeViews(torch.autograd.Function):
         o = R.rasterize_backward_views_raw(sts, gcs, gdas, arena=rc.grad_arena, accumulate=rc.accumulate,
                                            stats=rc.densify_stats, stats_views=rc.stats_views,
                                            per_view_scales=ctx.per_view_scales, profile=rc.profile)
+        if not ctx.has_means2D:
+            o["dL_dmeans2D"] = None
         if rc.grad_arena is not None:      # the parameter gradients live in the arena, not in .grad (RasterContext)
             return (None, o["dL_dmeans2D"], None, o["dL_dcolors"], None,
                     o["dL_dscales"] if ctx.per_view_scales else None, None, o["dL_dcov3D"], None, None)
@@ -254,7 +257,7 @@ class GaussianRasterizerViews(torch.nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         V = len(self.raster_settings_list)
-        if means2D.shape[0] != V:
+        if means2D is not None and means2D.shape[0] != V:      # (None: like GaussianRasterizer, nobody wants its gradient)
             raise ValueError(f"means2D must be [V,P,3] with V = {V} views")
         if any(s.score_flag for s in self.raster_settings_list):
             # forward-only, like the reference's score_render (scene_gaussian.py:546-671): per view the 4-tuple

@@ -155,3 +155,29 @@ def test_views_of_one_call_must_share_image_size():
         GaussianRasterizerViews([mk(32, 48), mk(32, 48, sm=2.0)])
     with pytest.raises(ValueError):
         GaussianRasterizerViews([])
+
+
+@pytest.mark.gpu
+def test_batched_views_accept_means2D_none(built_lib):
+    """GaussianRasterizer takes means2D=None (nobody wants the screen-space gradient: inference renders); so does the batched
+    module -- same images, and a backward to the parameters alone."""
+    from dreamscene_amd import synth
+    from dreamscene_amd.views import GaussianRasterizerViews
+    dev = torch.device("cuda:0")
+    P, H, W, V = 800, 64, 80, 3
+    g, _ = small_scene(P=P, H=H, W=W, K=16, seed=5)
+    cams = synth.object_cameras(V + 1, H, W, radius=3.0)[1:]
+    sets = [settings_for(c, [1.0, 1.0, 1.0], 3, dev) for c in cams]
+    t = {k: torch.tensor(v, device=dev, requires_grad=True) for k, v in g.items()}
+    kw = dict(means3D=t["means3D"], shs=t["shs"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+    ref = GaussianRasterizerViews(sets)(means2D=torch.zeros((V, P, 3), device=dev, requires_grad=True), **kw)
+    gref = torch.autograd.grad([o[0].sum() + o[2].sum() for o in ref], [t["means3D"], t["opacities"]], [torch.ones((), device=dev)] * V)
+    out = GaussianRasterizerViews(sets)(means2D=None, **kw)
+    got = torch.autograd.grad([o[0].sum() + o[2].sum() for o in out], [t["means3D"], t["opacities"]], [torch.ones((), device=dev)] * V)
+    for a, b in zip(out, ref):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for a, b in zip(got, gref):
+        assert tol_ok(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6)
+    with torch.no_grad():
+        out2 = GaussianRasterizerViews(sets)(means2D=None, **kw)
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(out2, ref))

@@ -3,7 +3,8 @@ radius, per-view backgrounds / degrees / scale noise) through
   (a) one GaussianRasterizer call per view (the reference's interface),
   (b) ONE GaussianRasterizerViews call,
   (c) ONE CapturedViews call (twice: eager warm-up steps, then replays),
-outputs of (b), (c) bit-equal to (a); parameter gradients (sum over the views) within 2e-6 x max(1, max|ref|) of (a)'s sum in
+outputs of (b), (c) bit-equal to (a) -- within 2e-6 x max(1, max|ref|) where the host picked the other forward variant for the
+batch --; parameter gradients (sum over the views) within 2e-6 x max(1, max|ref|) of (a)'s sum in
 float64 -- (b) and (c) add the views' gradients on the device in fp32, (a) leaves the sum to the caller.
 usage: python tools/fuzz_views.py [n_configs] [first_seed]   -> prints one line per failure and a summary; exit code 1 on failure"""
 import os
@@ -22,6 +23,7 @@ from tests.util import settings_for  # noqa: E402
 
 DEV = torch.device("cuda:0")
 NAMES = ("means3D", "shs", "opacities", "scales", "rotations")
+VARIANT = [0]           # (view, call) pairs whose image was not bit-equal to the per-view call's (other forward variant)
 
 
 def config(seed):
@@ -70,9 +72,23 @@ def run(cfg):
 
     def compare(tag, outs, grads, m2d_g, arena):
         for k, ((img, radii, da), (rimg, rradii, rda)) in enumerate(zip(outs, outs_a)):
-            if not (torch.equal(radii, rradii) and torch.equal(img, rimg) and torch.equal(da, rda)):
-                fails.append(f"{tag}: outputs of view {k} differ from the per-view call")
-        got = [arena.views[n] for n in NAMES] if arena is not None else grads
+            if not torch.equal(radii, rradii):
+                fails.append(f"{tag}: radii of view {k} differ from the per-view call")
+            if torch.equal(img, rimg) and torch.equal(da, rda):
+                continue
+            # the host picks the forward variant (list-parallel / whole-tile: GsrBinning.fwd_mode) per launch from the
+            # previous launch's statistics -- a batch may take the other one than a single view, and the two differ in the
+            # association of the colour / depth sums (render.hip): ulps, not bits
+            VARIANT[0] += 1
+            for what, a, b in (("image", img, rimg), ("depth_alpha", da, rda)):
+                e = float((a.detach().double() - b.detach().double()).abs().max())
+                if not e <= 2e-6 * max(1.0, float(b.detach().abs().max())):
+                    fails.append(f"{tag}: {what} of view {k} off by {e:.2e} from the per-view call")
+        got = [arena.views[n] for n in NAMES] if arena is not None else list(grads)
+        if arena is not None and cfg["noisy"]:
+            # per-view scales ([V,P,3], a function of the leaf): their gradient goes back through autograd and the noise
+            # arithmetic to the leaf; the arena receives the other four (views.py, bench.py `training_like`)
+            got[NAMES.index("scales")] = grads[NAMES.index("scales")]
         for n, a, b in zip(NAMES, got, tot):
             a = a.reshape(b.shape).double()
             scale = max(1.0, float(b.abs().max()) if b.numel() else 1.0)
@@ -116,7 +132,8 @@ def main():
             bad += 1
             print(f"seed {seed} P={cfg['P']} K={cfg['K']} D={cfg['D']} {cfg['H']}x{cfg['W']} V={cfg['V']} noisy={cfg['noisy']} "
                   f"arena={cfg['arena']} radius={cfg['radius']}: " + "; ".join(fails[:4]), flush=True)
-    print(f"fuzz_views: {n - bad} of {n} configurations clean (seeds {first}..{first + n - 1})")
+    print(f"fuzz_views: {n - bad} of {n} configurations clean (seeds {first}..{first + n - 1}); {VARIANT[0]} (view, call) "
+          f"outputs equal to the per-view call's within 2e-6 instead of bit for bit")
     sys.exit(1 if bad else 0)
 
 
