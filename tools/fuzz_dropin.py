@@ -18,6 +18,7 @@ from tests.util import same_bits, settings_for  # noqa: E402
 
 DEV = torch.device("cuda:0")
 NAMES = ("means3D", "shs", "opacities", "scales", "rotations")
+TOTALS = dict(calls=0, replays=0, eager=0, no_slot=0)        # the captured ring over the whole run
 
 
 def config(seed):
@@ -98,6 +99,9 @@ def main():
                              ("ring + streams 2", RasterContext(side_streams=2, dropin_graphs=True))):
                 dropin.reset()
                 got = run(cfg, ctx)
+                for r_ in dropin.stats().values():
+                    for k_ in TOTALS:
+                        TOTALS[k_] += r_.get(k_, 0)
                 for step, ((o_r, g_r), (o_g, g_g)) in enumerate(zip(ref, got)):
                     for k, (a, b) in enumerate(zip(o_g, o_r)):
                         if not all(torch.equal(x, y) for x, y in zip(a, b)):
@@ -115,7 +119,10 @@ def main():
             bad += 1
             print(f"seed {seed} P={cfg['P']} K={cfg['K']} D={cfg['D']} {cfg['H']}x{cfg['W']} V={cfg['V']} {cfg['pattern']} "
                   f"blind={cfg['blind']}: {len(fails)} failures: " + "; ".join(fails[:3]), flush=True)
-    print(f"fuzz_dropin: {n - bad} of {n} configurations clean (seeds {first}..{first + n - 1})")
+    from dreamscene_amd import rasterizer as R
+    st = R.side_stream_stats()
+    print(f"fuzz_dropin: {n - bad} of {n} configurations clean (seeds {first}..{first + n - 1}); captured ring {TOTALS}; internal "
+          f"streams {dict(calls=sum(v['calls'] for v in st.values()), reused_forks=sum(v['reused_forks'] for v in st.values()))}")
     sys.exit(1 if bad else 0)
 
 
