@@ -203,3 +203,26 @@ def test_reduce_scatter_sharded_adam_all_gather(tmp_path):
     lr = torch.tensor(np.random.default_rng(8).uniform(1e-3, 1e-2, size=n).astype(np.float32))
     _adam_ref(params, g, torch.zeros(n), torch.zeros(n), 1, lr, (0.9, 0.999), 1e-15)
     assert np.array_equal(r0["params"], params.numpy())
+
+
+@pytest.mark.parametrize("mode,D,row_frac", [("dense", 3, 1.0), ("direct", 3, 0.4), ("direct", 1, 1.0), ("rows", 2, 0.1),
+                                             ("sparse_rs", 3, 0.16), ("sparse_rs", 0, 0.5)])
+def test_grad_exchange_formats_at_world_size_8(tmp_path, mode, D, row_frac):
+    """The node the driver scales to: 8 ranks. P = 257 is no multiple of 8 (`direct` pads its slices, the last owner of
+    `sparse_rs` holds a short range). Replicas bit-identical; the formats that add in RANK ORDER (direct, rows, sparse_rs)
+    give exactly ((g0 + g1) + g2) + ... in fp32; the ring of `dense` associates as gloo pleases (1e-6 of the float64 sum)."""
+    world, P, K = 8, 257, 16
+    port = _free_port()
+    mp.spawn(_exchange_worker, args=(world, port, P, K, D, row_frac, mode, str(tmp_path)), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert all(str(r["fmt"]) == mode for r in rs)
+    for r in rs[1:]:
+        assert np.array_equal(rs[0]["flat"], r["flat"]), "replicas must hold bit-identical sums"
+    parts = [_fake_rank_grads(r, P, K, D, row_frac).flat.numpy() for r in range(world)]
+    exact = np.sum([p.astype(np.float64) for p in parts], axis=0)
+    np.testing.assert_allclose(rs[0]["flat"], exact, rtol=0, atol=2e-6 * max(1.0, float(np.abs(exact).max())))
+    if mode != "dense":
+        ordered = parts[0].copy()
+        for p in parts[1:]:
+            ordered += p
+        assert np.array_equal(rs[0]["flat"], ordered), np.abs(rs[0]["flat"] - ordered).max()
