@@ -199,7 +199,8 @@ class GradExchange:
         (rank r receives slice r of every rank's buffer: W - 1 messages of |buffer| / W per rank, all seven links busy at
         once), a local sum in rank order, ONE all-gather of the reduced slices. Same bytes as the ring, but every byte
         crosses one link once instead of travelling W - 1 hops in lock step: (W-1)/W |buffer| / (7 x 153 GB/s) per phase
-        (2 x 96 us for 118 MB at W = 8) against the ring's 2 (W-1)/W |buffer| / busbw. Opt-in (never measured here);
+        (2 x 96 us for 118 MB at W = 8) against the ring's 2 (W-1)/W |buffer| / busbw. The local sum is one pass of the library
+        on a GPU (gsr_sum_slices, 26 us at C3). `bench.py --exchange measure` times it beside `dense` (no xGMI node has run it yet);
       * "rows":  every rank contributes only its non-zero rows: all-gather of the row counts, then of (row index, row
         values) padded to the largest count; each rank adds the contributions in RANK ORDER, so all replicas end up
         with bit-identical sums (as they do with the ring all-reduce) and keep taking identical optimizer steps.
