@@ -23,7 +23,9 @@ allow ~8 000). This module puts the launches of a view behind two graph launches
     slot's result dict holds as well: autograd consumes them in stream order (the next node's kernels are enqueued before
     the slot can be replayed again) and CLONES a tensor somebody else holds before it keeps it as `.grad` or adds into it,
     `retain_grad()` clones. Only the result of `torch.autograd.grad(...)` aliases a slot; it stays valid until that slot's
-    next backward -- at least one full step. INTEGRATION.md section 5c.
+    next backward -- a full step when the views' forwards of a step precede their backwards (the trainers), but only until the
+    NEXT view's backward when every view runs forward + backward before the next one starts (the freed slot is the first
+    one the next call finds): clone what you keep. INTEGRATION.md section 5b'.
 
 Not eligible (the eager path runs, as before): colors_precomp / cov3D_precomp inputs, score_flag, camera gradients, a
 RasterContext with an arena / profile / densify_stats, non-fp32 or non-contiguous inputs, P = 0, grids beyond 256 x 256

@@ -122,8 +122,9 @@ def test_edits_and_fresh_tensors_between_calls_are_seen(built_lib):
 
 
 def test_module_without_a_context_follows_the_environment(built_lib, monkeypatch):
-    from dreamscene_amd import rasterizer as R
+    from dreamscene_amd import dropin, rasterizer as R
     from dreamscene_amd.rasterizer import GaussianRasterizer
+    monkeypatch.setattr(dropin, "ENABLED", False)      # (with GSR_DROPIN_GRAPHS=1 exported the ring would take these calls first)
     g, cams, ups = _scene(P=10_000, res=128, n_cams=2)
     params = {k: torch.tensor(v, device=DEV) for k, v in g.items()}
     s = settings_for(cams[0], np.ones(3, np.float32), 3, DEV)

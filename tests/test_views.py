@@ -41,7 +41,7 @@ def test_batched_views_match_sequential(built_lib, K, D, use_arena, noisy_scales
                                                     opacities=t["opacities"], scales=sck, rotations=t["rotations"])
             gr = torch.autograd.grad([img, da], leaves + [m2d], [gis[k], gdas[k]])
             outs.append((img, radii, da))
-            m2ds.append(gr[-1])
+            m2ds.append(gr[-1].clone())     # (a torch.autograd.grad result of the captured ring aliases its slot: dropin.py)
             tot = [a.clone() for a in gr[:-1]] if tot is None else [a + b for a, b in zip(tot, gr[:-1])]
         return outs, tot, torch.stack(m2ds)
 
