@@ -536,7 +536,7 @@ def main():
     # The noise is drawn inside the timed loop with torch, as the trainers do. Then the same plain step in the reference's
     # INITIAL state (every opacity 0.1: gs_renderer.py:598 -- ~87 layers blend before a pixel stops), and forward-only
     # rendering (video_inference, object_trainer.py:81-118: test=True views under no_grad).
-    training_like = init_state = forward_only = None
+    training_like = init_state = forward_only = trainer_step = None
     if args.train_seconds > 0 and args.scene == "object" and world == 1:
         import random as _random
         rng_t = np.random.default_rng(11)
@@ -551,7 +551,7 @@ def main():
             for j in range(V):
                 c, vm_, pm_, cp_ = cam_t[(V * i + j) % 64]
                 bg_ = white
-                if pyrng.random() < 0.5:
+                if pyrng.random() < 0.66:           # bg_aug_ratio of the shipped config (configs/objects/sample.yaml:74)
                     bg_ = torch.rand(3, device=dev) if pyrng.random() < 0.5 else black
                 out_.append(GaussianRasterizationSettings(
                     image_height=H, image_width=W, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=bg_, scale_modifier=1.0,
@@ -615,7 +615,7 @@ def main():
         n_, dt_ = timed(step_train_dropin, args.train_seconds)
         tl.update(dropin_views_per_s=round(n_ * V / dt_, 3), dropin_steps=n_,
                   what="per-view scale noise (scales [V,P,3], drawn with torch inside the loop), SH degree 0 w.p. 0.1, "
-                       "random / black background w.p. 0.5, 64 random cameras, 4 new ones per step; batched: gradients to the "
+                       "random / black background w.p. 0.66, 64 random cameras, 4 new ones per step; batched: gradients to the "
                        "noisy scales and means2D through autograd, the other parameter gradients summed in the arena; "
                        "drop-in: the unmodified trainers' call, every gradient through autograd")
         training_like = tl
@@ -634,6 +634,29 @@ def main():
         del held_op
         for _ in range(3):
             step()
+        # A whole reference-shaped training step (training/object_trainer.py:293-400: activations on fresh tensors, the four
+        # object_render calls INCLUDING the disp glue and its boolean-mask host read, stand-in guidance loss + TV + scale loss,
+        # backward, densification statistics, Adam): tools/train_step.py, three legs, at C3 and in the opacity-0.1 state.
+        # `rasterizer_ms` = what the rasterizer alone takes for the step's views on the same path (the entries above).
+        try:
+            from tools import train_step as TS
+            trainer_step = {"c3": TS.measure(P, H, W, V, K, D, dev, init_opacity=False, seconds=args.train_seconds),
+                            "init_state": TS.measure(P, H, W, V, K, D, dev, init_opacity=True, seconds=args.train_seconds),
+                            "what": "one object-training step shaped like training/object_trainer.py:293-400 "
+                                    "(tools/train_step.py): as_imported = the package as a DreamScene checkout imports it "
+                                    "(per-view calls, disp glue with its host read, torch Adam); views_fused = "
+                                    "GaussianRasterizerViews + statistics in K8 + FusedAdam; raw_leaves = "
+                                    "scene.rasterize_models_views (activations and noise fused into K1 / K8)"}
+            ras = {"as_imported": tl.get("dropin_views_per_s"), "views_fused": tl.get("views_per_s"),
+                   "raw_leaves": tl.get("views_per_s")}
+            for leg_, vps_ in ras.items():
+                e_ = trainer_step["c3"].get(leg_, {})
+                if vps_ and "ms_per_step" in e_:
+                    e_["rasterizer_ms"] = round(1e3 * V / vps_, 3)
+                    e_["rasterizer_share"] = round(e_["rasterizer_ms"] / e_["ms_per_step"], 3)
+        except Exception as e_:           # (the harness must never take the bench line with it)
+            trainer_step = {"error": repr(e_)[:300]}
+        torch.cuda.empty_cache()
         # forward only (video_inference): test=True views, no_grad
         fo_rast = [GaussianRasterizer(raster_settings=s_) for s_ in settings_list]
         fo_views = GaussianRasterizerViews(settings_list)
@@ -919,6 +942,7 @@ def main():
             "rotating_cameras": rotating,
             "dropin_graphs": dropin_ring_stats(),
             "training_like": training_like,
+            "trainer_step": trainer_step,
             "init_views_per_s": init_state["views_per_s"] if init_state else None,
             "init_state": init_state,
             "forward_only": forward_only,
@@ -1113,13 +1137,16 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), 
     torch_legs = dict(t_best or {}, physical_cores=phys, **({"note": t_note} if t_note else {}))
     img, da, radii, grads = hip_out
     names = ["dL_dmeans3D", "dL_dshs", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"]
-    worst, worst_frac, per = 0.0, 0.0, {}
+    worst, worst_rel, worst_frac, per = 0.0, 0.0, 0.0, {}
     for n, gt in zip(names, grads):
         ref = np.asarray(b[n], dtype=np.float64).reshape(-1)
         e = np.abs(gt.detach().cpu().numpy().astype(np.float64).reshape(-1) - ref)
-        scale = max(1.0, float(np.abs(ref).max()))
-        per[n] = {"max_err_over_scale": float(e.max() / scale), "frac_over_1e-5": float((e > 1e-5 * scale).mean())}
+        mref = max(1e-6, float(np.abs(ref).max()))          # the bar: 1e-5 of the tensor's OWN largest entry (no floor of 1)
+        scale = max(1.0, mref)                              # (rounds 1-5 reported against max(1, max|ref|): kept beside it)
+        per[n] = {"max_err_over_max_ref": float(e.max() / mref), "max_ref": mref, "max_err_over_scale": float(e.max() / scale),
+                  "frac_over_1e-5": float((e > 1e-5 * mref).mean())}
         worst = max(worst, per[n]["max_err_over_scale"])
+        worst_rel = max(worst_rel, per[n]["max_err_over_max_ref"])
         worst_frac = max(worst_frac, per[n]["frac_over_1e-5"])
     d_img = np.abs(img.detach().cpu().numpy() - f["image"]).max(axis=0)
     what = f"{P} Gaussians @{W}x{H}, orbit cameras{', all opacities 0.1' if init_opacity else ''}"
@@ -1139,8 +1166,10 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), 
                                         "@512^2 with the best of them (`threads`)")
     err = {"bit_exact_radii": bool(np.array_equal(radii.cpu().numpy(), f["radii"])),
            "image_max_abs": float(d_img.max()), "image_frac_pixels_over_1e-5": float((d_img > 1e-5).mean()),
-           "grads_max_err_over_max1": worst, "grads_max_frac_entries_over_1e-5": worst_frac,
-           "per_tensor": per, "tol": "1e-5 * max(1, max|ref|)",
+           "grads_max_err_over_max_ref": worst_rel, "grads_max_err_over_max1": worst,
+           "grads_max_frac_entries_over_1e-5": worst_frac,
+           "per_tensor": per, "tol": "1e-5 * max|ref| per tensor (max_err_over_max_ref; frac_over_1e-5 counts against it); "
+                                     "max_err_over_scale = the max(1, max|ref|) figure of rounds 1-5",
            "what": "view 0 through the plain per-view module (the drop-in path) against the scalar C oracle"}
     if timed_path is not None:
         err["batched_sum"] = timed_path_check(timed_path, (f, b), g, D, K, H, W, gi_np, gda_np)
@@ -1171,26 +1200,30 @@ def timed_path_check(tp, view0, g, D, K, H, W, gi_np, gda_np):
     dt = time.perf_counter() - t0
     names = {"means3D": "dL_dmeans3D", "shs": "dL_dshs", "opacities": "dL_dopacity", "scales": "dL_dscales",
              "rotations": "dL_drotations"}
-    per, worst, worst_frac = {}, 0.0, 0.0
+    per, worst, worst_rel, worst_frac = {}, 0.0, 0.0, 0.0
     for an, on in names.items():
         ref = sum(np.asarray(b[on], dtype=np.float64).reshape(-1) for _, b in res)
         e = np.abs(tp["arena"][an].astype(np.float64).reshape(-1) - ref)
-        scale = max(1.0, float(np.abs(ref).max()))
-        per[on] = {"max_err_over_scale": float(e.max() / scale), "frac_over_1e-5": float((e > 1e-5 * scale).mean())}
+        mref = max(1e-6, float(np.abs(ref).max()))
+        scale = max(1.0, mref)
+        per[on] = {"max_err_over_max_ref": float(e.max() / mref), "max_ref": mref, "max_err_over_scale": float(e.max() / scale),
+                   "frac_over_1e-5": float((e > 1e-5 * mref).mean())}
         worst, worst_frac = max(worst, per[on]["max_err_over_scale"]), max(worst_frac, per[on]["frac_over_1e-5"])
+        worst_rel = max(worst_rel, per[on]["max_err_over_max_ref"])
     img_err, da_err, m2d_err, radii_ok = 0.0, 0.0, 0.0, True
     for k, (f, b) in enumerate(res):
         img_err = max(img_err, float(np.abs(tp["images"][k] - f["image"]).max()))
         da_ref = f["depth_alpha"]
-        da_err = max(da_err, float(np.abs(tp["depth_alphas"][k] - da_ref).max() / max(1.0, float(np.abs(da_ref).max()))))
+        da_err = max(da_err, float(np.abs(tp["depth_alphas"][k] - da_ref).max() / max(1e-6, float(np.abs(da_ref).max()))))
         ref = np.asarray(b["dL_dmeans2D"], dtype=np.float64)
-        m2d_err = max(m2d_err, float(np.abs(tp["means2D"][k].astype(np.float64) - ref).max() / max(1.0, float(np.abs(ref).max()))))
+        m2d_err = max(m2d_err, float(np.abs(tp["means2D"][k].astype(np.float64) - ref).max() / max(1e-6, float(np.abs(ref).max()))))
         radii_ok = radii_ok and bool(np.array_equal(tp["radii"][k], f["radii"]))
     return {"through": tp["through"], "views": V, "bit_exact_radii_all_views": radii_ok,
-            "image_max_abs_all_views": img_err, "depth_alpha_max_err_over_max1": da_err,
-            "means2D_grad_max_err_over_max1": m2d_err,
-            "arena_sum_max_err_over_max1": worst, "arena_sum_max_frac_entries_over_1e-5": worst_frac, "per_tensor": per,
-            "oracle_seconds": round(dt, 1), "tol": "1e-5 * max(1, max|ref|)",
+            "image_max_abs_all_views": img_err, "depth_alpha_max_err_over_max_ref": da_err,
+            "means2D_grad_max_err_over_max_ref": m2d_err,
+            "arena_sum_max_err_over_max_ref": worst_rel, "arena_sum_max_err_over_max1": worst,
+            "arena_sum_max_frac_entries_over_1e-5": worst_frac, "per_tensor": per,
+            "oracle_seconds": round(dt, 1), "tol": "1e-5 * max|ref| per tensor",
             "what": f"one step exactly as timed ({V} views through ONE batched call, gradients summed in the arena) against "
                     "the scalar C oracle's per-view results and the float64 sum of its per-view gradients"}
 

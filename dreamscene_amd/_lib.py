@@ -134,6 +134,10 @@ SYMBOLS = [
     ("gsr_rows_unpack", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64, C.c_int32, C.c_void_p,
                                   C.c_void_p]),
     ("gsr_sum_slices", C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    ("gsr_rowmsg_bytes", C.c_size_t, [C.c_int32, C.c_int32, C.c_uint32]),
+    ("gsr_rowmsg_pack", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("gsr_rowmsg_apply", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
     ("gsr_knn_scratch_bytes", C.c_size_t, [C.c_int32]),
     ("gsr_knn_mean_dist2", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("gsr_backward", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom), C.POINTER(GsrBinning),

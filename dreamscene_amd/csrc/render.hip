@@ -278,10 +278,6 @@ render_fwd_body(const uint32_t item, const int W, const int H, const uint32_t* _
   // lists are padded with it to a multiple of four, so the compositing loop has no partial step.
   __shared__ Stage<SCORE, 1> st;
   __shared__ uint16_t cand[4][kBatch + 16];  // per wave: the batch's candidates for its 4x4 block, in list order (+ padding)
-#ifdef GSR_K6_PAD_LDS      // (occupancy probe, tools/r05_calls: extra LDS per workgroup -> fewer workgroups per CU)
-  __shared__ uint32_t k6_pad[GSR_K6_PAD_LDS / 4];
-  if (threadIdx.x == 0 && item == 0xFFFFFFFFu) k6_pad[work[0] & 1023u] = 1u;
-#endif
   if (threadIdx.x < 2) {
     st.s0[threadIdx.x][kBatch] = make_float4(0.f, 0.f, 0.f, 0.f);
     st.s1[threadIdx.x][kBatch] = make_float4(0.f, 0.f, 0.f, 0.f);

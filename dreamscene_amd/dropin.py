@@ -117,9 +117,13 @@ class _Ring:
         return best
 
 
-def eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, context) -> bool:
-    want = getattr(context, "dropin_graphs", None) if context is not None else None
-    if not (ENABLED if want is None else want):
+def eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, context,
+             wanted: Optional[bool] = None) -> bool:
+    """wanted: the caller has already decided that this accelerator is the selected one (rasterizer.per_view_accel)."""
+    if wanted is None:
+        want = getattr(context, "dropin_graphs", None) if context is not None else None
+        wanted = ENABLED if want is None else bool(want)
+    if not wanted:
         return False
     if shs is None or colors_precomp is not None or cov3D_precomp is not None:
         return False

@@ -148,7 +148,10 @@ class _DeviceRows:
         return rs
 
     def pack(self, rs, mask: torch.Tensor, F: int, guess: int):
-        """-> (idx int32 [n], rows [n, F]): the rows of `rs` whose bit is set in `mask`, ascending. One host read (n)."""
+        """-> (idx int32 [n], rows [n, F]): the rows of `rs` whose bit is set in `mask`, ascending. One host read (n).
+        LIFETIME: the two results are VIEWS of this object's message buffers -- the next pack() on the same _DeviceRows
+        overwrites (or reallocates) them. A caller that keeps a message across another pack uses a second _DeviceRows
+        (GradExchange._own_rows does for the owner-side pack of sparse_rs) or clones."""
         n_rows = int(rs.rows)
         sb = int(self.lib.gsr_rows_scratch_bytes(n_rows))
         if self.scratch is None or self.scratch.numel() < sb:
@@ -183,6 +186,73 @@ class _DeviceRows:
                          "gsr_rows_unpack")
 
 
+class _RowMessages:
+    """Self-describing row messages (csrc/exchange.hip, gsr_rowmsg_pack / gsr_rowmsg_apply): the `rows` exchange of a cuda
+    arena without a count on the host. ONE pack launch, ONE fixed-size all-gather, ONE apply launch; the capacity is speculated
+    and the apply kernel reports -- into a page-locked word, when it STARTS -- whether every message fitted and the largest
+    count, which is all the capacity policy looks at (the same number on every rank: the capacities stay equal)."""
+
+    PENDING = 0
+
+    def __init__(self, device):
+        from . import _lib as L
+        self.L, self.lib, self.dev = L, L.load(), device
+        self.key = None
+        self.msg = self.all = None
+        self.status = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.status_np = self.status.numpy()
+        self.armed = False
+
+    def buffers(self, P: int, F: int, W: int, cap: int):
+        key = (P, F, W, cap)
+        if key != self.key:
+            nbytes = int(self.lib.gsr_rowmsg_bytes(P, F, cap))
+            self.msg = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            self.all = torch.empty(W * nbytes, dtype=torch.uint8, device=self.dev)
+            self.key, self.nbytes = key, nbytes
+        return self.msg, self.all, self.nbytes
+
+    def pack(self, rs, mask: torch.Tensor, cap: int) -> None:
+        with torch.cuda.device(self.dev):
+            self.L.check(self.lib.gsr_rowmsg_pack(rs, mask.data_ptr(), self.msg.data_ptr(), int(cap),
+                                                  torch.cuda.current_stream(self.dev).cuda_stream), "gsr_rowmsg_pack")
+
+    def apply(self, rs, W: int, cap: int) -> None:
+        self.status_np[0] = self.PENDING
+        self.armed = True
+        with torch.cuda.device(self.dev):
+            self.L.check(self.lib.gsr_rowmsg_apply(rs, self.all.data_ptr(), self.nbytes, int(W), int(cap), self.status.data_ptr(),
+                                                   None, torch.cuda.current_stream(self.dev).cuda_stream), "gsr_rowmsg_apply")
+
+    def result(self):
+        """(applied, largest count) of the last apply(); waits for the apply kernel to START (not for it to finish)."""
+        if not self.armed:
+            return True, 0
+        spins = 0
+        while int(self.status_np[0]) == self.PENDING:
+            spins += 1
+            if spins > 4096:            # (not fine-grained page-locked memory: the word shows at kernel end)
+                torch.cuda.current_stream(self.dev).synchronize()
+                if int(self.status_np[0]) == self.PENDING:      # (another stream's apply: wait for the device)
+                    torch.cuda.synchronize(self.dev)
+        self.armed = False
+        v = int(self.status_np[0])
+        return (v & 0xFFFFFFFF) == 1, (v >> 32) & 0xFFFFFFFF
+
+
+class ExchangeHandle:
+    """reduce(async_op=True): the exchange runs on the exchange's own stream; wait() makes the caller's current stream wait for it
+    (no host synchronisation)."""
+
+    def __init__(self, event, dev):
+        self._event, self._dev = event, dev
+
+    def wait(self) -> None:
+        if self._event is not None:
+            torch.cuda.current_stream(self._dev).wait_event(self._event)
+            self._event = None
+
+
 class GradExchange:
     """Sum of the arena over the ranks of a step, moving only what can be non-zero.
 
@@ -212,16 +282,32 @@ class GradExchange:
         bytes out), the owner adds them in rank order, and the owners' reduced rows (the union over the ranks' views)
         are all-gathered. Per rank at W = 8, C3 (15.7 % of the rows per rank, union ~30 %): 16.5 + 31.5 = 48 MB against
         the dense ring's 206 MB. Three small host reads per step (row counts).
-    `reduce_scatter_adam` is the sharded-optimizer form of the dense exchange (flat parameter arena required)."""
+    `reduce_scatter_adam` is the sharded-optimizer form of the dense exchange (flat parameter arena required).
+
+    "rows" on a cuda arena whose reached bitmap K8 left is valid takes the DEVICE form (`_RowMessages`): one pack launch, one
+    fixed-size all-gather of self-describing messages, one apply launch that stores the rank-ordered sums -- no count on the
+    host, no zero-fill of the arena, no index list on the wire. The capacity is speculated (it starts at P / 4 rows and follows
+    1.25 x the largest count any rank ever sent); `strict` (default True) polls the apply kernel's status word -- written when
+    the kernel starts, so the device is not drained -- and repeats the exchange with more room if a message did not fit (the
+    arena is untouched then). strict=False never reads: the status of step k is looked at when step k + 1 calls reduce() (or
+    finish()); a step that overflowed leaves its arena UN-reduced and is counted in `overflowed_steps` -- for loops whose
+    consumer can tolerate or detect that (bench.py checks the counter after its timed region).
+    reduce(async_op=True): the whole exchange on the exchange's own stream, ordered behind the caller's current stream;
+    ExchangeHandle.wait() joins -- the per-view statistics all-reduce and the optimizer's prologue run beside it."""
 
     GEOM = ("means3D", "scales", "rotations", "opacities")
 
     def __init__(self, arena: GradArena, sh_degree: Optional[int] = None, group=None, mode: str = "auto",
-                 rows_below: Optional[float] = None):
+                 rows_below: Optional[float] = None, strict: bool = True):
         if mode not in ("auto", "dense", "rows", "direct", "sparse_rs"):
             raise ValueError("mode is 'auto', 'dense', 'rows', 'sparse_rs' or 'direct'")
         self.arena, self.group, self.mode = arena, group, mode
         self.rows_below = rows_below
+        self.strict = bool(strict)
+        self.overflowed_steps = 0
+        self._msgs = None             # _RowMessages (device form of "rows")
+        self._rows_cap = 0            # speculated capacity of a row message (rows); the same on every rank
+        self._side = None             # the exchange's own stream (async_op)
         self.sh_degree = None
         self.set_sh_degree(sh_degree)
         self.last = {}          # what the last reduce() did (format, bytes): for logs / bench lines
@@ -313,14 +399,76 @@ class GradExchange:
         v["shs"][:, :nb, :].index_add_(0, idx, rows[:, 11:].reshape(n, nb, 3))
 
     # ---- the exchange
-    def reduce(self):
+    def reduce(self, async_op: bool = False):
         """Leaves the sum over all ranks in the arena, on every rank, bit-identical across ranks. Afterwards the arena's
-        reached-row bitmap (this rank's views only) no longer describes its contents: GradArena.touch()."""
+        reached-row bitmap (this rank's views only) no longer describes its contents: GradArena.touch().
+        async_op (cuda arenas): the exchange is enqueued on the exchange's own stream behind everything the caller's current
+        stream holds, and an ExchangeHandle is returned; the arena must not be touched before handle.wait()."""
+        if async_op and self.arena.flat.is_cuda and dist.is_available() and dist.is_initialized() \
+                and dist.get_world_size(self.group) > 1:
+            dev = self.arena.flat.device
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            self._side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._side):
+                self.reduce(False)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            return ExchangeHandle(ev, dev)
         try:
             self._reduce()
         finally:
             if self.last.get("format") != "none":
                 self.arena.touch()
+        return ExchangeHandle(None, None) if async_op else None
+
+    def finish(self) -> bool:
+        """strict=False: looks at the status of the last device-form exchange (waits for its apply kernel to start). False = a
+        message had not fitted: that step's arena was left un-reduced (counted in overflowed_steps, capacity raised)."""
+        return self._settle_rows()
+
+    def _settle_rows(self) -> bool:
+        if self._msgs is None or not self._msgs.armed:
+            return True
+        ok, worst = self._msgs.result()
+        self._grow_cap(worst)
+        if not ok:
+            self.overflowed_steps += 1
+        return ok
+
+    def _grow_cap(self, worst: int) -> None:
+        want = (int(worst * 1.25) + 2047) // 1024 * 1024
+        if want > self._rows_cap:
+            self._rows_cap = min(want, (self.arena.P + 1023) // 1024 * 1024)
+
+    def _reduce_rows_device(self, W: int) -> None:
+        """The `rows` format on the device (see the class docstring)."""
+        P, F = self.arena.P, self.row_floats
+        if self._msgs is None:
+            self._msgs = _RowMessages(self.arena.flat.device)
+        self._settle_rows()                        # (strict=False: the previous step's status, long since written)
+        if self._rows_cap == 0:
+            self._rows_cap = min((max(P // 4, 1024) + 1023) // 1024 * 1024, (P + 1023) // 1024 * 1024)
+        rs = self._arena_rowset()
+        tries = 0
+        while True:
+            cap = self._rows_cap
+            msg, allm, nbytes = self._msgs.buffers(P, F, W, cap)
+            self._msgs.pack(rs, self.arena.reached, cap)
+            _all_gather_into(allm, msg, self.group)
+            self._msgs.apply(rs, W, cap)
+            self.last = dict(format="rows", device=True, row_floats=F, cap_rows=cap, bytes_per_rank=int((W - 1) * nbytes),
+                             host_reads=0)
+            if not self.strict:
+                return
+            ok, worst = self._msgs.result()
+            self.last.update(rows_max=worst, host_reads=1)
+            self._grow_cap(worst)
+            if ok:
+                return
+            tries += 1                              # a message did not fit: nothing was applied, the arena is intact
+            if tries > 2:
+                raise RuntimeError(f"row messages of {worst} rows do not fit a capacity of {cap} after {tries} attempts")
 
     def _reduce(self):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
@@ -331,6 +479,9 @@ class GradExchange:
         mode = self.mode
         idx = counts = None
         msg_rows = None
+        if mode == "rows" and self._dev_rows is not None and getattr(self.arena, "reached_valid", False):
+            self._reduce_rows_device(W)
+            return
         if mode in ("auto", "rows"):      # ("sparse_rs" counts per owner itself)
             idx, msg_rows = self._message()
             cnt = torch.empty(W, dtype=torch.int64, device=idx.device)

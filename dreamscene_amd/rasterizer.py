@@ -77,6 +77,11 @@ class RasterContext:
                    (pick_seg_len); 256, 128 or 64 = that for every call made with this context
     side_streams   GaussianRasterizer only: consecutive calls rotate over this many internal HIP streams (see `_SideStreams`):
                    None = what the environment says (GSR_SIDE_STREAMS=n; default SIDE_STREAMS_DEFAULT), 0 / 1 = the caller's stream
+    per_view_accel GaussianRasterizer only: the ONE opt-in accelerator of the per-view call -- "off", "streams" (internal
+                   streams, `side_streams` of them, 2 when unset) or "graphs" (captured ring, dropin.py). None = derived from
+                   the two fields above / their environment variables. The two are mutually exclusive BY CONSTRUCTION: asking
+                   for both (fields or environment) raises -- they are slower together than either alone (HISTORY round 5:
+                   2 420 vs 2 497 / 2 583 views/s) and serve different call patterns.
     """
     score_mode: int = 0
     profile: Optional[L.Profile] = None
@@ -90,6 +95,7 @@ class RasterContext:
     host_stats: Optional["HostStats"] = None
     seg_len: Optional[int] = None
     side_streams: Optional[int] = None
+    per_view_accel: Optional[str] = None
 
     def snapshot(self) -> "RasterContext":
         # (a plain field-for-field copy: dataclasses.replace() re-runs __init__ through a keyword dict, ~3 us per call)
@@ -174,6 +180,7 @@ class _Workspace:
         return t
 
 
+_PAIR_COUNT_SPINS = 4096     # polls of the pair-count word before _wait_pair_counts falls back to event.synchronize()
 _WORKSPACES = {}
 _STATE_LAYOUTS = {}     # (sizes of a call) -> (offsets of the regions of its state buffer, total bytes)
 
@@ -200,8 +207,16 @@ def _wait_pair_counts(words, n: int, event) -> None:
         if (words[0] != -1) if n == 1 else (int(words[:n].min()) != -1):
             return
         spins += 1
-        if (spins & 31) == 0 and event.query():
-            return
+        if (spins & 31) == 0:
+            if event.query():
+                return
+            if spins >= _PAIR_COUNT_SPINS:
+                # the early store has not become visible for ~a millisecond of polling (page-locked memory that is not
+                # fine-grained -- HIP_HOST_COHERENT=0 -- shows it at kernel end only): stop burning a core under the GIL and
+                # block on the event; the words are final once it has completed
+                event.synchronize()
+                return
+            time.sleep(0)            # let other Python threads (data loaders, other ranks' helper threads) take the GIL
 
 
 def rasterize_forward_raw(s: GaussianRasterizationSettings, means3D, opacities, shs, colors_precomp, scales,
@@ -951,6 +966,29 @@ SIDE_STREAMS_DEFAULT = 0
 SIDE_STREAMS_MAX = 8
 
 
+PER_VIEW_ACCELS = ("off", "streams", "graphs")
+
+
+def per_view_accel(context) -> str:
+    """The one accelerator of the per-view call this context (or, with None fields, the environment) selects: "off", "streams"
+    or "graphs". Both at once is an error, never a silent precedence."""
+    mode = getattr(context, "per_view_accel", None) if context is not None else None
+    if mode is None:
+        mode = os.environ.get("GSR_PER_VIEW_ACCEL") or None
+    if mode is not None:
+        if mode not in PER_VIEW_ACCELS:
+            raise ValueError(f"per_view_accel is one of {PER_VIEW_ACCELS}, not {mode!r}")
+        return mode
+    from . import dropin
+    g = getattr(context, "dropin_graphs", None) if context is not None else None
+    graphs = dropin.ENABLED if g is None else bool(g)
+    streams = _side_streams_wanted(context) > 1
+    if graphs and streams:
+        raise ValueError("internal streams (side_streams / GSR_SIDE_STREAMS) and the captured ring (dropin_graphs / "
+                         "GSR_DROPIN_GRAPHS) are mutually exclusive: choose one (RasterContext.per_view_accel)")
+    return "graphs" if graphs else ("streams" if streams else "off")
+
+
 def _side_streams_wanted(context) -> int:
     n = context.side_streams if (context is not None and context.side_streams is not None) else None
     if n is None:
@@ -975,18 +1013,24 @@ class _SideStreams:
     def proves_complete(self, inputs) -> bool:
         """Every input is the same live tensor object, at the same version counter, as when it was last seen complete."""
         known = self.known
-        for t in inputs:
-            e = known.get(id(t))
-            if e is None or e[0]() is not t or e[1] != t._version:
-                return False
+        try:
+            for t in inputs:
+                e = known.get(id(t))
+                if e is None or e[0]() is not t or e[1] != t._version or e[2] != t.data_ptr():
+                    return False
+        except RuntimeError:             # (inference-mode tensors have no version counter: never provably unchanged)
+            return False
         return True
 
     def remember(self, inputs) -> None:
         known = self.known
         if len(known) > 512:                     # (ids of dead tensors accumulate: start over, one serialised call)
             known.clear()
-        for t in inputs:
-            known[id(t)] = (weakref.ref(t), t._version)
+        try:
+            for t in inputs:
+                known[id(t)] = (weakref.ref(t), t._version, t.data_ptr())
+        except RuntimeError:             # inference-mode tensor: forget everything, the next call forks from "now"
+            known.clear()
 
     def fork_event(self, cur, inputs):
         if self.fork is not None and self.proves_complete(inputs):
@@ -1061,9 +1105,22 @@ class _RasterizeGaussians(torch.autograd.Function):
             with torch.cuda.stream(side):
                 out, st = rasterize_forward_raw(settings, means3D, opacities, shs, colors_precomp, scales, rotations,
                                                 cov3D_precomp, want_aux=False, rc=rc)
-            for t_ in (out["color"], out["radii"], out["depth_alpha"], out["score"]) + tuple(st.keep[12]):
-                if t_ is not None:
-                    t_.record_stream(cur)     # allocated in the internal stream's pool; read by the caller / the backward
+            # Everything the caller's stream will read that may have been ALLOCATED inside this forward belongs to the internal
+            # stream's pool: the outputs, the state buffers, and every copy _prep() made of an input -- .contiguous() / .float()
+            # of bg / viewmatrix / projmatrix / campos (the reference builds its cameras as RT.transpose(0, 1).cuda(),
+            # utils/cam_utils.py:197: non-contiguous, so a fresh copy per call) or of a parameter tensor. K7 / K8 read them
+            # through raw pointers on the caller's stream; without record_stream the block would return to the internal pool
+            # when ctx dies and the next forward on that stream could overwrite it under a backward still in flight.
+            # (record_stream on a tensor of the caller's own pool -- an input passed through untouched -- is harmless.)
+            def _mark(x):
+                if isinstance(x, torch.Tensor):
+                    if x.is_cuda:
+                        x.record_stream(cur)
+                elif isinstance(x, (tuple, list)):
+                    for y in x:
+                        _mark(y)
+            _mark((out["color"], out["radii"], out["depth_alpha"], out["score"]))
+            _mark(st.keep)
         ctx.st, ctx.rc = st, rc
         ctx.opac_shape = opacities.shape
         ctx.cam_shapes = (viewmatrix.shape, projmatrix.shape, campos.shape)
@@ -1117,11 +1174,14 @@ class GaussianRasterizer(torch.nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         s = self.raster_settings
         ctx = self.context
-        from . import dropin
-        if dropin.eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, ctx):
-            out = dropin.rasterize(s, means3D, means2D, opacities, shs, scales, rotations, ctx)
-            if out is not None:
-                return out
+        accel = per_view_accel(ctx)
+        if accel == "graphs":
+            from . import dropin
+            if dropin.eligible(s, means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, ctx,
+                               wanted=True):
+                out = dropin.rasterize(s, means3D, means2D, opacities, shs, scales, rotations, ctx)
+                if out is not None:
+                    return out
 
         # no backward can follow (torch.no_grad(), or nothing that requires a gradient): the forward writes no checkpoints
         forward_only = not (torch.is_grad_enabled() and any(
@@ -1134,11 +1194,10 @@ class GaussianRasterizer(torch.nn.Module):
             rc._forward_only = forward_only
             return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                              cov3D_precomp, s.viewmatrix, s.projmatrix, s.campos, s, rc)
-        n = _side_streams_wanted(ctx)
+        n = max(_side_streams_wanted(ctx), 2) if accel == "streams" else 0
         # (a profile times stages with events on ONE stream; a stream being captured stays as it is; the captured ring above has
-        #  its own way of cutting the host's share and is not combined with the internal streams: measured slower together,
-        #  profiles/HISTORY.md round 5. An arena / densification statistics are written by the BACKWARD, which stays on the
-        #  caller's stream: no restriction.)
+        #  its own way of cutting the host's share and is never combined with the internal streams: per_view_accel. An arena /
+        #  densification statistics are written by the BACKWARD, which stays on the caller's stream: no restriction.)
         if n > 1 and means3D.is_cuda and (ctx is None or ctx.profile is None) \
                 and not torch.cuda.is_current_stream_capturing():
             return _call_on_side_stream(n, call, (means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp), s)

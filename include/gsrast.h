@@ -418,6 +418,21 @@ int gsr_rows_unpack(const GsrRowSet* set, const uint32_t* idx, const float* rows
  * ((s_0[i] + s_1[i]) + s_2[i]) + ... over n_slices slices of slice_floats floats, slice w at slices + w * stride_floats -- rank
  * order, the association every rank applies to the slice it owns. out may be slice 0 (in place). One launch. */
 int gsr_sum_slices(const float* slices, int32_t n_slices, uint64_t slice_floats, uint64_t stride_floats, float* out, void* stream);
+/* Self-describing row messages: the host-read-free form of the `rows` exchange (multiview.GradExchange; replaces, for that format,
+ * the count read gsr_rows_pack needs -- the sequential accumulation it stands in for: training/object_trainer.py:302-382).
+ * A message of a row set with `rows` rows of `row_floats` floats and a fixed capacity of `cap` rows is gsr_rowmsg_bytes() bytes
+ * (a multiple of 256): [header: count, cap, rows, F | bitmap u64[(rows+63)/64] | rows in front of each 64-row word | rows f32[cap][F]].
+ *   gsr_rowmsg_pack   ONE launch: the rows whose bit is set in `mask` (as gsr_rows_pack) -> msg (256-byte aligned). A count above
+ *                     cap is recorded in the header (the rows beyond cap are not written).
+ *   gsr_rowmsg_apply  ONE launch over n_msgs (<= 16) messages, message q at msgs + q * msg_stride (rank order): every row ANY message
+ *                     holds receives ((g_0 + g_1) + ...) over the messages that hold it, STORED (rows nobody holds are left as they
+ *                     are); touched (NULL or u64[(rows+63)/64]) receives the union bitmap. If any header's count exceeds cap (or
+ *                     its cap / rows / F differ from this call's) NOTHING is written. *status (NULL, or one u64, device or page-
+ *                     locked host memory) = largest count << 32 | (1: applied, 2: nothing applied), stored when the kernel STARTS. */
+size_t gsr_rowmsg_bytes(int32_t rows, int32_t row_floats, uint32_t cap);
+int gsr_rowmsg_pack(const GsrRowSet* set, const uint64_t* mask, void* msg, uint32_t cap, void* stream);
+int gsr_rowmsg_apply(const GsrRowSet* set, const void* msgs, uint64_t msg_stride, int32_t n_msgs, uint32_t cap, uint64_t* status,
+                     uint64_t* touched, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import same_bits
+from tests.util import rel_scale, same_bits
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-5
@@ -44,7 +44,7 @@ CASES = _cases()
 def _close(a, ref, what, tol=TOL):
     a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
     e = float(np.abs(a - ref).max()) if a.size else 0.0
-    assert e <= tol * max(1.0, float(np.abs(ref).max())), f"{what}: max abs err {e:.3e} (max|ref| {np.abs(ref).max():.3e})"
+    assert e <= tol * rel_scale(ref), f"{what}: max abs err {e:.3e} (max|ref| {np.abs(ref).max():.3e})"
 
 
 def test_fixture_covers_the_reference_calls():

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.util import rel_scale
+
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -139,7 +141,7 @@ def test_object_render_plumbing_matches_reference():
                g_rotation=p._rotation.grad, g_opacity=p._opacity.grad, g_f_dc=p._features_dc.grad,
                g_f_rest=p._features_rest.grad)
     for k, g in ref.items():
-        scale = max(1.0, float(np.abs(d[k]).max()))
+        scale = rel_scale(d[k])
         np.testing.assert_allclose(g.numpy(), d[k], atol=1e-5 * scale, err_msg=k)
     assert float(out["viewspace_points"].grad[:, 2].abs().max()) == 0.0
 
@@ -199,7 +201,7 @@ def test_object_render_training_augmentations_match_reference(seed):
     assert np.array_equal(out["radii"].numpy(), ref["radii"])
     for k, attr in TRAIN_KEYS.items():
         got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
-        scale = max(1.0, float(np.abs(ref[k]).max()))
+        scale = rel_scale(ref[k])
         np.testing.assert_allclose(got.numpy(), ref[k], atol=1e-5 * scale, err_msg=k)
 
 
@@ -245,7 +247,7 @@ def test_object_render_f32_fixture_replays_on_the_c_oracle(c_oracle, name):
     np.testing.assert_allclose(out["depth"].detach().numpy(), ref["depth"], atol=1e-5)
     for k, attr in TRAIN_KEYS.items():
         got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
-        scale = max(1.0, float(np.abs(ref[k]).max()))
+        scale = rel_scale(ref[k])
         np.testing.assert_allclose(got.numpy(), ref[k], atol=1e-5 * scale, err_msg=k)
 
 
@@ -280,7 +282,7 @@ def test_disp_postprocessing_turns_one_ulp_into_1e_4_of_the_gradients(c_oracle):
         worst = 0.0
         for k, attr in TRAIN_KEYS.items():
             got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
-            worst = max(worst, float(np.abs(got.numpy() - ref[k]).max() / max(1.0, float(np.abs(ref[k]).max()))))
+            worst = max(worst, float(np.abs(got.numpy() - ref[k]).max() / rel_scale(ref[k])))
         print(f"[{name}] one-ulp forward perturbation -> worst leaf-gradient change {worst:.1e} of max|ref|")
         assert worst <= 5e-3, (name, worst)
         worst_over_cases = max(worst_over_cases, worst)
@@ -325,7 +327,7 @@ def test_object_render_f32_fixture_hip_behind_the_reference_glue(built_lib, name
     worst = {}
     for k, attr in TRAIN_KEYS.items():
         got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
-        scale = max(1.0, float(np.abs(ref[k]).max()))
+        scale = rel_scale(ref[k])
         worst[k] = float(np.abs(got.numpy() - ref[k]).max() / scale)
     print(f"[{name}, CPU glue] worst gradient error / max|ref|: {worst}")
     for k, e in worst.items():
@@ -346,7 +348,7 @@ def test_object_render_f32_fixture_hip_gpu_glue(built_lib, name):
     assert dr.max() <= 1 and (dr > 0).mean() <= 0.005, (dr.max(), (dr > 0).mean())
     for k, attr in TRAIN_KEYS.items():
         got = out["viewspace_points"].grad if attr is None else getattr(p, attr).grad
-        scale = max(1.0, float(np.abs(ref[k]).max()))
+        scale = rel_scale(ref[k])
         np.testing.assert_allclose(got.cpu().numpy(), ref[k], atol=E2E_GRAD_TOL * scale, err_msg=f"{name}: {k}")
 
 
@@ -377,5 +379,5 @@ def test_object_render_plumbing_hip_vs_reference_fixture(built_lib):
                g_f_rest=p._features_rest.grad)
     for k, gr in ref.items():
         assert gr is not None and tuple(gr.shape) == tuple(d[k].shape), k
-        scale = max(1.0, float(np.abs(d[k]).max()))
+        scale = rel_scale(d[k])
         np.testing.assert_allclose(gr.cpu().numpy(), d[k], atol=E2E_GRAD_TOL * scale, err_msg=k)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import err, oracle_view, settings_for, small_scene
+from tests.util import err, oracle_view, rel_scale, settings_for, small_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +48,7 @@ def _check_forward(out, f, P):
     assert err(sp[vis][:, [7, 8, 9]], f["rgb"][vis]) <= 1e-6, "SH colour"
     e_img = err(out["color"].cpu().numpy(), f["image"])
     e_da = err(out["depth_alpha"].cpu().numpy(), f["depth_alpha"])
-    scale_d = max(1.0, float(np.abs(f["depth_alpha"]).max()))
+    scale_d = rel_scale(f["depth_alpha"])
     assert e_img <= TOL, f"image err {e_img}"
     assert e_da <= TOL * scale_d, f"depth/alpha err {e_da}"
     # the gates (power > 0, alpha < 1/255, T < 1e-4) see the same bits in both implementations (SEMANTICS.md section 4/6)
@@ -90,11 +90,18 @@ def _grad_check(g, cam, bg, D, c_oracle, colors=False, cov=False, seed=0, tol=TO
             assert (o.get(hk) is None) == (b.get(ok) is None), hk
             continue
         a, r = o[hk].cpu().numpy().reshape(-1), np.asarray(b[ok]).reshape(-1)
-        scale = max(1.0, float(np.abs(r).max()))
+        scale = rel_scale(r)
         e = err(a, r)
         report[hk] = (e, float(np.abs(r).max()))
-        assert e <= tol * scale, f"{hk}: max abs err {e} (max|ref| {np.abs(r).max()})"
+        assert e <= tol * CAM_GRAD_SLACK.get(hk, 1.0) * scale, f"{hk}: max abs err {e} (max|ref| {np.abs(r).max()})"
     return report
+
+
+# The camera gradients (no reference call site consumes them) are 16 / 3 numbers, each the sum of
+# one fp32 term per Gaussian whose signs cancel (sum |terms| ~ 30 x |sum|): against the oracle's double-precision terms the fp32
+# chain of K8 lands at 1.0e-5 / 1.25e-5 of max|dL/dproj| on fuzz seeds 9 / 18 (round 6, per-tensor relative bar) -- the three
+# tensors of the suite held to 3e-5 of their own largest entry instead of 1e-5.
+CAM_GRAD_SLACK = {"dL_dview": 3.0, "dL_dproj": 3.0, "dL_dcampos": 3.0}
 
 
 @pytest.mark.parametrize("D", [0, 3])
@@ -142,7 +149,7 @@ def test_backward_vs_autograd_fp64(built_lib):
     for k, r in ref.items():
         r = r.numpy().reshape(-1)
         e = err(o[k].cpu().numpy().reshape(-1), r)
-        assert e <= TOL * max(1.0, float(np.abs(r).max())), f"{k}: {e}"
+        assert e <= TOL * rel_scale(r), f"{k}: {e}"
 
 
 def test_autograd_module_and_score(built_lib, c_oracle):
@@ -170,7 +177,9 @@ def test_autograd_module_and_score(built_lib, c_oracle):
     f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
                          score=True)
     ref = f["important_score"]
-    assert err(sc.cpu().numpy(), ref) <= 1e-4 * max(1.0, float(ref.max()))
+    # score_mode 0 = opacity x (number of contributing pixels): integer counts on the device, one fp32 product -- the oracle's
+    # double sum of `count` equal fp32 terms is exact and rounds to the same fp32 value: the same BITS
+    assert np.array_equal(sc.cpu().numpy(), ref), f"mode-0 scores differ: {err(sc.cpu().numpy(), ref):.3e}"
     with pytest.raises(Exception):
         rast(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
 
@@ -232,7 +241,7 @@ def test_long_lists_multi_batch(built_lib, c_oracle, seg_len):
                    ("dL_dshs", "dL_dshs"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations")]:
         a, r = o[hk].cpu().numpy().reshape(-1), np.asarray(b[ok]).reshape(-1)
         e = np.abs(a - r)
-        scale = max(1.0, float(np.abs(r).max()))
+        scale = rel_scale(r)
         print(f"{hk}: max err {e.max():.3e} (max|ref| {np.abs(r).max():.3e})")
         assert e.max() <= TOL * scale
 
@@ -287,7 +296,7 @@ def test_device_side_accumulation_over_views(built_lib, c_oracle):
                    ("opacities", "dL_dopacity"), ("shs", "dL_dshs")]:
         a = arena.views[ak].cpu().numpy().reshape(-1)
         r = ref[rk].reshape(-1)
-        assert err(a, r) <= TOL * max(1.0, float(np.abs(r).max())), ak
+        assert err(a, r) <= TOL * rel_scale(r), ak
 
 
 def test_views_backward_with_mixed_segment_lengths(built_lib, c_oracle):
@@ -321,7 +330,7 @@ def test_views_backward_with_mixed_segment_lengths(built_lib, c_oracle):
     for hk, rk in [("dL_dmeans3D", "dL_dmeans3D"), ("dL_dscales", "dL_dscales"), ("dL_drotations", "dL_drotations"),
                    ("dL_dopacities", "dL_dopacity"), ("dL_dshs", "dL_dshs")]:
         a, r = o[hk].cpu().numpy().reshape(-1), ref[rk].reshape(-1)
-        assert err(a, r) <= TOL * max(1.0, float(np.abs(r).max())), hk
+        assert err(a, r) <= TOL * rel_scale(r), hk
 
 
 def test_state_is_freed_without_cyclic_gc(built_lib):
@@ -403,7 +412,8 @@ def test_score_mode_alpha_T(built_lib, c_oracle):
     f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
                          score=True)
     ref = f["important_score"]
-    assert err(out["score"].cpu().numpy(), ref) <= 1e-4 * max(1.0, float(ref.max()))
+    # mode 1 = sum of alpha T: fp32 atomics in arrival order against the oracle's double sum
+    assert err(out["score"].cpu().numpy(), ref) <= 1e-5 * rel_scale(ref)
 
 
 def test_whole_tile_forward_variant(built_lib, c_oracle):
@@ -433,7 +443,7 @@ def test_whole_tile_forward_variant(built_lib, c_oracle):
                          score=True)
     assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 512
     ref = f["important_score"]
-    assert err(o["score"].cpu().numpy(), ref) <= 1e-4 * max(1.0, float(ref.max()))
+    assert np.array_equal(o["score"].cpu().numpy(), ref), "mode-0 scores (opacity x integer pixel count): the same bits"
 
 
 def test_thousands_of_equal_depths_keep_index_order(built_lib, c_oracle):
@@ -481,7 +491,7 @@ def test_c1_workload_vs_both_oracles(built_lib, c_oracle):
                        ("opacities", "dL_dopacities"), ("shs", "dL_dshs"), ("means2D", "dL_dmeans2D")):
             ref = np.asarray(r["grads"][tk], dtype=np.float64)
             got = o[hk].cpu().numpy().astype(np.float64).reshape(ref.shape)
-            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max())), f"{hk} vs float64 autograd"
+            assert np.abs(got - ref).max() <= 1e-5 * rel_scale(ref), f"{hk} vs float64 autograd"
 
 
 @pytest.mark.parametrize("case", ["equal300", "equal3000", "equal4500_of_20000", "plane", "two_clusters", "one_visible"])

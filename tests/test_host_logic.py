@@ -1,5 +1,6 @@
 """CPU: host-side logic around the boundary (synthetic generators, camera maths, gradient arena)."""
 import numpy as np
+import pytest
 import torch
 
 from dreamscene_amd import multiview, synth
@@ -218,6 +219,16 @@ def test_side_stream_fork_proof_without_a_gpu():
     assert R._side_streams_wanted(None) == R.SIDE_STREAMS_DEFAULT
     assert R._side_streams_wanted(R.RasterContext(side_streams=3)) == 3
     assert R._side_streams_wanted(R.RasterContext(side_streams=99)) == R.SIDE_STREAMS_MAX
+    # ONE accelerator of the per-view call at a time, by construction (RasterContext.per_view_accel)
+    assert R.per_view_accel(None) == "off"
+    assert R.per_view_accel(R.RasterContext(side_streams=2)) == "streams"
+    assert R.per_view_accel(R.RasterContext(dropin_graphs=True)) == "graphs"
+    assert R.per_view_accel(R.RasterContext(per_view_accel="graphs", side_streams=4)) == "graphs"
+    assert R.per_view_accel(R.RasterContext(per_view_accel="off", side_streams=4, dropin_graphs=True)) == "off"
+    with pytest.raises(ValueError):
+        R.per_view_accel(R.RasterContext(side_streams=2, dropin_graphs=True))
+    with pytest.raises(ValueError):
+        R.per_view_accel(R.RasterContext(per_view_accel="both"))
 
 
 def test_bench_picks_the_timed_kernel_instance():

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import err, oracle_view, small_scene
+from tests.util import err, oracle_view, rel_scale, small_scene
 
 
 def _torch_run(g, cam, bg, D, dt=torch.float64, score=False, score_mode=0, cam_grad=True, gi=None, gda=None, tile_window=None):
@@ -63,7 +63,7 @@ def test_forward_backward_c_vs_torch(c_oracle, D, K, seed):
              ("proj", "dL_dproj"), ("campos", "dL_dcampos")]
     for tk, ck in pairs:
         a, c = r["grads"][tk], b[ck]
-        assert err(a, c) <= 1e-5 * max(1.0, float(np.abs(a).max())), tk
+        assert err(a, c) <= 1e-5 * rel_scale(a), tk
 
 
 def test_needles_vs_float64(c_oracle):
@@ -91,7 +91,11 @@ def test_needles_vs_float64(c_oracle):
                    ("opacities", "dL_dopacity"), ("shs", "dL_dshs"), ("means2D", "dL_dmeans2D")):
         a = r["grads"][tk]
         c = np.asarray(b[ck]).reshape(a.shape)
-        assert err(a, c) <= 2e-6 * max(1.0, float(np.abs(a).max())), tk
+        print(f"[needles, fp32 C oracle vs float64 autograd] {tk}: {err(a, c) / rel_scale(a):.2e} of max|ref| = {rel_scale(a):.2e}")
+        # 1000 : 1 needles: the fp32 forward chain (covariance -> conic, shared operation by operation with the device) carries
+        # cond(Sigma)^2 x eps into the rotation / scale gradients; against float64 this fp32 restatement itself sits at 2.1e-5 of
+        # max|dL/drotations| (3.3e-2) here -- the one tensor of the suite whose bar is stated above 1e-5 of its own scale
+        assert err(a, c) <= (4e-5 if tk == "rotations" else 1e-5) * rel_scale(a), tk
 
 
 def test_colors_precomp_and_cov3d_precomp(c_oracle):
@@ -111,7 +115,7 @@ def test_colors_precomp_and_cov3d_precomp(c_oracle):
     for tk, ck in [("means3D", "dL_dmeans3D"), ("cov3D_precomp", "dL_dcov3D"), ("colors_precomp", "dL_dcolors"),
                    ("opacities", "dL_dopacity")]:
         a, c = r["grads"][tk], b[ck]
-        assert err(a, c) <= 1e-5 * max(1.0, float(np.abs(a).max())), tk
+        assert err(a, c) <= 1e-5 * rel_scale(a), tk
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -122,7 +126,7 @@ def test_importance_score(c_oracle, mode):
     v = oracle_view(c_oracle, cam, 400, 16, 1, bg, score_mode=mode)
     f = c_oracle.forward(v, g["means3D"], g["opacities"], shs=g["shs"], scales=g["scales"], rotations=g["rotations"],
                          score=True)
-    assert err(f["important_score"], r["score"]) <= 1e-3 * max(1.0, float(r["score"].max()))
+    assert err(f["important_score"], r["score"]) <= 1e-3 * rel_scale(r["score"])
     assert (f["important_score"][f["radii"] == 0] == 0).all()
 
 

@@ -8,7 +8,16 @@ import numpy as np
 import pytest
 import torch
 
+from tests.util import rel_scale
+
 from tests.test_golden import _cam_from_fixture, load
+
+# fp32 HIP path through the scene glue against the reference's scene_render captured in float64. Measured per tensor, relative to
+# its own largest entry (round 6): worst 4.1e-5 (model 2 _scaling), 1.9e-5 _xyz, 1.5e-5 _rotation, everything else below 1e-5 --
+# the disp post-processing of the glue (scene_gaussian.py:1023-1032) sits between the rasterizer and these gradients and
+# turns one ulp of the forward outputs into 2e-5 ... 1e-3 of them (tests/test_golden.py::
+# test_disp_postprocessing_turns_one_ulp_into_1e_4_of_the_gradients, CPU). Rounds 1-5 had 3e-3 of max(1, max|ref|) here.
+SCENE_GLUE_TOL = 1e-4
 
 LEAVES = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
 
@@ -41,11 +50,11 @@ def test_scene_oracle_glue_matches_reference_scene_render():
     np.testing.assert_allclose(out["scales"].detach().numpy(), d["scales_out"], rtol=1e-6)
     _loss(out, d).backward()
     np.testing.assert_allclose(out["viewspace_points"].grad.numpy(), d["vsp_grad"],
-                               atol=1e-5 * max(1.0, np.abs(d["vsp_grad"]).max()))
+                               atol=1e-5 * rel_scale(d["vsp_grad"]))
     for m, leaves in enumerate(models):
         for leaf, t in zip(LEAVES, leaves):
             ref = d[f"g{m}{leaf}"]
-            np.testing.assert_allclose(t.grad.numpy(), ref, atol=1e-5 * max(1.0, float(np.abs(ref).max())),
+            np.testing.assert_allclose(t.grad.numpy(), ref, atol=1e-5 * rel_scale(ref),
                                        err_msg=f"model {m} {leaf}")
 
 
@@ -61,18 +70,20 @@ def test_fused_scene_render_vs_reference_fixture(built_lib):
     assert sorted(out.keys()) == list(d["keys"])
     np.testing.assert_allclose(out["image"].detach().cpu().numpy(), d["image"], atol=1e-5)
     np.testing.assert_allclose(out["alpha"].detach().cpu().numpy(), d["alpha"], atol=1e-5)
+    print(f"[scene fixture] depth: {np.abs(out['depth'].detach().cpu().numpy() - d['depth']).max():.2e} abs, max|ref| {np.abs(d['depth']).max():.2e}")
     np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), d["depth"], atol=2e-4)
     np.testing.assert_allclose(out["scales"].detach().cpu().numpy(), d["scales_out"], rtol=4e-7)   # expf: <= 2 ulp
     assert np.mean(out["radii"].cpu().numpy() != d["radii"]) <= 2e-3      # 1-ulp scales may move a ceil()
     _loss(out, d, dev).backward()
     vg = out["viewspace_points"].grad.cpu().numpy()
-    np.testing.assert_allclose(vg, d["vsp_grad"], atol=3e-3 * max(1.0, np.abs(d["vsp_grad"]).max()))
+    print(f"[scene fixture] viewspace_points.grad: {np.abs(vg - d['vsp_grad']).max() / rel_scale(d['vsp_grad']):.2e} of max|ref|")
+    np.testing.assert_allclose(vg, d["vsp_grad"], atol=SCENE_GLUE_TOL * rel_scale(d["vsp_grad"]))
     for m, leaves in enumerate(models):
         for leaf, t in zip(LEAVES, leaves):
             ref = d[f"g{m}{leaf}"]
-            # disp post-processing in fp32 vs the float64 capture: 1e-3 relative on the largest entries (as in the
-            # object_render plumbing test)
-            np.testing.assert_allclose(t.grad.cpu().numpy(), ref, atol=3e-3 * max(1.0, float(np.abs(ref).max())),
+            print(f"[scene fixture] model {m} {leaf}: {np.abs(t.grad.cpu().numpy() - ref).max() / rel_scale(ref):.2e} of max|ref| "
+                  f"= {rel_scale(ref):.2e}")
+            np.testing.assert_allclose(t.grad.cpu().numpy(), ref, atol=SCENE_GLUE_TOL * rel_scale(ref),
                                        err_msg=f"model {m} {leaf}")
 
 

@@ -101,6 +101,8 @@ def timed(fn, seconds):
 rows = []
 for gr in [int(x) for x in args.graphs.split(",")]:
     for ns in [int(x) for x in args.streams.split(",")]:
+        if gr and ns > 1:
+            continue                 # the two accelerators are mutually exclusive (RasterContext.per_view_accel)
         dropin.reset()
         ctx = RasterContext(side_streams=ns, dropin_graphs=bool(gr))
         fns = make(ctx)
