@@ -390,7 +390,8 @@ def main():
         rccl = measure_allreduce(arena, dev, backend, allreduce_scalars)
         if args.exchange == "measure":
             # gloo (functional tests on one device) stages device tensors through the host for dense / rows only
-            cands = ["dense", "direct"] if backend == "nccl" else ["dense", "rows"]
+            # (rows: the device form of round 6 -- self-describing messages, no host read: multiview._RowMessages)
+            cands = ["dense", "direct", "rows"] if backend == "nccl" else ["dense", "rows"]
             if args.exchange_candidates:
                 cands = [f for f in (x.strip() for x in args.exchange_candidates.split(",")) if f]
                 unknown = [f for f in cands if f not in ("dense", "direct", "rows", "sparse_rs")]
@@ -401,14 +402,20 @@ def main():
                 ok = 1.0
                 try:
                     exchange.mode = fmt
+                    exchange.strict = True        # (warm-up: a row message that does not fit is repeated with more room)
                     for _ in range(3):
                         step()
                     sync()
+                    exchange.strict = False       # timed: no host read at all; an overflow would show in overflowed_steps
+                    over0 = exchange.overflowed_steps
                     tp = time.perf_counter()
                     for _ in range(args.exchange_probe_steps):
                         step()
                     sync()
                     dt_f = (time.perf_counter() - tp) / args.exchange_probe_steps
+                    exchange.finish()
+                    if exchange.overflowed_steps != over0:
+                        raise RuntimeError(f"{exchange.overflowed_steps - over0} timed steps overflowed their row messages")
                 except Exception as e:          # a format that fails on this stack is dropped on EVERY rank
                     ok, dt_f = 0.0, float("inf")
                     print(f"bench.py rank {rank}: exchange format {fmt} failed: {e!r}", file=sys.stderr, flush=True)
@@ -418,9 +425,11 @@ def main():
                     {"failed": True}
             good = {f: v["ms_per_step"] for f, v in exchange_probe.items() if "ms_per_step" in v}
             exchange.mode = min(good, key=good.get) if good else "dense"
+            exchange.strict = True
             for _ in range(2):
                 step()
             sync()
+            exchange.strict = False               # (the timed region: checked behind it, `exchange.overflowed_steps` on the line)
     stage_ms = {}
     dominant = None
     if prof is not None:
@@ -777,7 +786,9 @@ def main():
         skip_reduce[0] = False
         torch.cuda.synchronize(dev)
         nz = int(exchange.nonzero_rows().numel())
+        exchange.finish()
         exch = {"row_floats": exchange.row_floats, "dense_bytes": int(4 * exchange.row_floats * P),
+                "overflowed_steps": exchange.overflowed_steps,
                 "nonzero_row_frac": round(nz / max(P, 1), 4), "format": exchange.mode, "last": exchange.last or None,
                 "probe_ms_per_step": exchange_probe}
 

@@ -138,6 +138,12 @@ SYMBOLS = [
     ("gsr_rowmsg_pack", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     ("gsr_rowmsg_apply", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    ("gsr_rowmsg_pack_slices", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32,
+                                         C.c_void_p]),
+    ("gsr_rowmsg_reduce", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p,
+                                    C.c_uint32, C.c_void_p]),
+    ("gsr_rowmsg_apply_slices", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p,
+                                          C.c_void_p]),
     ("gsr_knn_scratch_bytes", C.c_size_t, [C.c_int32]),
     ("gsr_knn_mean_dist2", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("gsr_backward", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom), C.POINTER(GsrBinning),

@@ -148,7 +148,7 @@ k_rows_unpack(const Regions r, const uint32_t* __restrict__ idx, const float* __
 // write touches the arena. A message that does not fit its capacity says so in its header: the apply kernel then changes nothing
 // and reports the largest count (the caller repeats the step with more room -- the arena still holds its own gradients).
 constexpr uint32_t kMsgHdrBytes = 256;
-constexpr int kMsgWordsPerBlock = 16;       // k_msg_pack: 4 waves x 4 words of 64 rows
+constexpr int kMsgWordsPerBlock = 4;        // k_msg_pack: one word of 64 rows per wave
 
 struct MsgLayout { size_t bitmap, offs, rows, total; };
 __host__ __device__ inline MsgLayout msg_layout(int32_t n_rows, int32_t F, uint32_t cap) {
@@ -167,122 +167,342 @@ __device__ __forceinline__ unsigned long long msg_word(const unsigned long long*
   return m;
 }
 
-// Workgroup b packs words [16 b, 16 b + 16): it counts the set bits in FRONT of its range itself (a strided pass over at most
-// n_words words of the L2-resident bitmap: 62 KB at 500 k rows -- no scan launch, no look-back chain), then every wave copies the
-// rows of its four words. The last workgroup knows the total and writes the header.
+// Lane -> (row slot, element) of a wave-wide copy of rows of F floats: F <= 64: 64 / F rows per instruction, lane = slot * F + f
+// (the element a lane handles never changes, so the region it lives in -- base pointer, stride -- is selected ONCE per wave: the
+// second build of these kernels re-selected it per element from the by-value region table and spent its time on the scalar
+// reloads of that table, 55 / 106 us for pack / apply at C3); F > 64: one row per instruction, elements in chunks of 64.
+struct LaneMap {
+  int slots;       // rows per wave instruction
+  int slot, f;     // this lane's row slot and element (chunk 0)
+  bool active;
+};
+__device__ __forceinline__ LaneMap lane_map(int F, int lane, uint32_t f_magic) {
+  LaneMap lm;
+  if (F <= 64) {
+    lm.slots = 64 / F;
+    lm.slot = f_magic ? (int)__umulhi((uint32_t)lane, f_magic) : lane;
+    lm.f = lane - lm.slot * F;
+    lm.active = lm.slot < lm.slots;
+  } else {
+    lm.slots = 1; lm.slot = 0; lm.f = lane; lm.active = true;
+  }
+  return lm;
+}
+struct ElemRef { float* base; int stride; };       // element f of row i = base[i * stride]
+__device__ __forceinline__ ElemRef elem_ref(const Regions& r, int f) {
+  float* p = r.ptr[0];
+  int st = r.stride[0], f0 = 0;
+#pragma unroll
+  for (int j = 1; j < GSR_ROWSET_MAX_REGIONS; ++j) {
+    const bool in = (j < r.n) && (f >= r.first[j]);
+    p = in ? r.ptr[j] : p;
+    st = in ? r.stride[j] : st;
+    f0 = in ? r.first[j] : f0;
+  }
+  ElemRef e;
+  e.base = p + (f - f0);
+  e.stride = st;
+  return e;
+}
+
+// SLICES (the sparse reduce-scatter): a row set of `rows` rows cut into slices of slice_rows rows (a multiple of 64), slice y =
+// rows [y slice_rows, min(rows, (y + 1) slice_rows)); message y describes slice y with slice-local row numbers. slice_rows = 0:
+// one message for the whole set.
+__host__ __device__ inline int32_t slice_len(int32_t rows, int32_t slice_rows, int y) {
+  if (slice_rows <= 0) return rows;
+  const int64_t left = (int64_t)rows - (int64_t)y * slice_rows;
+  return left <= 0 ? 0 : (left < slice_rows ? (int32_t)left : slice_rows);
+}
+
+// Workgroup b packs words [4 b, 4 b + 4) of slice blockIdx.y, one word of 64 rows per wave: it counts the set bits in FRONT of its
+// range itself (a strided pass over at most n_words words of the L2-resident bitmap: 62 KB at 500 k rows -- no scan launch, no
+// look-back chain), then every wave copies the rows of its word, four row-instructions in flight. The last workgroup writes the header.
 __global__ void __launch_bounds__(256)
-k_msg_pack(const Regions r, const unsigned long long* __restrict__ mask, const int32_t n_words, unsigned char* __restrict__ msg,
-           const MsgLayout lay, const uint32_t cap) {
+k_msg_pack(const Regions r, const unsigned long long* __restrict__ mask, unsigned char* __restrict__ msg, const size_t msg_stride,
+           const int32_t slice_rows, const MsgLayout lay, const uint32_t cap, const uint32_t f_magic) {
   __shared__ uint32_t red[4];
-  __shared__ uint32_t wpre[kMsgWordsPerBlock + 1];
   __shared__ uint8_t bitpos[4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int first = (int)blockIdx.x * kMsgWordsPerBlock;
+  const int y = (int)blockIdx.y;
+  const int64_t row0 = (int64_t)y * (slice_rows > 0 ? slice_rows : 0);
+  const int32_t rows_here = slice_len(r.rows, slice_rows, y);
+  const int32_t n_words = (rows_here + 63) / 64;
+  mask += row0 >> 6;
+  msg += (size_t)y * msg_stride;
+  const int first = min((int)blockIdx.x * kMsgWordsPerBlock, n_words);
   uint32_t c = 0;
   for (int w = tid; w < first; w += 256) c += (uint32_t)__popcll(mask[w]);     // (the masked last word is never in front of a range)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
   if (lane == 0) red[wave] = c;
-  if (tid < kMsgWordsPerBlock) {
-    const int w = first + tid;
-    wpre[tid + 1] = w < n_words ? (uint32_t)__popcll(msg_word(mask, w, n_words, r.rows)) : 0u;
-  }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t run = (red[0] + red[1]) + (red[2] + red[3]);
-    wpre[0] = run;
-    for (int k = 1; k <= kMsgWordsPerBlock; ++k) { const uint32_t x = wpre[k]; wpre[k] = run; run += x; }
-    // (now wpre[j + 1] = rows in front of word first + j, and `run` = rows up to the end of this range)
-    if (blockIdx.x == gridDim.x - 1) {
-      uint32_t* hdr = reinterpret_cast<uint32_t*>(msg);
-      hdr[0] = run; hdr[1] = cap; hdr[2] = (uint32_t)r.rows; hdr[3] = (uint32_t)r.F;
-    }
+  uint32_t o0 = (red[0] + red[1]) + (red[2] + red[3]);
+  uint32_t range_total = 0;
+  unsigned long long m = 0ull;
+#pragma unroll
+  for (int j = 0; j < kMsgWordsPerBlock; ++j) {
+    const int wj = first + j;
+    const unsigned long long mj = wj < n_words ? msg_word(mask, wj, n_words, rows_here) : 0ull;
+    const uint32_t pj = (uint32_t)__popcll(mj);
+    if (j < wave) o0 += pj;
+    if (j == wave) m = mj;
+    range_total += pj;
   }
-  __syncthreads();
-  unsigned long long* bm = reinterpret_cast<unsigned long long*>(msg + lay.bitmap);
-  uint32_t* offs = reinterpret_cast<uint32_t*>(msg + lay.offs);
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(msg);
+    hdr[0] = (red[0] + red[1]) + (red[2] + red[3]) + range_total; hdr[1] = cap; hdr[2] = (uint32_t)rows_here; hdr[3] = (uint32_t)r.F;
+    hdr[4] = 0u;
+  }
+  const int w = first + wave;
+  if ((int)blockIdx.x * kMsgWordsPerBlock + wave >= n_words) return;
+  if (lane == 0) {
+    reinterpret_cast<unsigned long long*>(msg + lay.bitmap)[w] = m;
+    reinterpret_cast<uint32_t*>(msg + lay.offs)[w] = o0;
+  }
+  if (m == 0ull) return;
   float* out = reinterpret_cast<float*>(msg + lay.rows);
   uint8_t* mybits = bitpos[wave];
-  for (int k = 0; k < 4; ++k) {
-    const int j = wave * 4 + k, w = first + j;
-    if (w >= n_words) break;
-    const unsigned long long m = msg_word(mask, w, n_words, r.rows);
-    const uint32_t o0 = wpre[j + 1];          // after the scan above wpre[j + 1] = rows in front of word first + j
-    if (lane == 0) { bm[w] = m; offs[w] = o0; }
-    if (m == 0ull) continue;
-    if ((m >> lane) & 1ull) mybits[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int nset = (int)__popcll(m), total = nset * r.F;
-    for (int e = lane; e < total; e += 64) {
-      const int q = e / r.F, f = e - q * r.F;
-      const uint32_t pos = o0 + (uint32_t)q;
-      if (pos < cap) out[(size_t)pos * r.F + f] = *row_elem(r, (int64_t)w * 64 + mybits[q], f);
+  if ((m >> lane) & 1ull) mybits[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int nset = (int)__popcll(m), F = r.F;
+  const LaneMap lm = lane_map(F, lane, f_magic);
+  for (int f0 = 0; f0 < F; f0 += 64) {            // (one trip unless F > 64)
+    const int f = lm.f + f0;
+    const ElemRef src = elem_ref(r, f < F ? f : 0);
+    const bool lane_on = lm.active && f < F;
+    for (int k0 = 0; k0 < nset; k0 += 4 * lm.slots) {
+      float v[4];
+      bool on[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * lm.slots + lm.slot;
+        on[u] = lane_on && k < nset && o0 + (uint32_t)k < cap;
+        v[u] = on[u] ? src.base[(row0 + (int64_t)w * 64 + mybits[k < nset ? k : 0]) * (int64_t)src.stride] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * lm.slots + lm.slot;
+        if (on[u]) out[(size_t)(o0 + (uint32_t)k) * F + f] = v[u];
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
-// One wave per word of 64 rows: union of the W bitmaps; every row of the union = the ranks' rows added in rank order, stored.
-// *status (one u64, may be page-locked host memory) = largest count << 32 | 1 (applied) or 2 (some message overflowed its
-// capacity, or does not match this call's shape: NOTHING applied), stored by the first workgroup before any row is touched.
-template <int MAXW>
-__global__ void __launch_bounds__(256)
-k_msg_apply(const Regions r, const unsigned char* __restrict__ msgs, const size_t msg_stride, const int W, const int32_t n_words,
-            const MsgLayout lay, const uint32_t cap, unsigned long long* __restrict__ status,
-            unsigned long long* __restrict__ touched) {
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-  uint32_t worst = 0;
+// The status word an apply kernel leaves: bits 1:0 = 1 (applied) / 2 (nothing applied), bits 32:2 = the largest count among the
+// messages (clamped to 2^31 - 1: a poisoned owner message says 0xFFFFFFFF), bits 63:33 = the largest count their senders RECEIVED
+// (header word 4: owners' messages of the sparse reduce-scatter; 0 otherwise).
+__device__ __forceinline__ unsigned long long msg_status(bool bad, uint32_t worst, uint32_t worst_in) {
+  const unsigned long long a = worst > 0x7FFFFFFFu ? 0x7FFFFFFFull : (unsigned long long)worst;
+  const unsigned long long b = worst_in > 0x7FFFFFFFu ? 0x7FFFFFFFull : (unsigned long long)worst_in;
+  return (bad ? 2ull : 1ull) | (a << 2) | (b << 33);
+}
+
+// Header check of n messages (uniform): largest count, and whether every message fits `cap` and has this call's shape.
+// rows_of(q) = the number of rows message q must describe.
+template <int MAXW, typename RowsOf>
+__device__ __forceinline__ bool msg_headers_bad(const unsigned char* __restrict__ msgs, size_t msg_stride, int W, uint32_t cap, int F,
+                                                RowsOf rows_of, uint32_t& worst, uint32_t& worst_in) {
   bool bad = false;
+  worst = 0;
+  worst_in = 0;
 #pragma unroll
   for (int q = 0; q < MAXW; ++q) {
     if (q < W) {
       const uint32_t* hdr = reinterpret_cast<const uint32_t*>(msgs + (size_t)q * msg_stride);
-      const uint32_t n = hdr[0];
+      const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[0]);
       worst = n > worst ? n : worst;
-      bad = bad || n > cap || hdr[1] != cap || hdr[2] != (uint32_t)r.rows || hdr[3] != (uint32_t)r.F;
+      const uint32_t ni = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[4]);      // (an owner's message: the largest count it received)
+      worst_in = ni > worst_in ? ni : worst_in;
+      bad = bad || n > cap || hdr[1] != cap || hdr[2] != (uint32_t)rows_of(q) || hdr[3] != (uint32_t)F;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && status)
-    __hip_atomic_store(status, ((unsigned long long)worst << 32) | (bad ? 2ull : 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (bad || w >= n_words) return;
-  unsigned long long m[MAXW], U = 0ull;
-  uint32_t o[MAXW];
+  return bad;
+}
+
+// The merge of word w of W messages (all describing the same rows): for the k-th row of the union (bit b of the word), the
+// messages' rows added in RANK ORDER -> put(k, b, f, sum). The bitmap words and row offsets of the messages are wave-uniform
+// (scalar registers); lane b holds, for row b of the word, its position in every message (offset + set bits below b) and the mask
+// of the messages that hold it; a lane working on row b fetches both with ds_bpermute. kTrip row-instructions per trip of the row
+// loop: their loads (up to MAXW each) are all issued before the first add -- a word holds ~13 rows of the union at C3: four per
+// trip = 4 dependent memory round trips per wave instead of 7. (Second build, two per trip: 106 us at C3; the same kernel without
+// its row loads 59, without its stores 82 -- a chain of round trips, not bytes: gpurun_out/r6h.)
+// Returns the union word (0: nothing to do).
+template <int MAXW, typename Put>
+__device__ __forceinline__ unsigned long long
+msg_merge_word(const unsigned char* __restrict__ msgs, const size_t msg_stride, const int W, const int w, const MsgLayout lay,
+               const int F, const uint32_t f_magic, uint8_t* ubits, Put put) {
+#ifdef GSR_MSG_TRIP
+  constexpr int kTrip = GSR_MSG_TRIP;
+#else
+  constexpr int kTrip = MAXW <= 8 ? 4 : 2;
+#endif
+  const int lane = threadIdx.x & 63;
+  unsigned long long U = 0ull;
+  uint32_t posl[MAXW];         // lane b: position of row b of the word in message q (meaningful where the message holds the row)
+  uint32_t hasl = 0;           // lane b: bit q set = message q holds row b
+  const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int q = 0; q < MAXW; ++q) {
-    m[q] = 0ull; o[q] = 0u;
+    posl[q] = 0u;
     if (q < W) {
       const unsigned char* base = msgs + (size_t)q * msg_stride;
-      m[q] = reinterpret_cast<const unsigned long long*>(base + lay.bitmap)[w];
-      o[q] = reinterpret_cast<const uint32_t*>(base + lay.offs)[w];
-      U |= m[q];
+      const unsigned long long mv = reinterpret_cast<const unsigned long long*>(base + lay.bitmap)[w];
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mv);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mv >> 32));
+      const unsigned long long mq = ((unsigned long long)hi << 32) | lo;
+      const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(base + lay.offs)[w]);
+      posl[q] = o + (uint32_t)__popcll(mq & below);
+      hasl |= (uint32_t)((mq >> lane) & 1ull) << q;
+      U |= mq;
     }
   }
-  if (touched && lane == 0) touched[w] = U;
-  while (U) {
-    const int b = __builtin_ctzll(U);
-    U &= U - 1ull;
-    const unsigned long long below = (1ull << b) - 1ull;
-    for (int f = lane; f < r.F; f += 64) {
-      float v[MAXW];
+  if (U == 0ull) return 0ull;
+  if ((U >> lane) & 1ull) ubits[__popcll(U & below)] = (uint8_t)lane;      // k -> bit index of the k-th row of the union
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int nrow = (int)__popcll(U);
+  const LaneMap lm = lane_map(F, lane, f_magic);
+  for (int f0 = 0; f0 < F; f0 += 64) {            // (one trip unless F > 64)
+    const int f = lm.f + f0;
+    const bool lane_on = lm.active && f < F;
+    for (int k0 = 0; k0 < nrow; k0 += kTrip * lm.slots) {
+      float v[kTrip][MAXW];
+      uint32_t has[kTrip];
+      int b[kTrip], kk[kTrip];
 #pragma unroll
-      for (int q = 0; q < MAXW; ++q) {          // all the loads of the row first (independent), then the adds in rank order
-        v[q] = 0.f;
-        if (q < W && ((m[q] >> b) & 1ull)) {
-          const float* rows = reinterpret_cast<const float*>(msgs + (size_t)q * msg_stride + lay.rows);
-          v[q] = rows[(size_t)(o[q] + (uint32_t)__popcll(m[q] & below)) * r.F + f];
+      for (int t = 0; t < kTrip; ++t) {
+        kk[t] = k0 + t * lm.slots + lm.slot;
+        const bool on = lane_on && kk[t] < nrow;
+        b[t] = ubits[kk[t] < nrow ? kk[t] : 0];
+        has[t] = (uint32_t)__shfl((int)hasl, b[t], 64);
+        if (!on) has[t] = 0u;
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q) {
+          v[t][q] = 0.f;
+          if (q < W) {
+            const uint32_t pos = (uint32_t)__shfl((int)posl[q], b[t], 64);
+            if ((has[t] >> q) & 1u)
+              v[t][q] = (reinterpret_cast<const float*>(msgs + (size_t)q * msg_stride + lay.rows))[(size_t)pos * F + f];
+          }
         }
       }
-      float acc = 0.f;
-      bool any = false;
 #pragma unroll
-      for (int q = 0; q < MAXW; ++q) {
-        if (q < W && ((m[q] >> b) & 1ull)) { acc = any ? __fadd_rn(acc, v[q]) : v[q]; any = true; }
+      for (int t = 0; t < kTrip; ++t) {
+        if (has[t] == 0u) continue;
+        float acc = 0.f;
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q)
+          if (q < W && ((has[t] >> q) & 1u)) { acc = any ? __fadd_rn(acc, v[t][q]) : v[t][q]; any = true; }
+        put(kk[t], b[t], f, acc);
       }
-      *row_elem(r, (int64_t)w * 64 + b, f) = acc;
     }
+  }
+  return U;
+}
+
+// Messages -> row set. One wave per word of 64 rows.
+//   slice_rows = 0: the W messages all describe the whole set; every row any of them holds receives the ranks' contributions
+//                   added in rank order, STORED (rows nobody holds are left as they are).
+//   slice_rows > 0: message y describes slice y (blockIdx.y): its rows are stored into the set's rows [y slice_rows, ...) -- the
+//                   last step of the sparse reduce-scatter (the owners' reduced slices, disjoint).
+// *status (one u64, may be page-locked host memory; msg_status above): applied, or NOTHING applied because some message overflowed
+// its capacity / does not match this call's shape; stored by the first workgroup before any row is touched.
+template <int MAXW>
+__global__ void __launch_bounds__(256)
+k_msg_apply(const Regions r, const unsigned char* __restrict__ msgs, const size_t msg_stride, const int W, const int32_t slice_rows,
+            const MsgLayout lay, const uint32_t cap, unsigned long long* __restrict__ status,
+            unsigned long long* __restrict__ touched, const uint32_t f_magic) {
+  __shared__ uint8_t ubits_s[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+  const int y = (int)blockIdx.y;
+  uint32_t worst, worst_in;
+  const int32_t total_rows = r.rows;
+  const bool bad = msg_headers_bad<MAXW>(msgs, msg_stride, W, cap, r.F,
+                                          [=](int q) { return slice_len(total_rows, slice_rows, q); }, worst, worst_in);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && status)
+    __hip_atomic_store(status, msg_status(bad, worst, worst_in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int32_t rows_here = slice_len(r.rows, slice_rows, y);
+  if (bad || w >= (rows_here + 63) / 64) return;
+  const int64_t row0 = (int64_t)y * (slice_rows > 0 ? slice_rows : 0);
+  // (the element a lane stores never changes: its region is selected once -- lane_map / elem_ref)
+  const LaneMap lm = lane_map(r.F, lane, f_magic);
+  const ElemRef d0 = elem_ref(r, lm.f < r.F ? lm.f : 0);
+  const Regions& rr = r;
+  auto put = [&](int k, int b, int f, float v) {
+    (void)k;
+    const ElemRef d = (f == lm.f) ? d0 : elem_ref(rr, f);            // (f != lm.f only for F > 64)
+    d.base[(row0 + (int64_t)w * 64 + b) * (int64_t)d.stride] = v;
+  };
+  const unsigned char* data = slice_rows > 0 ? msgs + (size_t)y * msg_stride : msgs;
+  const unsigned long long U = msg_merge_word<MAXW>(data, msg_stride, slice_rows > 0 ? 1 : W, w, lay, r.F, f_magic, ubits_s[wave], put);
+  if (touched && U && lane == 0) touched[(row0 >> 6) + w] = U;
+}
+
+// Messages -> message: the OWNER side of the sparse reduce-scatter. The W messages describe the same slice (one from every rank);
+// the output describes the union of their rows, every row = the ranks' contributions added in rank order. The output's count may
+// exceed cap_out (recorded in its header, the rows beyond are not written); if an INPUT does not fit / match, the output's count is
+// 0xFFFFFFFF: whoever applies it applies nothing (gsr_rowmsg_apply_slices), i.e. the arena of no rank is touched.
+template <int MAXW>
+__global__ void __launch_bounds__(256)
+k_msg_reduce(const unsigned char* __restrict__ msgs, const size_t msg_stride, const int W, const int32_t rows, const int F,
+             const MsgLayout lay_in, const uint32_t cap_in, unsigned char* __restrict__ out, const MsgLayout lay_out,
+             const uint32_t cap_out, const uint32_t f_magic) {
+  __shared__ uint8_t ubits_s[4][64];
+  __shared__ uint32_t red[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int32_t n_words = (rows + 63) / 64;
+  uint32_t worst, worst_in;
+  const bool bad = msg_headers_bad<MAXW>(msgs, msg_stride, W, cap_in, F, [=](int) { return rows; }, worst, worst_in);
+  uint32_t* hdr = reinterpret_cast<uint32_t*>(out);
+  if (bad) {
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+      hdr[0] = 0xFFFFFFFFu; hdr[1] = cap_out; hdr[2] = (uint32_t)rows; hdr[3] = (uint32_t)F; hdr[4] = worst;
+    }
+    return;
+  }
+  // rows of the union in front of this workgroup's words
+  const int first = min((int)blockIdx.x * kMsgWordsPerBlock, n_words);
+  auto union_word = [&](int wq) {
+    unsigned long long u = 0ull;
+#pragma unroll
+    for (int q = 0; q < MAXW; ++q)
+      if (q < W) u |= reinterpret_cast<const unsigned long long*>(msgs + (size_t)q * msg_stride + lay_in.bitmap)[wq];
+    return u;
+  };
+  uint32_t c = 0;
+  for (int wq = tid; wq < first; wq += 256) c += (uint32_t)__popcll(union_word(wq));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+  if (lane == 0) red[wave] = c;
+  __syncthreads();
+  uint32_t o0 = (red[0] + red[1]) + (red[2] + red[3]);
+  uint32_t range_total = 0;
+#pragma unroll
+  for (int j = 0; j < kMsgWordsPerBlock; ++j) {
+    const int wj = first + j;
+    const uint32_t pj = wj < n_words ? (uint32_t)__popcll(union_word(wj)) : 0u;
+    if (j < wave) o0 += pj;
+    range_total += pj;
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+    hdr[0] = (red[0] + red[1]) + (red[2] + red[3]) + range_total; hdr[1] = cap_out; hdr[2] = (uint32_t)rows; hdr[3] = (uint32_t)F;
+    hdr[4] = worst;                    // the largest count this owner received: the capacity policy of the first phase needs it
+  }
+  const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kMsgWordsPerBlock + wave);
+  if (w >= n_words) return;
+  float* orow = reinterpret_cast<float*>(out + lay_out.rows);
+  auto put = [&](int k, int b, int f, float v) {
+    (void)b;
+    const uint32_t pos = o0 + (uint32_t)k;
+    if (pos < cap_out) orow[(size_t)pos * F + f] = v;
+  };
+  const unsigned long long U = msg_merge_word<MAXW>(msgs, msg_stride, W, w, lay_in, F, f_magic, ubits_s[wave], put);
+  if (lane == 0) {
+    reinterpret_cast<unsigned long long*>(out + lay_out.bitmap)[w] = U;
+    reinterpret_cast<uint32_t*>(out + lay_out.offs)[w] = o0;
   }
 }
 
@@ -380,42 +600,96 @@ size_t gsr_rowmsg_bytes(int32_t rows, int32_t row_floats, uint32_t cap) {
   return msg_layout(rows, row_floats > 0 ? row_floats : 1, cap).total;
 }
 
-int gsr_rowmsg_pack(const GsrRowSet* rs, const uint64_t* mask, void* msg, uint32_t cap, void* stream_) {
+static uint32_t f_magic_of(int F) { return (uint32_t)(0xFFFFFFFFu / (uint32_t)F + 1u); }   // floor(x / F) = umulhi(x, magic); 0 for F = 1
+
+static int rowmsg_pack(const GsrRowSet* rs, const uint64_t* mask, void* msgs, uint64_t msg_stride, int32_t n_slices,
+                       int32_t slice_rows, uint32_t cap, void* stream_) {
   Regions r;
   const int rc = make_regions(rs, r);
   if (rc) return rc;
-  if (!mask || !msg || (reinterpret_cast<uintptr_t>(mask) & 7u) || (reinterpret_cast<uintptr_t>(msg) & 255u)) return GSR_EINVAL;
+  if (!mask || !msgs || (reinterpret_cast<uintptr_t>(mask) & 7u) || (reinterpret_cast<uintptr_t>(msgs) & 255u)) return GSR_EINVAL;
+  if (slice_rows < 0 || (slice_rows & 63) || n_slices < 1 || (slice_rows == 0 && n_slices != 1) || (msg_stride & 255u)) return GSR_EINVAL;
+  if (slice_rows > 0 && (int64_t)n_slices * slice_rows < rs->rows) return GSR_EINVAL;
+  const int32_t per = slice_rows > 0 ? slice_rows : rs->rows;
+  const MsgLayout lay = msg_layout(per, r.F, cap);
+  if (n_slices > 1 && msg_stride < lay.total) return GSR_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
-  GsrDeviceGuard dev(msg);
-  const int32_t n_words = (rs->rows + 63) / 64;
-  const MsgLayout lay = msg_layout(rs->rows, r.F, cap);
+  GsrDeviceGuard dev(msgs);
+  const int32_t n_words = (per + 63) / 64;
   const uint32_t blocks = (uint32_t)((n_words + kMsgWordsPerBlock - 1) / kMsgWordsPerBlock);
-  hipLaunchKernelGGL(k_msg_pack, dim3(blocks ? blocks : 1u), dim3(256), 0, stream, r, reinterpret_cast<const unsigned long long*>(mask),
-                     n_words, reinterpret_cast<unsigned char*>(msg), lay, cap);
+  hipLaunchKernelGGL(k_msg_pack, dim3(blocks ? blocks : 1u, (uint32_t)n_slices), dim3(256), 0, stream, r,
+                     reinterpret_cast<const unsigned long long*>(mask), reinterpret_cast<unsigned char*>(msgs), (size_t)msg_stride,
+                     slice_rows, lay, cap, f_magic_of(r.F));
+  GSR_HIP(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_rowmsg_pack(const GsrRowSet* rs, const uint64_t* mask, void* msg, uint32_t cap, void* stream_) {
+  return rowmsg_pack(rs, mask, msg, 0, 1, 0, cap, stream_);
+}
+
+int gsr_rowmsg_pack_slices(const GsrRowSet* rs, const uint64_t* mask, void* msgs, uint64_t msg_stride, int32_t n_slices,
+                           int32_t slice_rows, uint32_t cap, void* stream_) {
+  if (slice_rows <= 0) return GSR_EINVAL;
+  return rowmsg_pack(rs, mask, msgs, msg_stride, n_slices, slice_rows, cap, stream_);
+}
+
+static int rowmsg_apply(const GsrRowSet* rs, const void* msgs, uint64_t msg_stride, int32_t n_msgs, int32_t slice_rows, uint32_t cap,
+                        uint64_t* status, uint64_t* touched, void* stream_) {
+  Regions r;
+  const int rc = make_regions(rs, r);
+  if (rc) return rc;
+  if (!msgs || n_msgs < 1 || n_msgs > 16 || (reinterpret_cast<uintptr_t>(msgs) & 255u) || (msg_stride & 255u)) return GSR_EINVAL;
+  if ((touched && (reinterpret_cast<uintptr_t>(touched) & 7u)) || (status && (reinterpret_cast<uintptr_t>(status) & 7u))) return GSR_EINVAL;
+  if (slice_rows < 0 || (slice_rows & 63) || (slice_rows > 0 && (int64_t)n_msgs * slice_rows < rs->rows)) return GSR_EINVAL;
+  const int32_t per = slice_rows > 0 ? slice_rows : rs->rows;
+  const MsgLayout lay = msg_layout(per, r.F, cap);
+  if (msg_stride < lay.total) return GSR_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  GsrDeviceGuard dev(msgs);
+  const int32_t n_words = (per + 63) / 64;
+  const dim3 grid((uint32_t)((n_words + 3) / 4 > 0 ? (n_words + 3) / 4 : 1), slice_rows > 0 ? (uint32_t)n_msgs : 1u);
+  const unsigned char* m = reinterpret_cast<const unsigned char*>(msgs);
+  if (n_msgs <= 8)
+    hipLaunchKernelGGL(k_msg_apply<8>, grid, dim3(256), 0, stream, r, m, (size_t)msg_stride, n_msgs, slice_rows, lay, cap,
+                       reinterpret_cast<unsigned long long*>(status), reinterpret_cast<unsigned long long*>(touched), f_magic_of(r.F));
+  else
+    hipLaunchKernelGGL(k_msg_apply<16>, grid, dim3(256), 0, stream, r, m, (size_t)msg_stride, n_msgs, slice_rows, lay, cap,
+                       reinterpret_cast<unsigned long long*>(status), reinterpret_cast<unsigned long long*>(touched), f_magic_of(r.F));
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }
 
 int gsr_rowmsg_apply(const GsrRowSet* rs, const void* msgs, uint64_t msg_stride, int32_t n_msgs, uint32_t cap, uint64_t* status,
                      uint64_t* touched, void* stream_) {
-  Regions r;
-  const int rc = make_regions(rs, r);
-  if (rc) return rc;
-  if (!msgs || n_msgs < 1 || n_msgs > 16 || (reinterpret_cast<uintptr_t>(msgs) & 255u) || (msg_stride & 255u)) return GSR_EINVAL;
-  if ((touched && (reinterpret_cast<uintptr_t>(touched) & 7u)) || (status && (reinterpret_cast<uintptr_t>(status) & 7u))) return GSR_EINVAL;
-  const MsgLayout lay = msg_layout(rs->rows, r.F, cap);
-  if (msg_stride < lay.total) return GSR_EINVAL;
+  return rowmsg_apply(rs, msgs, msg_stride, n_msgs, 0, cap, status, touched, stream_);
+}
+
+int gsr_rowmsg_apply_slices(const GsrRowSet* rs, const void* msgs, uint64_t msg_stride, int32_t n_slices, int32_t slice_rows,
+                            uint32_t cap, uint64_t* status, void* stream_) {
+  if (slice_rows <= 0) return GSR_EINVAL;
+  return rowmsg_apply(rs, msgs, msg_stride, n_slices, slice_rows, cap, status, nullptr, stream_);
+}
+
+int gsr_rowmsg_reduce(int32_t rows, int32_t layout_rows, int32_t row_floats, const void* msgs, uint64_t msg_stride, int32_t n_msgs,
+                      uint32_t cap_in, void* msg_out, uint32_t cap_out, void* stream_) {
+  if (rows < 0 || row_floats < 1 || row_floats > 1024 || !msgs || !msg_out || n_msgs < 1 || n_msgs > 16) return GSR_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(msgs) & 255u) || (reinterpret_cast<uintptr_t>(msg_out) & 255u) || (msg_stride & 255u)) return GSR_EINVAL;
+  if (layout_rows <= 0) layout_rows = rows;
+  if (layout_rows < rows) return GSR_EINVAL;
+  const MsgLayout lin = msg_layout(layout_rows, row_floats, cap_in), lout = msg_layout(layout_rows, row_floats, cap_out);
+  if (msg_stride < lin.total) return GSR_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   GsrDeviceGuard dev(msgs);
-  const int32_t n_words = (rs->rows + 63) / 64;
-  const dim3 grid((uint32_t)((n_words + 3) / 4 > 0 ? (n_words + 3) / 4 : 1));
+  const int32_t n_words = (rows + 63) / 64;
+  const dim3 grid((uint32_t)((n_words + kMsgWordsPerBlock - 1) / kMsgWordsPerBlock > 0 ? (n_words + kMsgWordsPerBlock - 1) / kMsgWordsPerBlock : 1));
   const unsigned char* m = reinterpret_cast<const unsigned char*>(msgs);
   if (n_msgs <= 8)
-    hipLaunchKernelGGL(k_msg_apply<8>, grid, dim3(256), 0, stream, r, m, (size_t)msg_stride, n_msgs, n_words, lay, cap,
-                       reinterpret_cast<unsigned long long*>(status), reinterpret_cast<unsigned long long*>(touched));
+    hipLaunchKernelGGL(k_msg_reduce<8>, grid, dim3(256), 0, stream, m, (size_t)msg_stride, n_msgs, rows, row_floats, lin, cap_in,
+                       reinterpret_cast<unsigned char*>(msg_out), lout, cap_out, f_magic_of(row_floats));
   else
-    hipLaunchKernelGGL(k_msg_apply<16>, grid, dim3(256), 0, stream, r, m, (size_t)msg_stride, n_msgs, n_words, lay, cap,
-                       reinterpret_cast<unsigned long long*>(status), reinterpret_cast<unsigned long long*>(touched));
+    hipLaunchKernelGGL(k_msg_reduce<16>, grid, dim3(256), 0, stream, m, (size_t)msg_stride, n_msgs, rows, row_floats, lin, cap_in,
+                       reinterpret_cast<unsigned char*>(msg_out), lout, cap_out, f_magic_of(row_floats));
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }

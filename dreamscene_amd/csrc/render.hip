@@ -145,8 +145,8 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t x, uint32_t* w
   return excl;
 }
 
-// Forward work list: tile ids ordered heaviest-first (33 buckets of floor(log2(len+1)), descending; the order
-// inside a bucket is arbitrary); zeroes tile_depth. Single workgroup.
+// Forward work list: tile ids ordered heaviest-first (length classes of floor(log2(len)) with GSR_ORDER_FRAC_BITS more bits,
+// descending; the order inside a class is arbitrary); zeroes tile_depth. Single workgroup.
 // Several views at once: workgroup blockIdx.x builds the list of view blockIdx.x (pointer tables in the kernel arguments).
 struct WorkFwdViews {
   const uint32_t* ranges[GSR_MAX_BATCH_VIEWS];
@@ -161,32 +161,47 @@ struct WorkBwdViews {
   uint32_t seg_len[GSR_MAX_BATCH_VIEWS];
 };
 
+// Length classes per octave of the forward work list = 2^GSR_ORDER_FRAC_BITS. Round 6, one call, two interleaved runs each: 1 / 4 /
+// 8 classes per octave: K6 44.6 / 44.3 / 44.2 us per view at C3 (value 5 059 / 5 088 / 4 994), 108.4 / 107.6 / 107.8 in the
+// opacity-0.1 state -- the heaviest-first order inside an octave is worth half a percent, finer than 4 nothing (gpurun_out/r6f).
+#ifndef GSR_ORDER_FRAC_BITS
+#define GSR_ORDER_FRAC_BITS 2
+#endif
+constexpr int kOrderFrac = GSR_ORDER_FRAC_BITS;
+constexpr int kOrderClasses = 2 + (32 << kOrderFrac);
+__device__ __forceinline__ uint32_t order_class(uint32_t len) {
+  if (len == 0u) return 0u;
+  const int msb = 31 - __clz(len);
+  if constexpr (kOrderFrac == 0) return (uint32_t)msb + 1u;
+  const uint32_t frac = (msb >= kOrderFrac ? (len >> (msb - kOrderFrac)) : (len << (kOrderFrac - msb))) & ((1u << kOrderFrac) - 1u);
+  return 1u + ((uint32_t)msb << kOrderFrac) + frac;
+}
 __global__ void __launch_bounds__(1024)
 k_work_order_fwd(const uint32_t n_tiles, const WorkFwdViews wv) {
   const uint32_t* __restrict__ ranges = wv.ranges[blockIdx.x];
   uint32_t* __restrict__ tile_depth = wv.tile_depth[blockIdx.x];
   uint32_t* __restrict__ work = wv.work[blockIdx.x];
   uint32_t* __restrict__ stats_host = wv.stats_host[blockIdx.x];
-  __shared__ uint32_t cnt[34], cur[34];
+  __shared__ uint32_t cnt[kOrderClasses], cur[kOrderClasses];
   const int tid = threadIdx.x;
-  if (tid < 34) cnt[tid] = 0;
+  if (tid < kOrderClasses) cnt[tid] = 0;
   __syncthreads();
   for (uint32_t t = tid; t < n_tiles; t += 1024) {
     const uint32_t len = ranges[2 * t + 1] - ranges[2 * t];
-    atomicAdd(&cnt[len ? 32 - __clz(len) : 0], 1u);
+    atomicAdd(&cnt[order_class(len)], 1u);
     tile_depth[t] = 0;
   }
   __syncthreads();
   if (tid == 0) {
     uint32_t run = 0;
-    for (int b = 33; b >= 0; --b) { cur[b] = run; run += cnt[b]; }
+    for (int b = kOrderClasses - 1; b >= 0; --b) { cur[b] = run; run += cnt[b]; }
     work[n_tiles] = n_tiles - cnt[0];          // number of non-empty tiles (a statistic for the host's mode choice)
     if (stats_host) *stats_host = n_tiles - cnt[0];   // page-locked host word, written straight from the kernel
   }
   __syncthreads();
   for (uint32_t t = tid; t < n_tiles; t += 1024) {
     const uint32_t len = ranges[2 * t + 1] - ranges[2 * t];
-    work[atomicAdd(&cur[len ? 32 - __clz(len) : 0], 1u)] = t;
+    work[atomicAdd(&cur[order_class(len)], 1u)] = t;
   }
 }
 

@@ -202,6 +202,7 @@ class _RowMessages:
         self.status = torch.zeros(1, dtype=torch.int64).pin_memory()
         self.status_np = self.status.numpy()
         self.armed = False
+        self.worst_in = 0
 
     def buffers(self, P: int, F: int, W: int, cap: int):
         key = (P, F, W, cap)
@@ -211,6 +212,37 @@ class _RowMessages:
             self.all = torch.empty(W * nbytes, dtype=torch.uint8, device=self.dev)
             self.key, self.nbytes = key, nbytes
         return self.msg, self.all, self.nbytes
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    # ---- the sparse reduce-scatter: slices of slice_rows rows, one owner each
+    def slice_buffers(self, P: int, F: int, W: int, slice_rows: int, cap1: int, cap2: int):
+        key = ("slices", P, F, W, slice_rows, cap1, cap2)
+        if key != self.key:
+            n1 = int(self.lib.gsr_rowmsg_bytes(slice_rows, F, cap1))
+            n2 = int(self.lib.gsr_rowmsg_bytes(slice_rows, F, cap2))
+            mk = lambda n: torch.empty(n, dtype=torch.uint8, device=self.dev)
+            self.send1, self.recv1, self.own2, self.all2 = mk(W * n1), mk(W * n1), mk(n2), mk(W * n2)
+            self.key, self.n1, self.n2 = key, n1, n2
+        return self.send1, self.recv1, self.own2, self.all2
+
+    def pack_slices(self, rs, mask: torch.Tensor, W: int, slice_rows: int, cap1: int) -> None:
+        with torch.cuda.device(self.dev):
+            self.L.check(self.lib.gsr_rowmsg_pack_slices(rs, mask.data_ptr(), self.send1.data_ptr(), self.n1, int(W), int(slice_rows),
+                                                         int(cap1), self._stream()), "gsr_rowmsg_pack_slices")
+
+    def reduce_owned(self, rows_here: int, slice_rows: int, F: int, W: int, cap1: int, cap2: int) -> None:
+        with torch.cuda.device(self.dev):
+            self.L.check(self.lib.gsr_rowmsg_reduce(int(rows_here), int(slice_rows), int(F), self.recv1.data_ptr(), self.n1, int(W),
+                                                    int(cap1), self.own2.data_ptr(), int(cap2), self._stream()), "gsr_rowmsg_reduce")
+
+    def apply_slices(self, rs, W: int, slice_rows: int, cap2: int) -> None:
+        self.status_np[0] = self.PENDING
+        self.armed = True
+        with torch.cuda.device(self.dev):
+            self.L.check(self.lib.gsr_rowmsg_apply_slices(rs, self.all2.data_ptr(), self.n2, int(W), int(slice_rows), int(cap2),
+                                                          self.status.data_ptr(), self._stream()), "gsr_rowmsg_apply_slices")
 
     def pack(self, rs, mask: torch.Tensor, cap: int) -> None:
         with torch.cuda.device(self.dev):
@@ -237,7 +269,8 @@ class _RowMessages:
                     torch.cuda.synchronize(self.dev)
         self.armed = False
         v = int(self.status_np[0])
-        return (v & 0xFFFFFFFF) == 1, (v >> 32) & 0xFFFFFFFF
+        self.worst_in = (v >> 33) & 0x7FFFFFFF           # (owners' messages: the largest count any owner received)
+        return (v & 3) == 1, (v >> 2) & 0x7FFFFFFF
 
 
 class ExchangeHandle:
@@ -307,6 +340,8 @@ class GradExchange:
         self.overflowed_steps = 0
         self._msgs = None             # _RowMessages (device form of "rows")
         self._rows_cap = 0            # speculated capacity of a row message (rows); the same on every rank
+        self._rs_caps = [0, 0]        # sparse_rs: capacity of a (rank -> owner) message, of an owner's reduced message
+        self._settle = None           # how the pending status word is to be read: "rows" / "sparse_rs"
         self._side = None             # the exchange's own stream (async_op)
         self.sh_degree = None
         self.set_sh_degree(sh_degree)
@@ -431,10 +466,65 @@ class GradExchange:
         if self._msgs is None or not self._msgs.armed:
             return True
         ok, worst = self._msgs.result()
-        self._grow_cap(worst)
+        if self._settle == "sparse_rs":
+            self._grow_rs_caps(self._msgs.worst_in, worst)
+        else:
+            self._grow_cap(worst)
         if not ok:
             self.overflowed_steps += 1
         return ok
+
+    def _grow_rs_caps(self, worst_in: int, worst_out: int) -> None:
+        per = self._slice_rows(dist.get_world_size(self.group))
+        lim = (per + 1023) // 1024 * 1024
+        for i, wv in enumerate((worst_in, worst_out)):
+            if wv >= 0x7FFFFFFF:          # (a poisoned owner message: its own count is unknown -- the first phase overflowed)
+                continue
+            want = (int(wv * 1.25) + 1535) // 512 * 512
+            if want > self._rs_caps[i]:
+                self._rs_caps[i] = min(want, lim)
+
+    def _slice_rows(self, W: int) -> int:
+        return ((self.arena.P + W - 1) // W + 63) // 64 * 64
+
+    def _reduce_sparse_rs_device(self, W: int) -> None:
+        """`sparse_rs` on the device, no host read: every rank packs W slice messages (ONE launch), ONE all-to-all with equal
+        splits hands owner o its slice from every rank, the owner reduces the W messages into the message of their union (ONE
+        launch), ONE all-gather moves the owners' messages and ONE launch stores them -- the arena is written by that last
+        launch only, and only if every message of both phases fitted."""
+        P, F = self.arena.P, self.row_floats
+        if self._msgs is None:
+            self._msgs = _RowMessages(self.arena.flat.device)
+        self._settle_rows()
+        per = self._slice_rows(W)
+        lim = (per + 1023) // 1024 * 1024
+        if self._rs_caps[0] == 0:
+            self._rs_caps = [min((max(per // 4, 512) + 511) // 512 * 512, lim), min((max(per // 2, 512) + 511) // 512 * 512, lim)]
+        rs = self._arena_rowset()
+        r = dist.get_rank(self.group)
+        rows_here = max(0, min(per, P - r * per))
+        tries = 0
+        while True:
+            cap1, cap2 = self._rs_caps
+            send1, recv1, own2, all2 = self._msgs.slice_buffers(P, F, W, per, cap1, cap2)
+            self._msgs.pack_slices(rs, self.arena.reached, W, per, cap1)
+            _all_to_all_single(recv1, send1, self.group)
+            self._msgs.reduce_owned(rows_here, per, F, W, cap1, cap2)
+            _all_gather_into(all2, own2, self.group)
+            self._msgs.apply_slices(rs, W, per, cap2)
+            self._settle = "sparse_rs"
+            self.last = dict(format="sparse_rs", device=True, row_floats=F, cap_rows=[cap1, cap2], host_reads=0,
+                             bytes_per_rank=int((W - 1) * (self._msgs.n1 + self._msgs.n2)))
+            if not self.strict:
+                return
+            ok, worst = self._msgs.result()
+            self.last.update(rows_max=[self._msgs.worst_in, worst], host_reads=1)
+            self._grow_rs_caps(self._msgs.worst_in, worst)
+            if ok:
+                return
+            tries += 1                              # nothing was applied: the arena still holds this rank's own gradients
+            if tries > 3:
+                raise RuntimeError(f"slice messages do not fit their capacities {self._rs_caps} after {tries} attempts")
 
     def _grow_cap(self, worst: int) -> None:
         want = (int(worst * 1.25) + 2047) // 1024 * 1024
@@ -457,6 +547,7 @@ class GradExchange:
             self._msgs.pack(rs, self.arena.reached, cap)
             _all_gather_into(allm, msg, self.group)
             self._msgs.apply(rs, W, cap)
+            self._settle = "rows"
             self.last = dict(format="rows", device=True, row_floats=F, cap_rows=cap, bytes_per_rank=int((W - 1) * nbytes),
                              host_reads=0)
             if not self.strict:
@@ -522,7 +613,10 @@ class GradExchange:
             self.last = dict(format="direct", row_floats=F, bytes_per_rank=int(2 * (W - 1) / W * 4 * n))
             return
         if mode == "sparse_rs":
-            self._reduce_sparse_rs(W)
+            if self._dev_rows is not None and getattr(self.arena, "reached_valid", False):
+                self._reduce_sparse_rs_device(W)
+            else:
+                self._reduce_sparse_rs(W)
             return
         nmax = max(counts)
         dev, dt = self.arena.flat.device, self.arena.flat.dtype

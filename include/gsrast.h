@@ -418,21 +418,36 @@ int gsr_rows_unpack(const GsrRowSet* set, const uint32_t* idx, const float* rows
  * ((s_0[i] + s_1[i]) + s_2[i]) + ... over n_slices slices of slice_floats floats, slice w at slices + w * stride_floats -- rank
  * order, the association every rank applies to the slice it owns. out may be slice 0 (in place). One launch. */
 int gsr_sum_slices(const float* slices, int32_t n_slices, uint64_t slice_floats, uint64_t stride_floats, float* out, void* stream);
-/* Self-describing row messages: the host-read-free form of the `rows` exchange (multiview.GradExchange; replaces, for that format,
- * the count read gsr_rows_pack needs -- the sequential accumulation it stands in for: training/object_trainer.py:302-382).
- * A message of a row set with `rows` rows of `row_floats` floats and a fixed capacity of `cap` rows is gsr_rowmsg_bytes() bytes
- * (a multiple of 256): [header: count, cap, rows, F | bitmap u64[(rows+63)/64] | rows in front of each 64-row word | rows f32[cap][F]].
- *   gsr_rowmsg_pack   ONE launch: the rows whose bit is set in `mask` (as gsr_rows_pack) -> msg (256-byte aligned). A count above
- *                     cap is recorded in the header (the rows beyond cap are not written).
- *   gsr_rowmsg_apply  ONE launch over n_msgs (<= 16) messages, message q at msgs + q * msg_stride (rank order): every row ANY message
- *                     holds receives ((g_0 + g_1) + ...) over the messages that hold it, STORED (rows nobody holds are left as they
- *                     are); touched (NULL or u64[(rows+63)/64]) receives the union bitmap. If any header's count exceeds cap (or
- *                     its cap / rows / F differ from this call's) NOTHING is written. *status (NULL, or one u64, device or page-
- *                     locked host memory) = largest count << 32 | (1: applied, 2: nothing applied), stored when the kernel STARTS. */
+/* Self-describing row messages: the host-read-free forms of the sparse exchanges (multiview.GradExchange `rows` / `sparse_rs`; they
+ * stand in for the count reads gsr_rows_pack needs -- the sequential accumulation all of it implements: training/object_trainer.py:
+ * 302-382). A message of `rows` rows of `row_floats` floats with a fixed capacity of `cap` rows is gsr_rowmsg_bytes() bytes (a multiple
+ * of 256): [header u32[64]: count, cap, rows, F, largest count its sender received | bitmap u64[(rows+63)/64] | rows in front of each
+ * 64-row word u32[...] | rows f32[cap][F]]. Messages are 256-byte aligned; message q of an array sits at msgs + q * msg_stride.
+ *   gsr_rowmsg_pack          ONE launch: the rows whose bit is set in `mask` (as gsr_rows_pack) -> msg. A count above cap is recorded
+ *                            in the header (the rows beyond cap are not written).
+ *   gsr_rowmsg_pack_slices   ONE launch: the set cut into n_slices slices of slice_rows rows (a multiple of 64; n_slices * slice_rows
+ *                            >= rows): message y = slice y with slice-local row numbers -- what a rank sends to owner y.
+ *   gsr_rowmsg_reduce        ONE launch, messages -> message: n_msgs (<= 16) messages describing the SAME rows (one per rank, rank
+ *                            order) -> the message of their union, every row = ((g_0 + g_1) + ...) over the messages that hold it. If
+ *                            an input does not fit cap_in (or has another shape) the output's count is 0xFFFFFFFF. layout_rows (0 =
+ *                            rows): the row count the messages' layout was sized for (slice_rows of a slice message; >= rows).
+ *   gsr_rowmsg_apply         ONE launch over n_msgs messages of the whole set (rank order): every row ANY message holds receives the
+ *                            rank-ordered sum over the messages that hold it, STORED (rows nobody holds are left as they are); touched
+ *                            (NULL or u64[(rows+63)/64]) receives the union bitmap.
+ *   gsr_rowmsg_apply_slices  ONE launch: message y (an owner's reduced slice) stored into rows [y * slice_rows, ...) of the set.
+ * Both apply forms write NOTHING if any header's count exceeds cap (or its cap / rows / F differ from the call's). *status (NULL, or
+ * one u64, device or page-locked host memory), stored when the kernel STARTS: bits 1:0 = 1 applied / 2 nothing applied, bits 32:2 the
+ * largest count among the messages, bits 63:33 the largest count their senders received (owners' messages; 0 otherwise). */
 size_t gsr_rowmsg_bytes(int32_t rows, int32_t row_floats, uint32_t cap);
 int gsr_rowmsg_pack(const GsrRowSet* set, const uint64_t* mask, void* msg, uint32_t cap, void* stream);
+int gsr_rowmsg_pack_slices(const GsrRowSet* set, const uint64_t* mask, void* msgs, uint64_t msg_stride, int32_t n_slices,
+                           int32_t slice_rows, uint32_t cap, void* stream);
+int gsr_rowmsg_reduce(int32_t rows, int32_t layout_rows, int32_t row_floats, const void* msgs, uint64_t msg_stride, int32_t n_msgs,
+                      uint32_t cap_in, void* msg_out, uint32_t cap_out, void* stream);
 int gsr_rowmsg_apply(const GsrRowSet* set, const void* msgs, uint64_t msg_stride, int32_t n_msgs, uint32_t cap, uint64_t* status,
                      uint64_t* touched, void* stream);
+int gsr_rowmsg_apply_slices(const GsrRowSet* set, const void* msgs, uint64_t msg_stride, int32_t n_slices, int32_t slice_rows,
+                            uint32_t cap, uint64_t* status, void* stream);
 
 #ifdef __cplusplus
 }

@@ -122,3 +122,132 @@ def test_slice_sum_of_the_direct_format_equals_the_rank_order_adds(built_lib, W,
         for r in range(1, W):
             want2.add_(off.view(W, per2)[r])
         assert torch.equal(multiview._sum_slices(off, W, per2), want2)
+
+
+@pytest.mark.parametrize("P,K,D,W,frac", [(1000, 16, 3, 3, 0.2), (64 * 37 + 5, 16, 1, 8, 0.4), (4099, 4, 1, 2, 0.03),
+                                          (513, 16, 0, 5, 1.0), (300, 9, 2, 4, 0.0), (200_000, 16, 3, 8, 0.16)])
+def test_row_messages_give_the_rank_ordered_sum(built_lib, P, K, D, W, frac):
+    """gsr_rowmsg_pack / gsr_rowmsg_apply (the host-read-free `rows` exchange): W ranks' arenas packed into self-describing
+    messages, applied in ONE launch -> every row of the union holds ((g_0 + g_1) + ...) over the ranks that sent it, the same
+    bits the rank-by-rank torch adds give (what the sequential accumulation of training/object_trainer.py:302-382 becomes across
+    ranks); rows nobody sent stay zero; a message that does not fit leaves the arena untouched and says so."""
+    from dreamscene_amd import multiview
+    arenas = [_arena(P, K, 100 + r, frac) for r in range(W)]
+    ex = [multiview.GradExchange(a, sh_degree=D, mode="rows") for a, _ in arenas]
+    nb = (D + 1) ** 2
+    # reference: zero, then the ranks' rows added in rank order (torch index arithmetic, what the `rows` format always did)
+    ref = multiview.GradArena(P, K, torch.device(DEV))
+    ex_ref = multiview.GradExchange(ref, sh_degree=D, mode="rows")
+    ex_ref._dev_rows = None
+    for r in range(W):
+        ex[r]._dev_rows, held = None, ex[r]._dev_rows
+        idx = ex[r].nonzero_rows()
+        if idx.numel():
+            ex_ref._add_rows(idx, ex[r]._rows_of(idx))
+        ex[r]._dev_rows = held
+    counts = [int(rows.sum()) for _, rows in arenas]
+    cap = (max(counts) + 1023) // 1024 * 1024 + 1024
+    msgs = multiview._RowMessages(torch.device(DEV))
+    F = ex[0].row_floats
+    msg, allm, nbytes = msgs.buffers(P, F, W, cap)
+    for r in range(W):
+        msgs.pack(ex[r]._arena_rowset(), arenas[r][0].reached, cap)
+        allm[r * nbytes:(r + 1) * nbytes].copy_(msg)
+        hdr = msg[:16].view(torch.int32).cpu().tolist()
+        assert hdr == [counts[r], cap, P, F], (hdr, counts[r])
+    for r in (0, W - 1):                       # every rank ends with the same bits
+        a = arenas[r][0]
+        own = a.flat.clone()
+        msgs.apply(ex[r]._arena_rowset(), W, cap)
+        ok, worst = msgs.result()
+        assert ok and worst == max(counts)
+        for name in ("means3D", "scales", "rotations", "opacities"):
+            assert torch.equal(a.views[name], ref.views[name]), f"rank {r}: {name}"
+        assert torch.equal(a.views["shs"][:, :nb, :], ref.views["shs"][:, :nb, :]), f"rank {r}: active SH columns"
+        if nb < K:                             # SH columns beyond the active degree are never touched
+            assert torch.equal(a.views["shs"][:, nb:, :], own[ex[r]._offset_of_shs():].view(P, K, 3)[:, nb:, :])
+        a.flat.copy_(own)
+    # capacity too small: the header says so, nothing is applied
+    if max(counts) > 1024:
+        small = 1024
+        msg, allm, nbytes = msgs.buffers(P, F, W, small)
+        for r in range(W):
+            msgs.pack(ex[r]._arena_rowset(), arenas[r][0].reached, small)
+            allm[r * nbytes:(r + 1) * nbytes].copy_(msg)
+        a = arenas[0][0]
+        own = a.flat.clone()
+        msgs.apply(ex[0]._arena_rowset(), W, small)
+        ok, worst = msgs.result()
+        assert not ok and worst == max(counts)
+        torch.cuda.synchronize()
+        assert torch.equal(a.flat, own)
+
+
+@pytest.mark.parametrize("P,K,D,W,frac", [(1000, 16, 3, 3, 0.3), (64 * 37 + 5, 16, 1, 8, 0.4), (4099, 4, 1, 2, 0.05),
+                                          (513, 16, 0, 5, 1.0), (300, 9, 2, 4, 0.0), (200_000, 16, 3, 8, 0.16)])
+def test_slice_messages_give_the_sparse_reduce_scatter(built_lib, P, K, D, W, frac):
+    """The device form of `sparse_rs`, all W ranks emulated on one GPU: gsr_rowmsg_pack_slices (rank -> owner messages), the
+    all-to-all as copies, gsr_rowmsg_reduce at every owner, the all-gather as copies, gsr_rowmsg_apply_slices on every rank -> the
+    same bits as the rank-ordered torch adds of the `rows` format (training/object_trainer.py:302-382 across ranks); capacities
+    too small in either phase: the status says so (which phase, how many rows) and no arena is touched."""
+    from dreamscene_amd import multiview
+    arenas = [_arena(P, K, 300 + r, frac) for r in range(W)]
+    ex = [multiview.GradExchange(a, sh_degree=D, mode="sparse_rs") for a, _ in arenas]
+    nb, F = (D + 1) ** 2, ex[0].row_floats
+    ref = multiview.GradArena(P, K, torch.device(DEV))
+    ex_ref = multiview.GradExchange(ref, sh_degree=D, mode="rows")
+    ex_ref._dev_rows = None
+    for r in range(W):
+        ex[r]._dev_rows, held = None, ex[r]._dev_rows
+        idx = ex[r].nonzero_rows()
+        if idx.numel():
+            ex_ref._add_rows(idx, ex[r]._rows_of(idx))
+        ex[r]._dev_rows = held
+    per = ex[0]._slice_rows(W)
+    masks = [rows for _, rows in arenas]
+    c1 = max([int(m[o * per:(o + 1) * per].sum()) for m in masks for o in range(W)] + [0])
+    union = torch.stack(masks).any(0)
+    c2 = max([int(union[o * per:(o + 1) * per].sum()) for o in range(W)] + [0])
+
+    def run(cap1, cap2):
+        ms = [multiview._RowMessages(torch.device(DEV)) for _ in range(W)]
+        for r in range(W):
+            ms[r].slice_buffers(P, F, W, per, cap1, cap2)
+            ms[r].pack_slices(ex[r]._arena_rowset(), arenas[r][0].reached, W, per, cap1)
+        n1, n2 = ms[0].n1, ms[0].n2
+        for o in range(W):                      # all-to-all: owner o receives slice o of every rank, in rank order
+            for r in range(W):
+                ms[o].recv1[r * n1:(r + 1) * n1].copy_(ms[r].send1[o * n1:(o + 1) * n1])
+        for o in range(W):
+            ms[o].reduce_owned(max(0, min(per, P - o * per)), per, F, W, cap1, cap2)
+        for r in range(W):                      # all-gather
+            for o in range(W):
+                ms[r].all2[o * n2:(o + 1) * n2].copy_(ms[o].own2)
+        res = []
+        for r in range(W):
+            ms[r].apply_slices(ex[r]._arena_rowset(), W, per, cap2)
+            ok, worst = ms[r].result()
+            res.append((ok, worst, ms[r].worst_in))
+        torch.cuda.synchronize()
+        return res
+
+    own = [a.flat.clone() for a, _ in arenas]
+    big1, big2 = (c1 + 511) // 512 * 512 + 512, (c2 + 511) // 512 * 512 + 512
+    res = run(big1, big2)
+    assert all(ok for ok, _, _ in res) and {w for _, w, _ in res} == {c2} and {wi for _, _, wi in res} == {c1}, (res, c1, c2)
+    for r in range(W):
+        a = arenas[r][0]
+        for name in ("means3D", "scales", "rotations", "opacities"):
+            assert torch.equal(a.views[name], ref.views[name]), f"rank {r}: {name}"
+        assert torch.equal(a.views["shs"][:, :nb, :], ref.views["shs"][:, :nb, :]), f"rank {r}: active SH columns"
+        if nb < K:
+            assert torch.equal(a.views["shs"][:, nb:, :], own[r][ex[r]._offset_of_shs():].view(P, K, 3)[:, nb:, :])
+        a.flat.copy_(own[r])
+    if c1 > 512:                                 # first phase too small: every owner poisons its message, nobody applies
+        res = run(512, big2)
+        assert not any(ok for ok, _, _ in res) and all(wi == c1 for _, _, wi in res), res
+        assert all(torch.equal(arenas[r][0].flat, own[r]) for r in range(W))
+    if c2 > 512:                                 # second phase too small
+        res = run(big1, 512)
+        assert not any(ok for ok, _, _ in res) and all(w == c2 and wi == c1 for _, w, wi in res), res
+        assert all(torch.equal(arenas[r][0].flat, own[r]) for r in range(W))

@@ -104,6 +104,99 @@ for deg in (3, 0):
                                  "sparse_rs": round(w_(km) + w_(ko) + zero_us + 2.0 * g_(ks), 1)}
     hip[f"D{deg}"] = h
 res_["hip_kernels"] = hip
+# ---- round 6: self-describing row messages (gsr_rowmsg_pack / gsr_rowmsg_apply): the `rows` format without a host read. The W
+# ranks are REAL here: rank r's arena is the sum of its own V views (cameras r V .. r V + V - 1 of a 360-degree orbit), so the union
+# of the ranks' rows -- what the apply kernel writes -- is what an 8-GPU step would see.
+rm = {}
+reached0 = arena.reached.clone()
+orbit = synth.object_cameras(W * V, res, res)
+for deg in (3, 0):
+    ex = multiview.GradExchange(arena, sh_degree=deg, mode="rows", strict=False)
+    F = ex.row_floats
+    msgs = multiview._RowMessages(dev)
+    cap = (max(P // 4, 1024) + 1023) // 1024 * 1024
+    msg, allm, nbytes = msgs.buffers(P, F, W, cap)
+    counts = []
+    # (and the slice messages of the sparse reduce-scatter, capacities as the policy would set them for these counts)
+    per = ex._slice_rows(W)
+    cap1 = (int(0.2 * per * 1.25) + 1535) // 512 * 512
+    cap2 = (int(0.3 * per * 1.25) + 1535) // 512 * 512
+    sl_msgs = multiview._RowMessages(dev)
+    sl_msgs.slice_buffers(P, F, W, per, cap1, cap2)
+    sends = []
+    for r in range(W):
+        sl_r = [GaussianRasterizationSettings(image_height=res, image_width=res, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=t([1, 1, 1]),
+                                              scale_modifier=1.0, viewmatrix=t(c.world_view_transform),
+                                              projmatrix=t(c.full_proj_transform), sh_degree=D, campos=t(c.camera_center),
+                                              prefiltered=False, score_flag=False) for c in orbit[r * V:(r + 1) * V]]
+        rast_r = GaussianRasterizerViews(sl_r, context=RasterContext(grad_arena=arena))
+        for _ in range(2):
+            m2d = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+            outs = rast_r(means3D=params["means3D"], means2D=m2d, opacities=params["opacities"], shs=params["shs"],
+                          scales=params["scales"], rotations=params["rotations"])
+            torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], [m2d], [gi, gda] * V)
+        torch.cuda.synchronize()
+        msgs.pack(ex._arena_rowset(), arena.reached, cap)
+        allm[r * nbytes:(r + 1) * nbytes].copy_(msg)
+        counts.append(int(msg[:4].view(torch.int32).item()))
+        sl_msgs.pack_slices(ex._arena_rowset(), arena.reached, W, per, cap1)
+        sends.append(sl_msgs.send1.clone())
+    own = arena.flat.clone()                       # (the last rank's arena: the one the timed calls run on)
+
+    def restore_own():
+        arena.flat.copy_(own)
+    h = {"row_floats": F, "cap_rows": cap, "rows_per_rank": counts, "message_bytes": nbytes}
+    rs_ = ex._arena_rowset()
+
+    def timed_own(fn):
+        gpu = []
+        for _ in range(args.reps + 2):
+            torch.cuda.synchronize()
+            # (no synchronisation between the restore and the timed call: the 118 MB copy keeps the GPU busy while the host enqueues
+            #  the call, so the events bracket the kernel and not the host's launch path -- the first numbers of this section did
+            #  include it: ~30-60 us of Python + ctypes per call on an idle GPU)
+            restore_own(); restore_own()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            gpu.append(e0.elapsed_time(e1) * 1e3)
+        gpu = sorted(gpu[2:])
+        return round(gpu[len(gpu) // 2], 1)
+    h["pack_us (one launch)"] = timed_own(lambda: msgs.pack(rs_, arena.reached, cap))
+    h["apply_us (one launch, W messages, rank-ordered sums stored)"] = timed_own(lambda: msgs.apply(rs_, W, cap))
+    ok, worst = msgs.result()
+    h["applied"], h["rows_max"] = bool(ok), int(worst)
+    union = torch.zeros_like(arena.reached)
+    lay_bitmap = 256
+    for r in range(W):
+        union |= allm[r * nbytes + lay_bitmap:r * nbytes + lay_bitmap + arena.reached.numel() * 8].view(torch.int64)
+    sh = torch.arange(64, device=dev, dtype=torch.int64)
+    h["union_rows"] = int((((union.unsqueeze(1) >> sh) & 1).reshape(-1)[:P]).sum())
+    h["device_side_total_us"] = round(h["pack_us (one launch)"] + h["apply_us (one launch, W messages, rank-ordered sums stored)"], 1)
+    h["host_reads"] = 0
+    # sparse_rs on the device: the all-to-all and the all-gather emulated by copies; timed on the LAST rank (owner W - 1)
+    n1, n2 = sl_msgs.n1, sl_msgs.n2
+    own_counts = []
+    for o in range(W):
+        for r in range(W):
+            sl_msgs.recv1[r * n1:(r + 1) * n1].copy_(sends[r][o * n1:(o + 1) * n1])
+        sl_msgs.reduce_owned(max(0, min(per, P - o * per)), per, F, W, cap1, cap2)
+        sl_msgs.all2[o * n2:(o + 1) * n2].copy_(sl_msgs.own2)
+        own_counts.append(int(sl_msgs.own2[:4].view(torch.int32).item()))
+    s_ = {"slice_rows": per, "cap_rows": [cap1, cap2], "message_bytes": [n1, n2], "owner_union_rows": own_counts,
+          "wire_bytes_per_rank": int((W - 1) * (n1 + n2))}
+    s_["pack_slices_us"] = timed_own(lambda: sl_msgs.pack_slices(rs_, arena.reached, W, per, cap1))
+    s_["reduce_owned_us"] = timed_own(lambda: sl_msgs.reduce_owned(max(0, min(per, P - (W - 1) * per)), per, F, W, cap1, cap2))
+    s_["apply_slices_us"] = timed_own(lambda: sl_msgs.apply_slices(rs_, W, per, cap2))
+    ok2, worst2 = sl_msgs.result()
+    s_["applied"], s_["rows_max"] = bool(ok2), [int(sl_msgs.worst_in), int(worst2)]
+    s_["device_side_total_us"] = round(s_["pack_slices_us"] + s_["reduce_owned_us"] + s_["apply_slices_us"], 1)
+    h["sparse_rs_device"] = s_
+    rm[f"D{deg}"] = h
+res_["row_messages"] = rm
+arena.flat.copy_(snapshot)
+arena.reached.copy_(reached0)
+arena.reached_valid = True
 # ---- the torch index arithmetic they replace (the reference of tests/test_exchange_rows.py)
 for deg in (3, 2, 1, 0):
     ex = multiview.GradExchange(arena, sh_degree=deg, mode="dense")

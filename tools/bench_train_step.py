@@ -16,9 +16,11 @@ def main():
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--init-opacity", action="store_true")
+    ap.add_argument("--legs", default="as_imported,views_fused,raw_leaves")
     a = ap.parse_args()
     from tools import train_step as TS
-    res = TS.measure(a.gaussians, a.res, a.res, a.views, 16, 3, init_opacity=a.init_opacity, seconds=a.seconds)
+    res = TS.measure(a.gaussians, a.res, a.res, a.views, 16, 3, init_opacity=a.init_opacity, seconds=a.seconds,
+                     legs=tuple(a.legs.split(",")))
     res["workload"] = (f"{a.gaussians} Gaussians, K=16, {a.views} views @{a.res}x{a.res}"
                        f"{', every opacity 0.1' if a.init_opacity else ''}: tools/train_step.py")
     print(json.dumps(res))
