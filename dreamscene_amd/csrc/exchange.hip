@@ -278,7 +278,8 @@ k_msg_pack(const Regions r, const unsigned long long* __restrict__ mask, unsigne
       for (int u = 0; u < 4; ++u) {
         const int k = k0 + u * lm.slots + lm.slot;
         on[u] = lane_on && k < nset && o0 + (uint32_t)k < cap;
-        v[u] = on[u] ? src.base[(row0 + (int64_t)w * 64 + mybits[k < nset ? k : 0]) * (int64_t)src.stride] : 0.f;
+        // (branch-free: a lane without a row re-reads the word's first set row -- see msg_merge_word)
+        v[u] = src.base[(row0 + (int64_t)w * 64 + mybits[k < nset ? k : 0]) * (int64_t)src.stride];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -363,6 +364,10 @@ msg_merge_word(const unsigned char* __restrict__ msgs, const size_t msg_stride, 
   __builtin_amdgcn_wave_barrier();
   const int nrow = (int)__popcll(U);
   const LaneMap lm = lane_map(F, lane, f_magic);
+  const float* rowsq[MAXW];
+#pragma unroll
+  for (int q = 0; q < MAXW; ++q)
+    rowsq[q] = reinterpret_cast<const float*>(msgs + (size_t)(q < W ? q : 0) * msg_stride + lay.rows);
   for (int f0 = 0; f0 < F; f0 += 64) {            // (one trip unless F > 64)
     const int f = lm.f + f0;
     const bool lane_on = lm.active && f < F;
@@ -377,14 +382,17 @@ msg_merge_word(const unsigned char* __restrict__ msgs, const size_t msg_stride, 
         b[t] = ubits[kk[t] < nrow ? kk[t] : 0];
         has[t] = (uint32_t)__shfl((int)hasl, b[t], 64);
         if (!on) has[t] = 0u;
+        // BRANCH-FREE loads: a lane whose message does not hold the row (or a message slot >= W) reads element 0 of that
+        // message's rows and discards it. With the loads under `if (has >> q & 1)` every one of the up to kTrip x MAXW loads of a
+        // trip sat in its own control-flow region and was waited for before the next was issued: ~13 us per trip, 109 us for the
+        // kernel at C3 whatever the number of rows (gpurun_out/r6k) -- serialised round trips, not bytes.
 #pragma unroll
         for (int q = 0; q < MAXW; ++q) {
-          v[t][q] = 0.f;
-          if (q < W) {
-            const uint32_t pos = (uint32_t)__shfl((int)posl[q], b[t], 64);
-            if ((has[t] >> q) & 1u)
-              v[t][q] = (reinterpret_cast<const float*>(msgs + (size_t)q * msg_stride + lay.rows))[(size_t)pos * F + f];
-          }
+          const uint32_t pos = (uint32_t)__shfl((int)posl[q], b[t], 64);
+          const bool h = (has[t] >> q) & 1u;
+          const size_t at = h ? (size_t)pos * F + f : 0;
+          const float x = rowsq[q][at];
+          v[t][q] = h ? x : 0.f;
         }
       }
 #pragma unroll
