@@ -333,11 +333,7 @@ template <int MAXW, typename Put>
 __device__ __forceinline__ unsigned long long
 msg_merge_word(const unsigned char* __restrict__ msgs, const size_t msg_stride, const int W, const int w, const MsgLayout lay,
                const int F, const uint32_t f_magic, uint8_t* ubits, Put put) {
-#ifdef GSR_MSG_TRIP
-  constexpr int kTrip = GSR_MSG_TRIP;
-#else
   constexpr int kTrip = MAXW <= 8 ? 4 : 2;
-#endif
   const int lane = threadIdx.x & 63;
   unsigned long long U = 0ull;
   uint32_t posl[MAXW];         // lane b: position of row b of the word in message q (meaningful where the message holds the row)

@@ -715,7 +715,11 @@ __device__ __forceinline__ void k1_clear_sort_state(const K1Views& vb) {
 }
 
 template <int KT>
-// (4 waves per SIMD: 128 VGPRs instead of 131 at K = 16, no spills -- the kernel is latency-bound on its division chains)
+// (4 waves per SIMD: 128 VGPRs instead of 131 at K = 16, no spills -- the kernel is latency-bound on its division chains.
+//  Round 6 probe, one call: the SAME kernel without its colour -- no SH row loaded or held, ~60 VGPRs -- takes 11.7 us per view at 4
+//  AND at 6 waves per SIMD, 10.0 at 8, against 16.1-17.3 with the colour: the geometry alone is 40-47 us per 4-view step at 3.2 TB/s
+//  of its own traffic, whatever the occupancy; the colour adds ~20 us for 96 MB of SH rows, i.e. it already runs at a stream's
+//  rate. A geometry pass + a separate colour pass would cost 47 + >= 22 us: the split round 4's review asked for does not pay.)
 #ifndef GSR_K1_WAVES
 #define GSR_K1_WAVES 4
 #endif
