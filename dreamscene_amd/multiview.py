@@ -267,6 +267,9 @@ class _RowMessages:
                 torch.cuda.current_stream(self.dev).synchronize()
                 if int(self.status_np[0]) == self.PENDING:      # (another stream's apply: wait for the device)
                     torch.cuda.synchronize(self.dev)
+                if int(self.status_np[0]) == self.PENDING:
+                    self.armed = False
+                    raise RuntimeError("the apply kernel of a row-message exchange never stored its status (launch failed?)")
         self.armed = False
         v = int(self.status_np[0])
         self.worst_in = (v >> 33) & 0x7FFFFFFF           # (owners' messages: the largest count any owner received)
