@@ -298,7 +298,9 @@ class GradExchange:
         can differ from zero, not 11 + 3 K  (14 of 59 at D = 0, 23 at D = 1, 38 at D = 2);
       * rows of Gaussians no pixel composited are identically zero: culled ones (indoor scenes: 94 % of 2 M per view) and
         everything behind the opaque front layers of an object (early termination T < 1e-4).
-    Wire formats (`mode`, "auto" picks per step from the non-zero row fraction, one small host read):
+    Wire formats (`mode`; "auto" picks per step: on a cuda arena with K8's reached bitmap between the message form of `sparse_rs` and
+    `dense` from the capacities the message form has learnt -- no host read --, elsewhere from the non-zero row fraction, one small
+    host read):
       * "dense": all-reduce of [geometry 11 P | active SH columns 3 (D+1)^2 P] -- the arena itself when D is the stored
         degree (zero-copy), else a packed staging buffer (one strided copy each way);
       * "direct": the dense exchange spelled as the two one-hop steps a fully connected xGMI node allows: ONE all-to-all
@@ -573,7 +575,22 @@ class GradExchange:
         mode = self.mode
         idx = counts = None
         msg_rows = None
-        if mode == "rows" and self._dev_rows is not None and getattr(self.arena, "reached_valid", False):
+        on_device = self._dev_rows is not None and getattr(self.arena, "reached_valid", False)
+        if mode == "auto" and on_device:
+            # no count on the host: the sparse reduce-scatter in its message form unless the capacities it has learnt say that it
+            # would move more than half of what the dense ring moves (the same decision on every rank: the capacities are)
+            cap1, cap2 = self._rs_caps
+            sparse_bytes = (W - 1) * (cap1 + cap2) * 4 * F
+            dense_bytes = 2 * (W - 1) / W * 4 * F * P
+            if self.rows_below is not None and cap1:
+                mode = "sparse_rs" if cap1 * W <= 1.25 * self.rows_below * P + 2048 * W else "dense"
+            else:
+                mode = "sparse_rs" if (cap1 == 0 or sparse_bytes < 0.5 * dense_bytes) else "dense"
+            if mode == "dense" and cap1:
+                self._rs_probe = getattr(self, "_rs_probe", 0) + 1      # (look again every 64 steps: the row sets change slowly)
+                if self._rs_probe % 64 == 0:
+                    mode = "sparse_rs"
+        if mode == "rows" and on_device:
             self._reduce_rows_device(W)
             return
         if mode in ("auto", "rows"):      # ("sparse_rs" counts per owner itself)

@@ -95,7 +95,7 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["dense", "rows", "rows_lazy_async", "direct", "sparse_rs", "sparse_rs_lazy_async"])
+@pytest.mark.parametrize("mode", ["dense", "rows", "rows_lazy_async", "direct", "sparse_rs", "sparse_rs_lazy_async", "auto"])
 def test_two_ranks_share_the_gpu(built_lib, tmp_path, mode):
     """Every wire format of GradExchange with the arena ON THE DEVICE (round 5: `direct` and `sparse_rs` too -- their device
     halves, searchsorted / index_add_ / the strided packs on GPU tensors, ran on CPU tensors only until now; the collectives
@@ -119,7 +119,8 @@ def test_two_ranks_share_the_gpu(built_lib, tmp_path, mode):
     assert e <= 1e-5 * scale, f"exchanged sum differs from the single-process 4-view sum by {e:.3e} (scale {scale:.3e})"
     # per-view outputs do not depend on how the views are grouped into calls: rank 0's first view is view 0
     assert np.array_equal(r0["img0"], outs[0][0].detach().cpu().numpy()), "view 0 rendered differently in the sharded run"
-    assert json.loads(str(r0["last"]))["format"] == mode.replace("_lazy_async", "")
+    fmt = json.loads(str(r0["last"]))["format"]
+    assert fmt in ("sparse_rs", "dense") if mode == "auto" else fmt == mode.replace("_lazy_async", "")
 
 
 def test_bench_two_ranks_one_gpu(built_lib, tmp_path):
