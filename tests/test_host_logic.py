@@ -255,3 +255,42 @@ def test_bench_picks_the_timed_kernel_instance():
     one = bench.algorithmic_bytes("preprocess", P, N, HW, K, D, views=1)
     four = bench.algorithmic_bytes("preprocess", P, N, HW, K, D, views=4)
     assert four < 4 * one and four - one == 3 * P * 48
+
+
+def test_exchange_capacity_policy_is_a_function_of_what_every_rank_sees():
+    """GradExchange's speculated capacities (row messages, multiview._RowMessages) follow ONLY numbers every rank reads from the
+    same message headers -- the largest counts -- so that the fixed-size collectives stay equal-sized without a collective:
+    they grow to 1.25 x the largest count (rounded), never shrink, never exceed the row set; a poisoned owner message (first
+    phase of the sparse reduce-scatter overflowed: its own count unknown) moves only the first capacity."""
+    from dreamscene_amd import multiview
+    arena = multiview.GradArena(100_000, 16, torch.device("cpu"))
+    ex = multiview.GradExchange(arena, sh_degree=3, mode="rows")
+    assert ex._rows_cap == 0 and ex.strict and ex.overflowed_steps == 0
+    ex._grow_cap(10_000)
+    c1 = ex._rows_cap
+    assert c1 >= 12_500 and c1 % 1024 == 0
+    ex._grow_cap(5_000)
+    assert ex._rows_cap == c1                              # never shrinks
+    ex._grow_cap(10_000_000)
+    assert ex._rows_cap == (100_000 + 1023) // 1024 * 1024 # never beyond the row set
+    # slices of the sparse reduce-scatter: a multiple of 64 rows, W of them cover the set
+    for W in (2, 3, 8):
+        per = ex._slice_rows(W)
+        assert per % 64 == 0 and per * W >= arena.P and (per - 64) * W < arena.P + 64 * W
+
+
+def test_exchange_slice_capacities(monkeypatch):
+    from dreamscene_amd import multiview
+    import torch.distributed as dist
+    arena = multiview.GradArena(100_000, 16, torch.device("cpu"))
+    ex = multiview.GradExchange(arena, sh_degree=3, mode="sparse_rs")
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 8)
+    ex._rs_caps = [1024, 2048]
+    ex._grow_rs_caps(2_000, 3_000)
+    assert ex._rs_caps[0] >= 2_500 and ex._rs_caps[1] >= 3_750 and all(c % 512 == 0 for c in ex._rs_caps)
+    held = list(ex._rs_caps)
+    ex._grow_rs_caps(4_000, 0x7FFFFFFF)                     # poisoned owner message: only the first capacity moves
+    assert ex._rs_caps[0] >= 5_000 and ex._rs_caps[1] == held[1]
+    lim = (ex._slice_rows(8) + 1023) // 1024 * 1024
+    ex._grow_rs_caps(10 ** 8, 10 ** 8)
+    assert ex._rs_caps == [lim, lim]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # call R (32 K-key buckets): depth sort as MSD partition + local sort where eligible: parity (every list bit-exact), then A/B against the LSD-only build
-ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/r6r; mkdir -p $O; cd $ROOT
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; O=$ROOT/gpurun_out/r6q; mkdir -p $O; cd $ROOT
 timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_fuzz.py tests/test_full_size.py tests/test_views.py tests/test_graph.py tests/test_early_count.py tests/test_knn.py tests/test_scene.py -m gpu -q -x </dev/null > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $O/pytest.log | tail -8
 B="--no-cpu-baseline --sustain-seconds 0 --rotate-seconds 0 --train-seconds 0"
 for cfg in "" "--gaussians 100000 --res 512" "--init-opacity --no-dropin" "--gaussians 1000000 --res 800 --no-dropin" "--scene indoor --gaussians 2000000 --no-dropin"; do
