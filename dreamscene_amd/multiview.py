@@ -776,10 +776,30 @@ def reduce_view_stats(means2D_grad: torch.Tensor, radii: torch.Tensor, group=Non
     maxr = radii.to(torch.int32).clone()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         packed = torch.stack([norm, vis], dim=0)
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(maxr, op=dist.ReduceOp.MAX, group=group)
+        if _host_staged(group, packed):          # (gloo on device tensors: the one-GPU-box tests)
+            hp, hm = packed.cpu(), maxr.cpu()
+            dist.all_reduce(hp, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(hm, op=dist.ReduceOp.MAX, group=group)
+            packed.copy_(hp); maxr.copy_(hm)
+        else:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(maxr, op=dist.ReduceOp.MAX, group=group)
         norm, vis = packed[0], packed[1]
     return norm, vis, maxr
+
+
+def reduce_step(exchange: "GradExchange", means2D_grad: torch.Tensor, radii: torch.Tensor, stats_group=None):
+    """The two exchanges of a data-parallel step side by side: the gradient exchange starts on the exchange's own stream (behind
+    everything the caller's stream holds -- K8 included), the per-view densification statistics (reduce_view_stats: two small
+    all-reduces, gs_renderer.py:1034-1065) run on the caller's stream beside it, then the caller's stream joins. stats_group: a
+    process group of its own for the statistics (dist.new_group()) lets RCCL run the two exchanges concurrently -- collectives of
+    ONE communicator execute one after the other whatever stream they were issued from; without it only the exchange's own kernels
+    (pack / reduce / apply) overlap the statistics. Returns reduce_view_stats' (norm sum, visible count, max radius)."""
+    handle = exchange.reduce(async_op=True)
+    stats = reduce_view_stats(means2D_grad, radii, stats_group if stats_group is not None else exchange.group)
+    if handle is not None:
+        handle.wait()
+    return stats
 
 
 def shard_views(n_views: int, rank: int, world: int):

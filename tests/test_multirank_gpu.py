@@ -78,9 +78,11 @@ def _worker(rank, world, port, mode, out_dir):
         outs, g2d = _render_into_arena(params, cams, ups, mine, arena, dev)
         own = arena.flat.clone()
         if lazy:
-            h = ex.reduce(async_op=True)
-            side_work = own.sum()      # (something on the caller's stream beside the exchange)
-            h.wait()
+            # the statistics all-reduce on the caller's stream beside the exchange on its own (multiview.reduce_step)
+            radii = outs[-1][1]
+            norm, vis, maxr = multiview.reduce_step(ex, g2d[-1], radii)
+            ref_norm, ref_vis, ref_maxr = multiview.reduce_view_stats(g2d[-1], radii)
+            assert torch.equal(norm, ref_norm) and torch.equal(vis, ref_vis) and torch.equal(maxr, ref_maxr)
             fitted = ex.finish()
             # (the first step may find the speculated capacity -- P / 4 rows -- too small for this small, dense scene: that step's
             #  arena then stays un-reduced, BY CONTRACT of strict=False, and the capacity follows the largest count seen)
