@@ -78,8 +78,9 @@ class RasterContext:
     side_streams   GaussianRasterizer only: consecutive calls rotate over this many internal HIP streams (see `_SideStreams`):
                    None = what the environment says (GSR_SIDE_STREAMS=n; default SIDE_STREAMS_DEFAULT), 0 / 1 = the caller's stream
     per_view_accel GaussianRasterizer only: the ONE opt-in accelerator of the per-view call -- "off", "streams" (internal
-                   streams, `side_streams` of them, 2 when unset) or "graphs" (captured ring, dropin.py). None = derived from
-                   the two fields above / their environment variables. The two are mutually exclusive BY CONSTRUCTION: asking
+                   streams, `side_streams` of them, 2 when unset) or "graphs" (captured ring, dropin.py). None = what the
+                   environment says (GSR_PER_VIEW_ACCEL=off|streams|graphs), else derived from the two fields above / their
+                   environment variables. The two are mutually exclusive BY CONSTRUCTION: asking
                    for both (fields or environment) raises -- they are slower together than either alone (HISTORY round 5:
                    2 420 vs 2 497 / 2 583 views/s) and serve different call patterns.
     """
