@@ -286,7 +286,12 @@ k_col_plan(const uint32_t* __restrict__ totals1, const int gx, uint32_t* __restr
 // inside the rectangle) 64 at a time; a pair's position in the "sorted by tx" list is the running counter of its
 // column (start: colstart + scanned hist1) plus its rank among the round's pairs of the same column -- the stable
 // scatter of a radix pass, fused with the generation of its input. One word per pair: ty << 24 | Gaussian index.
-__global__ void __launch_bounds__(64)
+// Workgroups of kEmitWaves independent waves (one run each, wave-private LDS, no workgroup barrier). Round 6, one call, 1 / 4 / 8
+// waves per workgroup: 12.7 / 12.7 / 12.8 us per view at C3 (the kernel is the serial chain of each wave -- ~22 k cycles for ~900
+// vector instructions, 26 waves resident per CU by SQ_WAVE_CYCLES -- not the dispatch of its 31 k workgroups), 9.5 / 8.2 / 8.9 us
+// per view on the 2 M indoor scene: four.
+constexpr int kEmitWaves = 4;
+__global__ void __launch_bounds__(64 * kEmitWaves)
 k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x, const uint32_t* __restrict__ rect_sorted,
             const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ sorted_idx_alt,
             const uint32_t* __restrict__ os_state, const uint32_t* __restrict__ hist1, const uint32_t nrun,
@@ -295,14 +300,21 @@ k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x,
   n_vis = batch_ptr(n_vis, ps); rect_sorted = batch_ptr(rect_sorted, ps);
   sorted_idx = batch_ptr(batch_ptr(os_state, ps)[kOsSkipFlag] ? sorted_idx_alt : sorted_idx, ps);      // (see k_col_hist)
   hist1 = batch_ptr(hist1, ps); colstart = batch_ptr(colstart, ps); vals = batch_ptr(vals, ss);
-  __shared__ uint32_t col_run[256];
-  __shared__ uint32_t pbase[65];
-  __shared__ uint32_t rs[64], ids[64], mg[64];
+  __shared__ uint32_t col_run_s[kEmitWaves][256];
+  __shared__ uint32_t pbase_s[kEmitWaves][65];
+  __shared__ uint32_t rs_s[kEmitWaves][64], ids_s[kEmitWaves][64], mg_s[kEmitWaves][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t* col_run = col_run_s[wave];
+  uint32_t* pbase = pbase_s[wave];
+  uint32_t *rs = rs_s[wave], *ids = ids_s[wave], *mg = mg_s[wave];
   const int64_t nv = (int64_t)*n_vis;
-  const uint32_t run_id = xcd_chunked(blockIdx.x, (uint32_t)((nv + kColRun - 1) / kColRun));   // (see col_blocks)
-  if (run_id == 0xFFFFFFFFu) return;
+  const uint32_t n_runs = (uint32_t)((nv + kColRun - 1) / kColRun);
+  // (groups of kEmitWaves consecutive runs dealt to the XCDs in contiguous ranges: see col_blocks)
+  const uint32_t grp = xcd_chunked(blockIdx.x, (n_runs + kEmitWaves - 1) / kEmitWaves);
+  if (grp == 0xFFFFFFFFu) return;
+  const uint32_t run_id = grp * kEmitWaves + (uint32_t)wave;
+  if (run_id >= n_runs) return;
   const int64_t s0 = (int64_t)run_id * kColRun;
-  const int lane = threadIdx.x;
   for (int tx = lane; tx < gx; tx += 64) col_run[tx] = colstart[tx] + hist1[(uint64_t)tx * nrun + run_id];
   const bool in = s0 + lane < nv;
   const uint32_t r = in ? rect_sorted[s0 + lane] : 0u;
@@ -320,7 +332,8 @@ k_emit_cols(const uint64_t* __restrict__ n_vis, const int gx, const int nbits_x,
   rs[lane] = r;
   ids[lane] = in ? sorted_idx[s0 + lane] : 0u;
   mg[lane] = w > 1 ? 0xFFFFFFFFu / w + 1u : 0u;   // floor(q / w) == umulhi(q, mg) for q < 2^16, w <= 256
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the LDS above is the wave's own)
+  __builtin_amdgcn_wave_barrier();
   uint32_t* run = col_run;
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (uint32_t q0 = 0; q0 < total; q0 += 64) {
@@ -695,7 +708,8 @@ static int launch_binning_columns(int n, const GsrView& v, const GsrGeom* geoms,
     GsrStageTimer t(prof, stream, GSR_STAGE_DUPLICATE);
     int nbits_x = 1;
     while ((1 << nbits_x) < gx) ++nbits_x;
-    hipLaunchKernelGGL(k_emit_cols, dim3((nrun + 7u) / 8u * 8u, ny), dim3(64), 0, stream, n_dev_vis, gx, nbits_x, rect_sorted,
+    const uint32_t ngrp = (nrun + kEmitWaves - 1) / kEmitWaves;
+    hipLaunchKernelGGL(k_emit_cols, dim3((ngrp + 7u) / 8u * 8u, ny), dim3(64 * kEmitWaves), 0, stream, n_dev_vis, gx, nbits_x, rect_sorted,
                        geom.sorted_idx, (const uint32_t*)((geom.sorted_idx == s.v0) ? s.v1 : s.v0), (const uint32_t*)s.hist,
                        s.hist1, nrun, s.colstart, cap, vals1, ps, ss);
     GSR_HIP(hipGetLastError());
