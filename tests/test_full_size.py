@@ -4,7 +4,7 @@ Two kinds of checks per configuration:
   * against the scalar C oracle on the same seeded inputs (it needs 0.3 .. 4 s per view at these sizes): every integer
     artefact bit-exact -- including n_contrib and the bits of final_T: the hard gates (alpha < 1/255, T < 1e-4) see the
     same bits in both implementations (SEMANTICS.md section 4/6) -- and images and gradients within
-    1e-5 * max(1, max|ref|) for EVERY entry (no outlier allowance);
+    1e-5 * max|ref| of the entry's own tensor for EVERY entry (no outlier allowance; tests/util.py: rel_scale);
   * size-independent properties of the rasterizer that need no oracle: the sorted list is ordered by (tile, depth bits)
     with ties in ascending Gaussian index (stable sort of the emission order) and the tile ranges partition it; the
     pair count is the sum of the tile rectangles; alpha + final_T = 1; image(white bg) - image(black bg) = final_T;

@@ -1,7 +1,7 @@
 """-m gpu: HIP path (through the C ABI) vs the oracles on the same seeded inputs.
 
 Bars (BASELINE.json north_star): bit-exact for tile assignment / sort indices (radii, tiles_touched, N, sorted
-value list, sorted keys, tile ranges); <= 1e-5 (fp32, normalised by max(1, max|ref|)) on RGB / depth / alpha and
+value list, sorted keys, tile ranges); <= 1e-5 (fp32, relative to the tensor's own max|ref|: tests/util.py rel_scale) on RGB / depth / alpha and
 on every gradient."""
 import numpy as np
 import pytest

@@ -1,7 +1,7 @@
 """One-off widening of tests/test_full_size.py on the GPU box: random configurations between C2 and C3 in size (Gaussians,
 image shape, SH stride / degree, camera distance / elevation / field of view, opacity state, scale range, object or room)
 through tests/test_gpu_parity.py's bars -- radii, tiles touched, pair count, sorted list, keys, ranges, n_contrib and the bits of
-final_T identical to the scalar C oracle; images and every gradient entry within 1e-5 x max(1, max|ref|).
+final_T identical to the scalar C oracle; images and every gradient entry within 1e-5 x max|ref| of their own tensor (tests/util.py: rel_scale).
 usage: python tools/fuzz_big.py [n_configs] [first_seed]"""
 import os
 import sys
