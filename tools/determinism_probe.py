@@ -54,7 +54,7 @@ def main():
             _, _, _, got = TB._hip_replay(c, up_img, up_da)
             for k, ref in c["grads"].items():
                 a = got[k].reshape(ref.shape)
-                e = float(np.abs(a.astype(np.float64) - ref.astype(np.float64)).max() / max(1.0, float(np.abs(ref).max())))
+                e = float(np.abs(a.astype(np.float64) - ref.astype(np.float64)).max() / max(1e-6, float(np.abs(ref).max())))
                 worst.setdefault(k, []).append(e)
                 if r == 0:
                     first[k], same[k] = a.copy(), True
