@@ -18,6 +18,7 @@ from __future__ import annotations
 import os
 
 import collections
+import contextlib
 import ctypes as C
 import dataclasses
 import threading
@@ -181,6 +182,7 @@ class _Workspace:
         return t
 
 
+_NULL_CTX = contextlib.nullcontext()
 _PAIR_COUNT_SPINS = 4096     # polls of the pair-count word before _wait_pair_counts falls back to event.synchronize()
 _WORKSPACES = {}
 _STATE_LAYOUTS = {}     # (sizes of a call) -> (offsets of the regions of its state buffer, total bytes)
@@ -341,7 +343,10 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     st.gauss = g
     st.scene = (sc_struct, sc_keep) if sc_struct is not None else None
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    # (a batched call looks the stream up once and sets the device once for all its views: torch.cuda.current_stream() and the
+    #  device context manager cost ~6 us each from Python, six of them per view)
+    stream = batch["stream"] if (batch is not None and batch.get("stream") is not None) else \
+        torch.cuda.current_stream(dev).cuda_stream
     ws = _workspace(dev, stream)
     prof = rc.profile.handle if rc.profile is not None else None
     i32 = torch.int32
@@ -356,7 +361,7 @@ def _forward_steps(s: GaussianRasterizationSettings, means3D, opacities, shs, co
     if batch is not None and hint is None:
         raise RuntimeError("batched forward needs a capacity hint (render the views once unbatched first)")
 
-    with torch.cuda.device(dev):
+    with (_NULL_CTX if (batch is not None and batch.get("device_set")) else torch.cuda.device(dev)):
         radii = torch.empty(Pm, dtype=i32, device=dev)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth_alpha = torch.empty((2, H, W), dtype=torch.float32, device=dev)

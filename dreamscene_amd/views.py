@@ -105,7 +105,7 @@ def rasterize_views_forward_raw(settings_list: Sequence, means3D, opacities, shs
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
                                       pinned_np=ws.batch_pinned_np, n_views=V,
                                       event=ws.event, sort=sort_of(k), synced=synced, score=score_sum, score_dirty=dirty,
-                                      seg_len=seg),
+                                      seg_len=seg, stream=stream, device_set=True),
                                  rc)
                 for k, s in enumerate(settings_list)]
         results = _drive_batch(lib, ws, gens, V, dev, stream, prof)
@@ -190,7 +190,7 @@ def _views_forward_scene(lib, settings_list, scenes, want_aux, rc):
         gens = [R._forward_steps(s, None, None, None, None, None, None, None, False, want_aux, None, scenes[k],
                                  dict(scratch=big[k * stride:(k + 1) * stride], pinned=ws.batch_pinned, index=k,
                                       pinned_np=ws.batch_pinned_np, n_views=V,
-                                      event=ws.event, sort=sort_of(k), synced=synced, seg_len=seg), rc)
+                                      event=ws.event, sort=sort_of(k), synced=synced, seg_len=seg, stream=stream, device_set=True), rc)
                 for k, s in enumerate(settings_list)]
         return _drive_batch(lib, ws, gens, V, dev, stream, prof)
 
