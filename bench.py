@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--exchange", choices=["measure", "dense", "auto", "rows", "sparse_rs", "direct"], default="measure",
                     help="wire format of the multi-GPU gradient exchange (multiview.GradExchange); dense = one in-place "
                          "all-reduce of the active columns, the only format that needs no host read; measure (default) = "
-                         "after the warm-up time the formats of --exchange-candidates (dense, direct) for a few steps each and keep the fastest "
+                         "after the warm-up time the formats of --exchange-candidates for a few steps each and keep the fastest "
                          "(every rank takes the same decision); with one rank there is nothing to exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true",
@@ -173,9 +173,9 @@ def main():
                     help="render the views of a step one call at a time (GaussianRasterizer) instead of through "
                          "GaussianRasterizerViews (same kernels; the depth sorts of all views share their launches)")
     ap.add_argument("--exchange-candidates", default=None,
-                    help="--exchange measure: comma-separated wire formats to time (default: dense,direct under RCCL -- "
-                         "the sparse formats' measured device side alone, 0.34-0.37 ms at C3, exceeds `direct`'s whole "
-                         "exchange, DESIGN.md section 6; add rows / sparse_rs here to time them too --, dense,rows under gloo)")
+                    help="--exchange measure: comma-separated wire formats to time (default: dense,direct,rows,sparse_rs under "
+                         "RCCL -- the sparse formats in their host-read-free message form, 84-90 us of device side at C3, "
+                         "DESIGN.md section 6 --, dense,rows under gloo)")
     ap.add_argument("--exchange-probe-steps", type=int, default=12,
                     help="--exchange measure: timed steps per wire format after the warm-up")
     args = ap.parse_args()
@@ -391,7 +391,8 @@ def main():
         if args.exchange == "measure":
             # gloo (functional tests on one device) stages device tensors through the host for dense / rows only
             # (rows: the device form of round 6 -- self-describing messages, no host read: multiview._RowMessages)
-            cands = ["dense", "direct", "rows"] if backend == "nccl" else ["dense", "rows"]
+            # (sparse_rs: the device form as well -- equal-split all-to-all + all-gather of fixed-size messages)
+            cands = ["dense", "direct", "rows", "sparse_rs"] if backend == "nccl" else ["dense", "rows"]
             if args.exchange_candidates:
                 cands = [f for f in (x.strip() for x in args.exchange_candidates.split(",")) if f]
                 unknown = [f for f in cands if f not in ("dense", "direct", "rows", "sparse_rs")]

@@ -157,7 +157,7 @@ __host__ __device__ inline MsgLayout msg_layout(int32_t n_rows, int32_t F, uint3
   l.bitmap = kMsgHdrBytes;
   l.offs = l.bitmap + ((words * 8 + 255) & ~(size_t)255);
   l.rows = l.offs + ((words * 4 + 255) & ~(size_t)255);
-  l.total = l.rows + (((size_t)cap * (size_t)F * 4 + 255) & ~(size_t)255);
+  l.total = l.rows + ((((size_t)cap * (size_t)F * 4 > 16 ? (size_t)cap * (size_t)F * 4 : (size_t)16) + 255) & ~(size_t)255);
   return l;
 }
 
@@ -167,27 +167,40 @@ __device__ __forceinline__ unsigned long long msg_word(const unsigned long long*
   return m;
 }
 
-// Lane -> (row slot, element) of a wave-wide copy of rows of F floats: F <= 64: 64 / F rows per instruction, lane = slot * F + f
-// (the element a lane handles never changes, so the region it lives in -- base pointer, stride -- is selected ONCE per wave: the
-// second build of these kernels re-selected it per element from the by-value region table and spent its time on the scalar
-// reloads of that table, 55 / 106 us for pack / apply at C3); F > 64: one row per instruction, elements in chunks of 64.
-struct LaneMap {
+// Lane -> (row slot, chunk) of a wave-wide copy of rows of F floats. A CHUNK is VW consecutive floats of a message row: VW = 4 for
+// F >= 4 -- one dwordx4 per lane on the message side (message rows are F floats apart, 4-byte aligned: gfx950 takes unaligned
+// dwordx4) --, VW = 1 for narrower rows. C = ceil(F / VW) chunks per row; the last chunk of a row whose F is no multiple of VW
+// starts at F - VW, i.e. it overlaps its neighbour (the doubly covered floats are computed identically by both lanes; the arena
+// side skips them). C <= 64: 64 / C rows per instruction, lane = slot * C + chunk -- the chunk a lane handles never changes, so the
+// regions its floats live in (base pointer, stride) are selected ONCE per wave (the second build re-selected them per element from
+// the by-value region table and spent its time on the scalar reloads of that table, 55 / 106 us for pack / apply at C3);
+// C > 64: one row per instruction, chunks in groups of 64.
+// Round 6, fourth -> fifth build: with one FLOAT per lane the apply kernel issued W dword loads per row of the union whatever the
+// messages held -- 85 us at C3 (148 MB of rows) and 81 us at C4 (75 MB): bound by the number of memory instructions, not bytes.
+template <int VW> struct __attribute__((aligned(4))) Vec { float v[VW]; };
+struct ChunkMap {
+  int C;           // chunks per row
   int slots;       // rows per wave instruction
-  int slot, f;     // this lane's row slot and element (chunk 0)
+  int slot, c;     // this lane's row slot and chunk (group 0)
   bool active;
 };
-__device__ __forceinline__ LaneMap lane_map(int F, int lane, uint32_t f_magic) {
-  LaneMap lm;
-  if (F <= 64) {
-    lm.slots = 64 / F;
-    lm.slot = f_magic ? (int)__umulhi((uint32_t)lane, f_magic) : lane;
-    lm.f = lane - lm.slot * F;
-    lm.active = lm.slot < lm.slots;
+template <int VW>
+__device__ __forceinline__ ChunkMap chunk_map(int F, int lane, uint32_t c_magic) {
+  ChunkMap cm;
+  cm.C = (F + VW - 1) / VW;
+  if (cm.C <= 64) {
+    cm.slots = 64 / cm.C;
+    cm.slot = c_magic ? (int)__umulhi((uint32_t)lane, c_magic) : lane;
+    cm.c = lane - cm.slot * cm.C;
+    cm.active = cm.slot < cm.slots;
   } else {
-    lm.slots = 1; lm.slot = 0; lm.f = lane; lm.active = true;
+    cm.slots = 1; cm.slot = 0; cm.c = lane; cm.active = true;
   }
-  return lm;
+  return cm;
 }
+// first float of chunk c
+template <int VW>
+__device__ __forceinline__ int chunk_start(int F, int c) { return min(c * VW, F - VW); }
 struct ElemRef { float* base; int stride; };       // element f of row i = base[i * stride]
 __device__ __forceinline__ ElemRef elem_ref(const Regions& r, int f) {
   float* p = r.ptr[0];
@@ -217,9 +230,10 @@ __host__ __device__ inline int32_t slice_len(int32_t rows, int32_t slice_rows, i
 // Workgroup b packs words [4 b, 4 b + 4) of slice blockIdx.y, one word of 64 rows per wave: it counts the set bits in FRONT of its
 // range itself (a strided pass over at most n_words words of the L2-resident bitmap: 62 KB at 500 k rows -- no scan launch, no
 // look-back chain), then every wave copies the rows of its word, four row-instructions in flight. The last workgroup writes the header.
+template <int VW>
 __global__ void __launch_bounds__(256)
 k_msg_pack(const Regions r, const unsigned long long* __restrict__ mask, unsigned char* __restrict__ msg, const size_t msg_stride,
-           const int32_t slice_rows, const MsgLayout lay, const uint32_t cap, const uint32_t f_magic) {
+           const int32_t slice_rows, const MsgLayout lay, const uint32_t cap, const uint32_t c_magic) {
   __shared__ uint32_t red[4];
   __shared__ uint8_t bitpos[4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -266,25 +280,30 @@ k_msg_pack(const Regions r, const unsigned long long* __restrict__ mask, unsigne
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int nset = (int)__popcll(m), F = r.F;
-  const LaneMap lm = lane_map(F, lane, f_magic);
-  for (int f0 = 0; f0 < F; f0 += 64) {            // (one trip unless F > 64)
-    const int f = lm.f + f0;
-    const ElemRef src = elem_ref(r, f < F ? f : 0);
-    const bool lane_on = lm.active && f < F;
-    for (int k0 = 0; k0 < nset; k0 += 4 * lm.slots) {
-      float v[4];
+  const ChunkMap cm = chunk_map<VW>(F, lane, c_magic);
+  for (int c0 = 0; c0 < cm.C; c0 += 64) {            // (one trip unless the row has more than 64 chunks)
+    const int ch = cm.c + c0;
+    const bool lane_on = cm.active && ch < cm.C;
+    const int fs = chunk_start<VW>(F, lane_on ? ch : 0);
+    ElemRef src[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) src[j] = elem_ref(r, fs + j);
+    for (int k0 = 0; k0 < nset; k0 += 4 * cm.slots) {
+      Vec<VW> v[4];
       bool on[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u * lm.slots + lm.slot;
+        const int k = k0 + u * cm.slots + cm.slot;
         on[u] = lane_on && k < nset && o0 + (uint32_t)k < cap;
         // (branch-free: a lane without a row re-reads the word's first set row -- see msg_merge_word)
-        v[u] = src.base[(row0 + (int64_t)w * 64 + mybits[k < nset ? k : 0]) * (int64_t)src.stride];
+        const int64_t row = row0 + (int64_t)w * 64 + mybits[k < nset ? k : 0];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) v[u].v[j] = src[j].base[row * (int64_t)src[j].stride];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u * lm.slots + lm.slot;
-        if (on[u]) out[(size_t)(o0 + (uint32_t)k) * F + f] = v[u];
+        const int k = k0 + u * cm.slots + cm.slot;
+        if (on[u]) *reinterpret_cast<Vec<VW>*>(out + (size_t)(o0 + (uint32_t)k) * F + fs) = v[u];
       }
     }
   }
@@ -325,15 +344,18 @@ __device__ __forceinline__ bool msg_headers_bad(const unsigned char* __restrict_
 // messages' rows added in RANK ORDER -> put(k, b, f, sum). The bitmap words and row offsets of the messages are wave-uniform
 // (scalar registers); lane b holds, for row b of the word, its position in every message (offset + set bits below b) and the mask
 // of the messages that hold it; a lane working on row b fetches both with ds_bpermute. kTrip row-instructions per trip of the row
-// loop: their loads (up to MAXW each) are all issued before the first add -- a word holds ~13 rows of the union at C3: four per
-// trip = 4 dependent memory round trips per wave instead of 7. (Second build, two per trip: 106 us at C3; the same kernel without
-// its row loads 59, without its stores 82 -- a chain of round trips, not bytes: gpurun_out/r6h.)
+// loop: their loads (up to MAXW each) are all issued before the first add -- a word holds ~13 rows of the union at C3; with
+// dwordx4 lanes a row-instruction covers 4 rows of 59 floats: two trips per word. (Second build, one float per lane, two
+// row-instructions per trip: 106 us at C3; the same kernel without its row loads 59, without its stores 82 -- a chain of round
+// trips, not bytes: gpurun_out/r6h. Fifth build, dwordx4: 65 us.)
 // Returns the union word (0: nothing to do).
-template <int MAXW, typename Put>
+template <int MAXW, int VW, typename Put>
 __device__ __forceinline__ unsigned long long
 msg_merge_word(const unsigned char* __restrict__ msgs, const size_t msg_stride, const int W, const int w, const MsgLayout lay,
-               const int F, const uint32_t f_magic, uint8_t* ubits, Put put) {
-  constexpr int kTrip = MAXW <= 8 ? 4 : 2;
+               const int F, const uint32_t c_magic, uint8_t* ubits, Put put) {
+  // kTrip x MAXW x VW registers of loads in flight. (dwordx4 lanes, MAXW = 8: one row-instruction per trip instead of two frees 40
+  // registers -- 4 waves per SIMD instead of 3 -- and changes nothing: apply 67 against 65 us at C3, gpurun_out/r6ad.)
+  constexpr int kTrip = MAXW == 1 ? 4 : (VW > 1 ? (MAXW <= 8 ? 2 : 1) : (MAXW <= 8 ? 4 : 2));
   const int lane = threadIdx.x & 63;
   unsigned long long U = 0ull;
   uint32_t posl[MAXW];         // lane b: position of row b of the word in message q (meaningful where the message holds the row)
@@ -359,26 +381,27 @@ msg_merge_word(const unsigned char* __restrict__ msgs, const size_t msg_stride, 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int nrow = (int)__popcll(U);
-  const LaneMap lm = lane_map(F, lane, f_magic);
+  const ChunkMap cm = chunk_map<VW>(F, lane, c_magic);
   const float* rowsq[MAXW];
 #pragma unroll
   for (int q = 0; q < MAXW; ++q)
     rowsq[q] = reinterpret_cast<const float*>(msgs + (size_t)(q < W ? q : 0) * msg_stride + lay.rows);
-  for (int f0 = 0; f0 < F; f0 += 64) {            // (one trip unless F > 64)
-    const int f = lm.f + f0;
-    const bool lane_on = lm.active && f < F;
-    for (int k0 = 0; k0 < nrow; k0 += kTrip * lm.slots) {
-      float v[kTrip][MAXW];
+  for (int c0 = 0; c0 < cm.C; c0 += 64) {            // (one trip unless the row has more than 64 chunks)
+    const int ch = cm.c + c0;
+    const bool lane_on = cm.active && ch < cm.C;
+    const int fs = chunk_start<VW>(F, lane_on ? ch : 0);
+    for (int k0 = 0; k0 < nrow; k0 += kTrip * cm.slots) {
+      Vec<VW> v[kTrip][MAXW];
       uint32_t has[kTrip];
       int b[kTrip], kk[kTrip];
 #pragma unroll
       for (int t = 0; t < kTrip; ++t) {
-        kk[t] = k0 + t * lm.slots + lm.slot;
+        kk[t] = k0 + t * cm.slots + cm.slot;
         const bool on = lane_on && kk[t] < nrow;
         b[t] = ubits[kk[t] < nrow ? kk[t] : 0];
         has[t] = (uint32_t)__shfl((int)hasl, b[t], 64);
         if (!on) has[t] = 0u;
-        // BRANCH-FREE loads: a lane whose message does not hold the row (or a message slot >= W) reads element 0 of that
+        // BRANCH-FREE loads: a lane whose message does not hold the row (or a message slot >= W) reads the first chunk of that
         // message's rows and discards it. With the loads under `if (has >> q & 1)` every one of the up to kTrip x MAXW loads of a
         // trip sat in its own control-flow region and was waited for before the next was issued: ~13 us per trip, 109 us for the
         // kernel at C3 whatever the number of rows (gpurun_out/r6k) -- serialised round trips, not bytes.
@@ -386,20 +409,25 @@ msg_merge_word(const unsigned char* __restrict__ msgs, const size_t msg_stride, 
         for (int q = 0; q < MAXW; ++q) {
           const uint32_t pos = (uint32_t)__shfl((int)posl[q], b[t], 64);
           const bool h = (has[t] >> q) & 1u;
-          const size_t at = h ? (size_t)pos * F + f : 0;
-          const float x = rowsq[q][at];
-          v[t][q] = h ? x : 0.f;
+          const size_t at = h ? (size_t)pos * F + fs : 0;
+          v[t][q] = *reinterpret_cast<const Vec<VW>*>(rowsq[q] + at);
         }
       }
 #pragma unroll
       for (int t = 0; t < kTrip; ++t) {
         if (has[t] == 0u) continue;
-        float acc = 0.f;
+        Vec<VW> acc;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc.v[j] = 0.f;
         bool any = false;
 #pragma unroll
         for (int q = 0; q < MAXW; ++q)
-          if (q < W && ((has[t] >> q) & 1u)) { acc = any ? __fadd_rn(acc, v[t][q]) : v[t][q]; any = true; }
-        put(kk[t], b[t], f, acc);
+          if (q < W && ((has[t] >> q) & 1u)) {
+#pragma unroll
+            for (int j = 0; j < VW; ++j) acc.v[j] = any ? __fadd_rn(acc.v[j], v[t][q].v[j]) : v[t][q].v[j];
+            any = true;
+          }
+        put(kk[t], b[t], c0 == 0, ch, fs, acc);
       }
     }
   }
@@ -413,11 +441,13 @@ msg_merge_word(const unsigned char* __restrict__ msgs, const size_t msg_stride, 
 //                   last step of the sparse reduce-scatter (the owners' reduced slices, disjoint).
 // *status (one u64, may be page-locked host memory; msg_status above): applied, or NOTHING applied because some message overflowed
 // its capacity / does not match this call's shape; stored by the first workgroup before any row is touched.
-template <int MAXW>
+// MAXW: the most messages the call may carry (headers); MERGE: the most messages that describe one word (MAXW, or 1 in slice mode --
+// with MERGE = MAXW there the W - 1 message slots nobody fills still cost a discarded load each: 43 -> 31 us at C3, gpurun_out/r6ad).
+template <int MAXW, int MERGE, int VW>
 __global__ void __launch_bounds__(256)
 k_msg_apply(const Regions r, const unsigned char* __restrict__ msgs, const size_t msg_stride, const int W, const int32_t slice_rows,
             const MsgLayout lay, const uint32_t cap, unsigned long long* __restrict__ status,
-            unsigned long long* __restrict__ touched, const uint32_t f_magic) {
+            unsigned long long* __restrict__ touched, const uint32_t c_magic) {
   __shared__ uint8_t ubits_s[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
@@ -431,17 +461,25 @@ k_msg_apply(const Regions r, const unsigned char* __restrict__ msgs, const size_
   const int32_t rows_here = slice_len(r.rows, slice_rows, y);
   if (bad || w >= (rows_here + 63) / 64) return;
   const int64_t row0 = (int64_t)y * (slice_rows > 0 ? slice_rows : 0);
-  // (the element a lane stores never changes: its region is selected once -- lane_map / elem_ref)
-  const LaneMap lm = lane_map(r.F, lane, f_magic);
-  const ElemRef d0 = elem_ref(r, lm.f < r.F ? lm.f : 0);
+  // (the chunk a lane stores never changes: the regions of its floats are selected once -- chunk_map / elem_ref)
+  const ChunkMap cm = chunk_map<VW>(r.F, lane, c_magic);
+  const int fs0 = chunk_start<VW>(r.F, (cm.active && cm.c < cm.C) ? cm.c : 0);
+  ElemRef d0[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) d0[j] = elem_ref(r, fs0 + j);
   const Regions& rr = r;
-  auto put = [&](int k, int b, int f, float v) {
+  auto put = [&](int k, int b, bool first_group, int ch, int fs, const Vec<VW>& v) {
     (void)k;
-    const ElemRef d = (f == lm.f) ? d0 : elem_ref(rr, f);            // (f != lm.f only for F > 64)
-    d.base[(row0 + (int64_t)w * 64 + b) * (int64_t)d.stride] = v;
+    const int64_t row = row0 + (int64_t)w * 64 + b;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      if (fs + j < ch * VW) continue;              // (the floats an overlapping last chunk shares with its neighbour: the neighbour stores them)
+      const ElemRef d = first_group ? d0[j] : elem_ref(rr, fs + j);            // (later groups only for rows of more than 64 chunks)
+      d.base[row * (int64_t)d.stride] = v.v[j];
+    }
   };
   const unsigned char* data = slice_rows > 0 ? msgs + (size_t)y * msg_stride : msgs;
-  const unsigned long long U = msg_merge_word<MAXW>(data, msg_stride, slice_rows > 0 ? 1 : W, w, lay, r.F, f_magic, ubits_s[wave], put);
+  const unsigned long long U = msg_merge_word<MERGE, VW>(data, msg_stride, slice_rows > 0 ? 1 : W, w, lay, r.F, c_magic, ubits_s[wave], put);
   if (touched && U && lane == 0) touched[(row0 >> 6) + w] = U;
 }
 
@@ -449,11 +487,11 @@ k_msg_apply(const Regions r, const unsigned char* __restrict__ msgs, const size_
 // the output describes the union of their rows, every row = the ranks' contributions added in rank order. The output's count may
 // exceed cap_out (recorded in its header, the rows beyond are not written); if an INPUT does not fit / match, the output's count is
 // 0xFFFFFFFF: whoever applies it applies nothing (gsr_rowmsg_apply_slices), i.e. the arena of no rank is touched.
-template <int MAXW>
+template <int MAXW, int VW>
 __global__ void __launch_bounds__(256)
 k_msg_reduce(const unsigned char* __restrict__ msgs, const size_t msg_stride, const int W, const int32_t rows, const int F,
              const MsgLayout lay_in, const uint32_t cap_in, unsigned char* __restrict__ out, const MsgLayout lay_out,
-             const uint32_t cap_out, const uint32_t f_magic) {
+             const uint32_t cap_out, const uint32_t c_magic) {
   __shared__ uint8_t ubits_s[4][64];
   __shared__ uint32_t red[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -498,12 +536,13 @@ k_msg_reduce(const unsigned char* __restrict__ msgs, const size_t msg_stride, co
   const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kMsgWordsPerBlock + wave);
   if (w >= n_words) return;
   float* orow = reinterpret_cast<float*>(out + lay_out.rows);
-  auto put = [&](int k, int b, int f, float v) {
-    (void)b;
+  auto put = [&](int k, int b, bool first_group, int ch, int fs, const Vec<VW>& v) {
+    (void)b; (void)first_group; (void)ch;
     const uint32_t pos = o0 + (uint32_t)k;
-    if (pos < cap_out) orow[(size_t)pos * F + f] = v;
+    // (an overlapping last chunk re-writes floats of its neighbour with the same values: same loads, same order of adds)
+    if (pos < cap_out) *reinterpret_cast<Vec<VW>*>(orow + (size_t)pos * F + fs) = v;
   };
-  const unsigned long long U = msg_merge_word<MAXW>(msgs, msg_stride, W, w, lay_in, F, f_magic, ubits_s[wave], put);
+  const unsigned long long U = msg_merge_word<MAXW, VW>(msgs, msg_stride, W, w, lay_in, F, c_magic, ubits_s[wave], put);
   if (lane == 0) {
     reinterpret_cast<unsigned long long*>(out + lay_out.bitmap)[w] = U;
     reinterpret_cast<uint32_t*>(out + lay_out.offs)[w] = o0;
@@ -605,6 +644,9 @@ size_t gsr_rowmsg_bytes(int32_t rows, int32_t row_floats, uint32_t cap) {
 }
 
 static uint32_t f_magic_of(int F) { return (uint32_t)(0xFFFFFFFFu / (uint32_t)F + 1u); }   // floor(x / F) = umulhi(x, magic); 0 for F = 1
+// floats per lane on the message side (chunk_map) and the magic of the chunks per row
+static int msg_vw(int F) { return F >= 4 ? 4 : 1; }
+static uint32_t c_magic_of(int F) { return f_magic_of((F + msg_vw(F) - 1) / msg_vw(F)); }
 
 static int rowmsg_pack(const GsrRowSet* rs, const uint64_t* mask, void* msgs, uint64_t msg_stride, int32_t n_slices,
                        int32_t slice_rows, uint32_t cap, void* stream_) {
@@ -621,9 +663,13 @@ static int rowmsg_pack(const GsrRowSet* rs, const uint64_t* mask, void* msgs, ui
   GsrDeviceGuard dev(msgs);
   const int32_t n_words = (per + 63) / 64;
   const uint32_t blocks = (uint32_t)((n_words + kMsgWordsPerBlock - 1) / kMsgWordsPerBlock);
-  hipLaunchKernelGGL(k_msg_pack, dim3(blocks ? blocks : 1u, (uint32_t)n_slices), dim3(256), 0, stream, r,
-                     reinterpret_cast<const unsigned long long*>(mask), reinterpret_cast<unsigned char*>(msgs), (size_t)msg_stride,
-                     slice_rows, lay, cap, f_magic_of(r.F));
+  const dim3 grid(blocks ? blocks : 1u, (uint32_t)n_slices);
+  if (msg_vw(r.F) == 4)
+    hipLaunchKernelGGL(k_msg_pack<4>, grid, dim3(256), 0, stream, r, reinterpret_cast<const unsigned long long*>(mask),
+                       reinterpret_cast<unsigned char*>(msgs), (size_t)msg_stride, slice_rows, lay, cap, c_magic_of(r.F));
+  else
+    hipLaunchKernelGGL(k_msg_pack<1>, grid, dim3(256), 0, stream, r, reinterpret_cast<const unsigned long long*>(mask),
+                       reinterpret_cast<unsigned char*>(msgs), (size_t)msg_stride, slice_rows, lay, cap, c_magic_of(r.F));
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }
@@ -654,12 +700,20 @@ static int rowmsg_apply(const GsrRowSet* rs, const void* msgs, uint64_t msg_stri
   const int32_t n_words = (per + 63) / 64;
   const dim3 grid((uint32_t)((n_words + 3) / 4 > 0 ? (n_words + 3) / 4 : 1), slice_rows > 0 ? (uint32_t)n_msgs : 1u);
   const unsigned char* m = reinterpret_cast<const unsigned char*>(msgs);
-  if (n_msgs <= 8)
-    hipLaunchKernelGGL(k_msg_apply<8>, grid, dim3(256), 0, stream, r, m, (size_t)msg_stride, n_msgs, slice_rows, lay, cap,
-                       reinterpret_cast<unsigned long long*>(status), reinterpret_cast<unsigned long long*>(touched), f_magic_of(r.F));
-  else
-    hipLaunchKernelGGL(k_msg_apply<16>, grid, dim3(256), 0, stream, r, m, (size_t)msg_stride, n_msgs, slice_rows, lay, cap,
-                       reinterpret_cast<unsigned long long*>(status), reinterpret_cast<unsigned long long*>(touched), f_magic_of(r.F));
+  unsigned long long* st = reinterpret_cast<unsigned long long*>(status);
+  unsigned long long* tc = reinterpret_cast<unsigned long long*>(touched);
+  const uint32_t cmg = c_magic_of(r.F);
+  const bool wide = n_msgs > 8, vec = msg_vw(r.F) == 4;
+#define GSR_APPLY(MAXW, MERGE, VW) \
+  hipLaunchKernelGGL((k_msg_apply<MAXW, MERGE, VW>), grid, dim3(256), 0, stream, r, m, (size_t)msg_stride, n_msgs, slice_rows, lay, cap, st, tc, cmg)
+  if (slice_rows > 0) {
+    if (vec) GSR_APPLY(16, 1, 4); else GSR_APPLY(16, 1, 1);
+  } else if (!wide) {
+    if (vec) GSR_APPLY(8, 8, 4); else GSR_APPLY(8, 8, 1);
+  } else {
+    if (vec) GSR_APPLY(16, 16, 4); else GSR_APPLY(16, 16, 1);
+  }
+#undef GSR_APPLY
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }
@@ -688,12 +742,14 @@ int gsr_rowmsg_reduce(int32_t rows, int32_t layout_rows, int32_t row_floats, con
   const int32_t n_words = (rows + 63) / 64;
   const dim3 grid((uint32_t)((n_words + kMsgWordsPerBlock - 1) / kMsgWordsPerBlock > 0 ? (n_words + kMsgWordsPerBlock - 1) / kMsgWordsPerBlock : 1));
   const unsigned char* m = reinterpret_cast<const unsigned char*>(msgs);
-  if (n_msgs <= 8)
-    hipLaunchKernelGGL(k_msg_reduce<8>, grid, dim3(256), 0, stream, m, (size_t)msg_stride, n_msgs, rows, row_floats, lin, cap_in,
-                       reinterpret_cast<unsigned char*>(msg_out), lout, cap_out, f_magic_of(row_floats));
-  else
-    hipLaunchKernelGGL(k_msg_reduce<16>, grid, dim3(256), 0, stream, m, (size_t)msg_stride, n_msgs, rows, row_floats, lin, cap_in,
-                       reinterpret_cast<unsigned char*>(msg_out), lout, cap_out, f_magic_of(row_floats));
+  unsigned char* mo = reinterpret_cast<unsigned char*>(msg_out);
+  const uint32_t cmg = c_magic_of(row_floats);
+  const bool wide = n_msgs > 8, vec = msg_vw(row_floats) == 4;
+#define GSR_REDUCE(MAXW, VW) \
+  hipLaunchKernelGGL((k_msg_reduce<MAXW, VW>), grid, dim3(256), 0, stream, m, (size_t)msg_stride, n_msgs, rows, row_floats, lin, \
+                     cap_in, mo, lout, cap_out, cmg)
+  if (!wide && vec) GSR_REDUCE(8, 4); else if (!wide) GSR_REDUCE(8, 1); else if (vec) GSR_REDUCE(16, 4); else GSR_REDUCE(16, 1);
+#undef GSR_REDUCE
   GSR_HIP(hipGetLastError());
   return GSR_OK;
 }
