@@ -78,7 +78,7 @@ class GsrGrads(C.Structure):
                 ("dL_dcampos", _f), ("partials", _f), ("accumulate", C.c_int32), ("reserved_", C.c_int32),
                 ("stat_max_radii2D", _f), ("stat_xyz_gradient_accum", _f), ("stat_denom", _f),
                 ("scene", C.POINTER(GsrSceneGrads)), ("reached_mask", C.c_void_p),
-                ("reach", C.c_void_p), ("scratch_clean", C.c_int32), ("reserved2_", C.c_int32)]
+                ("reach", C.c_void_p), ("scratch_clean", C.c_int32), ("zero_outside", C.c_int32)]
 
 
 class GsrAdamGroup(C.Structure):
@@ -143,7 +143,7 @@ SYMBOLS = [
     ("gsr_rowmsg_reduce", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p,
                                     C.c_uint32, C.c_void_p]),
     ("gsr_rowmsg_apply_slices", C.c_int, [C.POINTER(GsrRowSet), C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p,
-                                          C.c_void_p]),
+                                          C.c_void_p, C.c_void_p]),
     ("gsr_knn_scratch_bytes", C.c_size_t, [C.c_int32]),
     ("gsr_knn_mean_dist2", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("gsr_backward", C.c_int, [C.POINTER(GsrView), C.POINTER(GsrGaussians), C.POINTER(GsrGeom), C.POINTER(GsrBinning),

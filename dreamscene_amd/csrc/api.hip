@@ -386,6 +386,8 @@ static int check_backward(const GsrView* v, const GsrGaussians* g, const GsrGeom
   if (!b->tile_work || !img->tile_depth || !img->ckpt || !img->color || !img->depth_alpha) return GSR_EINVAL;
   if (!out->partials || !aligned16(out->partials)) return GSR_EINVAL;
   if (out->scratch_clean && !out->reach) return GSR_EINVAL;
+  if (out->zero_outside & ~3) return GSR_EINVAL;
+  if (out->zero_outside && (!out->reached_mask || out->accumulate)) return GSR_EINVAL;   // (the mask is what says which rows to clear)
   if (out->reach && (reinterpret_cast<uintptr_t>(out->reach) & 7u)) return GSR_EINVAL;
   {
     const int n_stat = (out->stat_max_radii2D != nullptr) + (out->stat_xyz_gradient_accum != nullptr) +

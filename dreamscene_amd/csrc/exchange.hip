@@ -480,7 +480,7 @@ k_msg_apply(const Regions r, const unsigned char* __restrict__ msgs, const size_
   };
   const unsigned char* data = slice_rows > 0 ? msgs + (size_t)y * msg_stride : msgs;
   const unsigned long long U = msg_merge_word<MERGE, VW>(data, msg_stride, slice_rows > 0 ? 1 : W, w, lay, r.F, c_magic, ubits_s[wave], put);
-  if (touched && U && lane == 0) touched[(row0 >> 6) + w] = U;
+  if (touched && lane == 0) touched[(row0 >> 6) + w] = U;        // (the word of the union, zero included)
 }
 
 // Messages -> message: the OWNER side of the sparse reduce-scatter. The W messages describe the same slice (one from every rank);
@@ -724,9 +724,9 @@ int gsr_rowmsg_apply(const GsrRowSet* rs, const void* msgs, uint64_t msg_stride,
 }
 
 int gsr_rowmsg_apply_slices(const GsrRowSet* rs, const void* msgs, uint64_t msg_stride, int32_t n_slices, int32_t slice_rows,
-                            uint32_t cap, uint64_t* status, void* stream_) {
+                            uint32_t cap, uint64_t* status, uint64_t* touched, void* stream_) {
   if (slice_rows <= 0) return GSR_EINVAL;
-  return rowmsg_apply(rs, msgs, msg_stride, n_slices, slice_rows, cap, status, nullptr, stream_);
+  return rowmsg_apply(rs, msgs, msg_stride, n_slices, slice_rows, cap, status, touched, stream_);
 }
 
 int gsr_rowmsg_reduce(int32_t rows, int32_t layout_rows, int32_t row_floats, const void* msgs, uint64_t msg_stride, int32_t n_msgs,

@@ -1506,6 +1506,7 @@ __device__ __forceinline__ void block_zero(float* __restrict__ dst, int n) {
 // 16-byte store never straddles into a skipped row (F % 4 == 0 and dst 16-byte aligned, or 4-byte stores)
 template <int F>
 __device__ __forceinline__ void wave_zero_rows(float* __restrict__ dst, int n, unsigned long long skip, int lane) {
+  if ((~skip & (n >= 64 ? ~0ull : ((1ull << n) - 1ull))) == 0ull) return;       // (uniform: nothing to clear in this chunk)
   if constexpr (F % 4 == 0) {
     constexpr int Q = F / 4;
     float4* d = reinterpret_cast<float4*>(dst);
@@ -1530,6 +1531,8 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
   __shared__ unsigned long long lmask[REACHED ? 4 * kPer : 1];   // reached Gaussians of the 64-row chunk (slice, wave)
   __shared__ unsigned long long vmask[REACHED ? GSR_MAX_BATCH_VIEWS : 1][REACHED ? 4 * kPer : 1];   // ... per view (K7's marks)
   __shared__ uint32_t zero_next;                                  // next chunk nobody has cleared yet
+  // GsrGrads.zero_outside: rows of chunk c that MAY be non-zero on entry (the previous writer's reached_mask; all ones: unknown)
+  __shared__ unsigned long long omask[REACHED ? 4 * kPer : 1];
   constexpr int F = 3 * KT;
   const int W = v.image_width, H = v.image_height;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1608,6 +1611,12 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
 #pragma unroll
     for (int t = 0; t < kPer; ++t)
       if (lane == 0) { wcnt[t * 4 + wave] = (uint32_t)__popcll(rmask[t]); lmask[t * 4 + wave] = rmask[t]; }
+    if (tid < 4 * kPer) {
+      // (the old word of chunk c is read here, by the workgroup that owns the chunk, before wave_exit stores the new one)
+      const int64_t r0 = chunk_base(tid);
+      omask[tid] = (out.zero_outside && !out.accumulate && out.reached_mask && r0 < P)
+                       ? reinterpret_cast<const unsigned long long*>(out.reached_mask)[r0 >> 6] : ~0ull;
+    }
     if (tid == 0) zero_next = 0u;
     GSR_K8_STAMP();   // 1: classified
     __syncthreads();
@@ -1723,7 +1732,11 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
       const int64_t r0 = chunk_base((int)c);
       const int n = (int)max((int64_t)0, min((int64_t)64, P - r0));
       if (n == 0) continue;
-      const unsigned long long skip = lmask[c];
+      // rows to clear: the ones nothing reached now -- of those, with GsrGrads.zero_outside, only the ones the previous writer
+      // of these buffers reached (everything else is zero already)
+      const unsigned long long known0 = out.accumulate ? 0ull : ~omask[c];
+      const unsigned long long skip = lmask[c] | ((out.zero_outside & 1) ? known0 : 0ull);
+      const unsigned long long skip_pv = lmask[c] | ((out.zero_outside & 2) ? known0 : 0ull);
       if (!out.accumulate) {
         wave_zero_rows<F>(out.dL_dshs + r0 * F, n, skip, lane);
         wave_zero_rows<3>(out.dL_dmeans3D + r0 * 3, n, skip, lane);
@@ -1735,8 +1748,8 @@ k_preprocess_bwd_views(const GsrView v, const GsrGaussians g, const K8Views vb, 
 #ifdef GSR_K8_STAMPS
         if (c == 0 && vv == 0) continue;        // (the stamps are left there)
 #endif
-        wave_zero_rows<3>(vb.dL_dmeans2D[vv] + r0 * 3, n, skip, lane);
-        if constexpr (PVS) wave_zero_rows<3>(vb.dL_dscales[vv] + r0 * 3, n, skip, lane);
+        wave_zero_rows<3>(vb.dL_dmeans2D[vv] + r0 * 3, n, skip_pv, lane);
+        if constexpr (PVS) wave_zero_rows<3>(vb.dL_dscales[vv] + r0 * 3, n, skip_pv, lane);
       }
     }
   };

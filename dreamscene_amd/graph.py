@@ -352,31 +352,87 @@ class CapturedViews(torch.nn.Module):
         dev = cap.g_color.device
         with torch.cuda.device(dev):
             # run it once eagerly: allocates the result tensors (kept as the static ones) and validates the arguments
+            # (persistent: the result tensors stay this capture's and nothing else writes them between replays -- K8 then clears
+            #  only the rows the previous replay reached, GsrGrads.zero_outside; _trusted checks the premise before every replay and
+            #  a replay it does not hold for takes the graph captured without it)
             o = R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
                                                accumulate=rc.accumulate, stats=None, per_view_scales=per_view,
-                                               private_scratch=True)
+                                               private_scratch=True, persistent=True)
             torch.cuda.synchronize(dev)
             with torch.cuda.graph(cap.gC, pool=cap.gF.pool(), capture_error_mode="thread_local"):
+                oc = R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
+                                                    accumulate=rc.accumulate, stats=rc.densify_stats,
+                                                    stats_views=rc.stats_views, per_view_scales=per_view, reuse=o)
+            cap.bwd = o
+            cap.bwd_zo = int(oc["_zero_outside"])       # what graph C's K8 takes for granted about the result tensors
+            cap.gC0 = None                              # graph C without that premise (captured when first needed)
+            cap.bwd_versions = self._result_versions(cap, rc)
+            self.stats["bwd_zero_outside"] = cap.bwd_zo
+            cap.direct = {}          # (upstream-gradient addresses, premise) -> (graph C reading the caller's tensors, its zero_outside)
+
+    _RESULTS = ("dL_dmeans3D", "dL_dopacities", "dL_dshs", "dL_dscales", "dL_drotations")
+
+    @classmethod
+    def _result_versions(cls, cap: _Captured, rc):
+        """Version counters of the result tensors this capture owns: the per-view rows, and -- without an arena -- the summed
+        gradients (an arena answers for itself: GradArena.zero_outside_ok)."""
+        o = cap.bwd
+        own = [o["_m2d"]] + ([o["dL_dscales"]] if cap.per_view and o.get("dL_dscales") is not None else [])
+        if rc.grad_arena is None:
+            own += [o[k] for k in cls._RESULTS if o.get(k) is not None]
+        return tuple(t._version for t in own)
+
+    def _trusted(self, cap: _Captured, rc, zo: int) -> bool:
+        """Does what a K8 captured with GsrGrads.zero_outside = zo takes for granted hold right now? Normally yes: the result
+        tensors hold what the previous replay wrote. Not after the arena went through a dense exchange or another writer
+        (GradArena.zero_outside_ok), another module left its bitmap in the arena, or the caller edited a returned gradient in place
+        (version counters)."""
+        if not zo:
+            return True
+        arena = rc.grad_arena
+        if self._result_versions(cap, rc) != cap.bwd_versions:
+            return False
+        if arena is not None:
+            if (zo & 1) and not arena.zero_outside_ok():
+                return False
+            if (zo & 2) and getattr(arena, "_mask_owner", None) is not cap.bwd["_token"]:
+                return False
+        return True
+
+    def _static_graph(self, cap: _Captured, rc, per_view, trusted: bool):
+        if trusted or not cap.bwd_zo:
+            return cap.gC
+        if cap.gC0 is None:
+            cap.gC0 = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(cap.g_color.device)
+            with torch.cuda.graph(cap.gC0, pool=cap.gF.pool(), capture_error_mode="thread_local"):
                 R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
                                                accumulate=rc.accumulate, stats=rc.densify_stats, stats_views=rc.stats_views,
-                                               per_view_scales=per_view, reuse=o)
-            cap.bwd = o
-            cap.direct = {}          # upstream-gradient addresses -> graph C reading the caller's tensors directly
+                                               per_view_scales=per_view, reuse=cap.bwd, trust_zeros=False)
+        return cap.gC0
 
-    def _direct_graph(self, cap: _Captured, gcs, gdas, rc, per_view):
+    def _replayed_backward(self, cap: _Captured, rc) -> None:
+        """Bookkeeping behind a replay of graph C (the launches ran without rasterize_backward_views_raw): the arena holds K8's
+        rows and bitmap again, and the result tensors what K8 wrote."""
+        if rc.grad_arena is not None:
+            R._arena_written(rc.grad_arena, bool(rc.accumulate), cap.bwd["_token"])
+        cap.bwd_versions = self._result_versions(cap, rc)
+
+    def _direct_graph(self, cap: _Captured, gcs, gdas, rc, per_view, trusted: bool):
         """A loss written in torch produces its gradients at the same addresses step after step (the caching allocator
         returns the blocks it was just given back), so graph C is also captured over the CALLER'S gradient tensors: when
         the addresses repeat nothing is copied (80 MB per 4-view step at 1024^2). The tensors are only read while the
         backward that received them runs (stream order), exactly like the eager path reads them."""
-        key = tuple(t.data_ptr() for t in gcs + gdas)
+        key = tuple(t.data_ptr() for t in gcs + gdas) + (bool(trusted or not cap.bwd_zo),)
         g = cap.direct.get(key)
         if g is None and len(cap.direct) < MAX_DIRECT_GRAPHS:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(cap.g_color.device)
             with torch.cuda.graph(g, pool=cap.gF.pool(), capture_error_mode="thread_local"):
-                R.rasterize_backward_views_raw(cap.states, gcs, gdas, arena=rc.grad_arena, accumulate=rc.accumulate,
-                                               stats=rc.densify_stats, stats_views=rc.stats_views,
-                                               per_view_scales=per_view, reuse=cap.bwd)
+                oc = R.rasterize_backward_views_raw(cap.states, gcs, gdas, arena=rc.grad_arena, accumulate=rc.accumulate,
+                                                    stats=rc.densify_stats, stats_views=rc.stats_views,
+                                                    per_view_scales=per_view, reuse=cap.bwd, trust_zeros=trusted)
+            g = (g, int(oc["_zero_outside"]))
             cap.direct[key] = g
             self.stats["captures_bwd_direct"] = self.stats.get("captures_bwd_direct", 0) + 1
         return g
@@ -400,9 +456,11 @@ class CapturedViews(torch.nn.Module):
             gdas = [grads[3 * k + 2] for k in range(V)]
             usable = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.data_ptr() % 4 == 0
                          for g in gcs + gdas)
-            g_direct = self._direct_graph(cap, gcs, gdas, rc, per_view) if usable else None
-            if g_direct is not None:
-                g_direct.replay()
+            trusted = self._trusted(cap, rc, cap.bwd_zo)
+            g_direct = self._direct_graph(cap, gcs, gdas, rc, per_view, trusted) if usable else None
+            if g_direct is not None and self._trusted(cap, rc, g_direct[1]):
+                g_direct[0].replay()
+                self._replayed_backward(cap, rc)
                 return cap.bwd
             dst, src = [], []
             for k in range(V):
@@ -414,5 +472,6 @@ class CapturedViews(torch.nn.Module):
                         src.append(g)
             if dst:
                 torch._foreach_copy_(dst, src)
-            cap.gC.replay()
+            self._static_graph(cap, rc, per_view, trusted).replay()
+            self._replayed_backward(cap, rc)
         return cap.bwd

@@ -40,10 +40,23 @@ class GradArena:
         # rows. Valid only while the HIP backward is what fills the arena: anything else that writes `flat` calls touch().
         self.reached = torch.zeros((P + 63) // 64, dtype=torch.int64, device=device)
         self.reached_valid = False
+        # "every row outside `reached` is zero" (GsrGrads.zero_outside): true of a fresh arena (all zero, empty bitmap) and kept
+        # by every HIP backward that overwrites the arena; K8 then clears only the rows the bitmap names instead of everything
+        # nothing reached (84 % of the rows at C3). A torch op that writes `flat` (or a view of it) in place shows in the
+        # version counter; anything that writes it through raw pointers calls touch().
+        self.zero_outside_reached = True
+        self._k8_version = self.flat._version
+        self._mask_owner = None       # whose per-view rows the bitmap describes as well (rasterize_backward_views_raw, `persistent`)
 
     def touch(self) -> None:
         """The arena was written by something other than the HIP backward: the reached-row bitmap no longer describes it."""
         self.reached_valid = False
+        self.zero_outside_reached = False
+
+    def zero_outside_ok(self) -> bool:
+        """Are the rows outside the reached bitmap known to be zero? (nothing but the HIP backward wrote the arena since the
+        bitmap was left)"""
+        return self.zero_outside_reached and self.flat._version == self._k8_version
 
     def reached_rows(self) -> Optional[torch.Tensor]:
         """Ascending indices of the Gaussians whose row MAY be non-zero (a superset of the non-zero rows), from the bitmap
@@ -237,24 +250,27 @@ class _RowMessages:
             self.L.check(self.lib.gsr_rowmsg_reduce(int(rows_here), int(slice_rows), int(F), self.recv1.data_ptr(), self.n1, int(W),
                                                     int(cap1), self.own2.data_ptr(), int(cap2), self._stream()), "gsr_rowmsg_reduce")
 
-    def apply_slices(self, rs, W: int, slice_rows: int, cap2: int) -> None:
+    def apply_slices(self, rs, W: int, slice_rows: int, cap2: int, touched: Optional[torch.Tensor] = None) -> None:
         self.status_np[0] = self.PENDING
         self.armed = True
         with torch.cuda.device(self.dev):
             self.L.check(self.lib.gsr_rowmsg_apply_slices(rs, self.all2.data_ptr(), self.n2, int(W), int(slice_rows), int(cap2),
-                                                          self.status.data_ptr(), self._stream()), "gsr_rowmsg_apply_slices")
+                                                          self.status.data_ptr(),
+                                                          touched.data_ptr() if touched is not None else None, self._stream()),
+                         "gsr_rowmsg_apply_slices")
 
     def pack(self, rs, mask: torch.Tensor, cap: int) -> None:
         with torch.cuda.device(self.dev):
             self.L.check(self.lib.gsr_rowmsg_pack(rs, mask.data_ptr(), self.msg.data_ptr(), int(cap),
                                                   torch.cuda.current_stream(self.dev).cuda_stream), "gsr_rowmsg_pack")
 
-    def apply(self, rs, W: int, cap: int) -> None:
+    def apply(self, rs, W: int, cap: int, touched: Optional[torch.Tensor] = None) -> None:
         self.status_np[0] = self.PENDING
         self.armed = True
         with torch.cuda.device(self.dev):
             self.L.check(self.lib.gsr_rowmsg_apply(rs, self.all.data_ptr(), self.nbytes, int(W), int(cap), self.status.data_ptr(),
-                                                   None, torch.cuda.current_stream(self.dev).cuda_stream), "gsr_rowmsg_apply")
+                                                   touched.data_ptr() if touched is not None else None,
+                                                   torch.cuda.current_stream(self.dev).cuda_stream), "gsr_rowmsg_apply")
 
     def result(self):
         """(applied, largest count) of the last apply(); waits for the apply kernel to START (not for it to finish)."""
@@ -455,11 +471,19 @@ class GradExchange:
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             return ExchangeHandle(ev, dev)
+        kept = self.arena.flat._version == getattr(self.arena, "_k8_version", None) and \
+            getattr(self.arena, "zero_outside_reached", False)
         try:
             self._reduce()
         finally:
             if self.last.get("format") != "none":
                 self.arena.touch()
+                if kept and self.last.get("device") and self.last.get("union_bitmap"):
+                    # The message forms store the union of the ranks' rows and leave its bitmap in arena.reached (or nothing at
+                    # all, when a message overflowed): rows outside the bitmap are as zero as they were before -- the next
+                    # backward may keep clearing only what the bitmap names (GsrGrads.zero_outside). The bitmap no longer says
+                    # what THIS rank has to send (reached_valid stays False until the next backward).
+                    self.arena.zero_outside_reached = True
         return ExchangeHandle(None, None) if async_op else None
 
     def finish(self) -> bool:
@@ -516,10 +540,11 @@ class GradExchange:
             _all_to_all_single(recv1, send1, self.group)
             self._msgs.reduce_owned(rows_here, per, F, W, cap1, cap2)
             _all_gather_into(all2, own2, self.group)
-            self._msgs.apply_slices(rs, W, per, cap2)
+            # (touched: the owners' bitmaps side by side = the union over the ranks, left in the arena's own bitmap -- _kept_sparse)
+            self._msgs.apply_slices(rs, W, per, cap2, touched=self.arena.reached)
             self._settle = "sparse_rs"
             self.last = dict(format="sparse_rs", device=True, row_floats=F, cap_rows=[cap1, cap2], host_reads=0,
-                             bytes_per_rank=int((W - 1) * (self._msgs.n1 + self._msgs.n2)))
+                             bytes_per_rank=int((W - 1) * (self._msgs.n1 + self._msgs.n2)), union_bitmap=True)
             if not self.strict:
                 return
             ok, worst = self._msgs.result()
@@ -551,10 +576,10 @@ class GradExchange:
             msg, allm, nbytes = self._msgs.buffers(P, F, W, cap)
             self._msgs.pack(rs, self.arena.reached, cap)
             _all_gather_into(allm, msg, self.group)
-            self._msgs.apply(rs, W, cap)
+            self._msgs.apply(rs, W, cap, touched=self.arena.reached)       # (the union bitmap: _kept_sparse)
             self._settle = "rows"
             self.last = dict(format="rows", device=True, row_floats=F, cap_rows=cap, bytes_per_rank=int((W - 1) * nbytes),
-                             host_reads=0)
+                             host_reads=0, union_bitmap=True)
             if not self.strict:
                 return
             ok, worst = self._msgs.result()

@@ -738,6 +738,30 @@ def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, mod
     return o
 
 
+def _arena_zero_outside(arena, accumulate: bool) -> int:
+    """GsrGrads.zero_outside bit 0 for a backward that OVERWRITES the arena: its rows outside the reached bitmap are known to be
+    zero (GradArena.zero_outside_reached) -- K8 clears what the bitmap names and nothing else."""
+    if arena is None or accumulate or getattr(arena, "reached", None) is None:
+        return 0
+    ok = getattr(arena, "zero_outside_ok", None)
+    return 1 if (ok is not None and ok()) else 0
+
+
+def _arena_written(arena, accumulate: bool, token=None) -> None:
+    """Bookkeeping behind a HIP backward into the arena: K8 left the bitmap of the rows it reached (OR-ed into it when
+    accumulating) and, when it overwrote, zeros everywhere else. token: the persistent result dict whose per-view rows the new
+    bitmap describes as well (an OR-ed bitmap stays a superset of whatever it described)."""
+    if arena is None or getattr(arena, "reached", None) is None:
+        return
+    arena.reached_valid = True
+    if not accumulate:
+        arena.zero_outside_reached = True
+        arena._k8_version = arena.flat._version
+        arena._mask_owner = token
+    elif arena.flat._version != getattr(arena, "_k8_version", None):
+        arena.zero_outside_reached = False        # (K8 added to rows a torch op had written)
+
+
 def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool = False, arena=None,
                            accumulate: bool = False, model_grads=None, dL_dscales_out=None, stats=None,
                            profile=None) -> dict:
@@ -776,7 +800,7 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
     gr.accumulate = int(bool(accumulate and arena is not None))
     if arena is not None and getattr(arena, "reached", None) is not None:
         gr.reached_mask = arena.reached.data_ptr()      # K8 marks the rows an exchange has to move (GradArena.reached_rows)
-        arena.reached_valid = True
+        gr.zero_outside = _arena_zero_outside(arena, gr.accumulate != 0)
     _bind_stats(gr, stats, P, dev)
     ig = L.GsrImageGrads()
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
@@ -791,6 +815,9 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
         ok = True
     finally:
         scratch.end(ok)
+        if not ok and arena is not None:
+            arena.touch()
+    _arena_written(arena, gr.accumulate != 0)
     return o
 
 
@@ -852,12 +879,18 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
 
 def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=None, accumulate: bool = False,
                                  stats=None, stats_views=None, per_view_scales: Optional[bool] = None,
-                                 profile=None, reuse: Optional[dict] = None, private_scratch: bool = False) -> dict:
+                                 profile=None, reuse: Optional[dict] = None, private_scratch: bool = False,
+                                 persistent: bool = False, trust_zeros: bool = True) -> dict:
     """Backward of several views of the same Gaussians through gsr_backward_views: K7 per view, one K8 pass over all
     views. Returns the SUMMED parameter gradients (written to / added to the arena's views when given) and the per-view
     means2D gradients [V,P,3]. per_view_scales (default: whether the views' scales are different tensors): every view has
     its own scales tensor, `dL_dscales` is then [V,P,3]. reuse: the dict a previous call with the same arguments returned --
-    its tensors receive the results again and nothing is allocated (graph capture, graph.py)."""
+    its tensors receive the results again and nothing is allocated (graph capture, graph.py).
+    persistent: the caller keeps the returned dict and hands it back as `reuse`, writing NOTHING into its tensors in between (or
+    zeroing them all if something did): the dict then carries a reached-row bitmap of its own (without an arena) and calls with
+    `reuse` run with GsrGrads.zero_outside -- K8 clears the rows the previous call reached and this one does not, instead of
+    everything nothing reached (118 + 24 MB of zeros per 4-view step at C3). trust_zeros=False: never (the call clears every row
+    nothing reached, whatever is known about the tensors)."""
     lib = L.load()
     V = len(states)
     st0 = states[0]
@@ -878,9 +911,11 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
     names = ("dL_dmeans3D", "dL_dopacities", "dL_dshs", "dL_dcolors", "dL_dscales", "dL_drotations", "dL_dcov3D")
     if per_view_scales is None:
         per_view_scales = any(st.gauss.scales != g.scales for st in states)
+    own_mask = None
     if reuse is not None:
         o = {k: reuse[k] for k in names}
         m2d, scratch = reuse["_m2d"], reuse["_scratch"]
+        own_mask = reuse.get("_reached")
     else:
         o = dict(dL_dmeans3D=new(P, 3, name="means3D"), dL_dopacities=new(P, 1, name="opacities"),
                  dL_dshs=new(P, K, 3, name="shs") if g.shs else None, dL_dcolors=new(P, 3) if g.colors_precomp else None,
@@ -894,6 +929,19 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         #  captured K7 / K8 pair maintains the all-zero invariant like an eager one; private_scratch: that call asks for a
         #  scratch of its own instead of the cached one eager calls share)
         scratch = _scratch_acquire(dev, V, P, private=private_scratch)
+        if persistent and arena is None:
+            own_mask = torch.zeros((P + 63) // 64, dtype=torch.int64, device=dev)
+    # GsrGrads.zero_outside: bit 0 the summed gradients (the arena, or a persistent dict's own tensors), bit 1 the per-view rows
+    # (only a persistent dict keeps those)
+    acc = bool(accumulate and arena is not None)
+    token = reuse.get("_token") if reuse is not None else (object() if persistent else None)
+    has_mask = (arena is not None and getattr(arena, "reached", None) is not None) or own_mask is not None
+    # (with an arena the bitmap is the ARENA's: it describes this dict's per-view rows only if this dict's call wrote it last)
+    keeps = reuse is not None and token is not None and not acc and has_mask and \
+        (arena is None or getattr(arena, "_mask_owner", None) is token)
+    zo = (_arena_zero_outside(arena, acc) if arena is not None else (1 if keeps else 0)) | (2 if keeps else 0)
+    if not trust_zeros:
+        zo = 0
     views = (L.GsrView * V)(*[st.view for st in states])
     gauss = (L.GsrGaussians * V)(*[st.gauss for st in states])
     geoms = (L.GsrGeom * V)(*[st.geom for st in states])
@@ -915,10 +963,13 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
             grs[k].dL_dscales = o["dL_dscales"][k].data_ptr()
         grs[k].dL_dmeans2D = m2d[k].data_ptr()
         _bind_scratch(grs[k], scratch, k)
-        grs[k].accumulate = int(bool(accumulate and arena is not None))
+        grs[k].accumulate = int(acc)
         if arena is not None and getattr(arena, "reached", None) is not None:
             grs[k].reached_mask = arena.reached.data_ptr()
-            arena.reached_valid = True
+            grs[k].zero_outside = zo
+        elif own_mask is not None:
+            grs[k].reached_mask = own_mask.data_ptr()
+            grs[k].zero_outside = zo
         if k in counted:
             _bind_stats(grs[k], stats, P, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -932,8 +983,12 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         ok = True
     finally:
         scratch.end(ok)
+        if not ok and arena is not None:
+            arena.touch()
+    _arena_written(arena, acc, token)
     o["dL_dmeans2D"] = m2d[:, :P]
     o["_m2d"], o["_scratch"] = m2d, scratch
+    o["_reached"], o["_token"], o["_zero_outside"] = own_mask, token, zo
     return o
 
 

@@ -28,6 +28,21 @@ def test_library_builds_and_exports_header_symbols(built_lib):
     assert set(names) == bound, f"ctypes binding and header disagree: {set(names) ^ bound}"
 
 
+def test_ctypes_signatures_have_the_header_s_parameter_counts():
+    """A binding with one argument too few still calls -- with the stream in the wrong slot (it happened: gsr_rowmsg_apply_slices
+    gained `touched` in the header and not in _lib.SYMBOLS, and the first call crashed the process)."""
+    from dreamscene_amd import _lib
+    src = open(os.path.join(ROOT, "include", "gsrast.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decl = {}
+    for name, args in re.findall(r"\b(gsr_[a-z_0-9]+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        args = " ".join(args.split())
+        decl[name] = 0 if args in ("", "void") else args.count(",") + 1
+    for name, _, argtypes in _lib.SYMBOLS:
+        assert name in decl, name
+        assert len(argtypes) == decl[name], f"{name}: {decl[name]} parameters in gsrast.h, {len(argtypes)} in _lib.SYMBOLS"
+
+
 def test_library_contains_gfx950_code_object(built_lib):
     from dreamscene_amd import _lib
     out = subprocess.run(["strings", "-n", "6", _lib.LIB_PATH], capture_output=True, text=True).stdout

@@ -158,9 +158,14 @@ def test_row_messages_give_the_rank_ordered_sum(built_lib, P, K, D, W, frac):
     for r in (0, W - 1):                       # every rank ends with the same bits
         a = arenas[r][0]
         own = a.flat.clone()
-        msgs.apply(ex[r]._arena_rowset(), W, cap)
+        union_bits = torch.full_like(a.reached, -1)           # (every word must be stored, the empty ones too)
+        msgs.apply(ex[r]._arena_rowset(), W, cap, touched=union_bits)
         ok, worst = msgs.result()
         assert ok and worst == max(counts)
+        want = torch.zeros_like(a.reached)
+        for q in range(W):
+            want |= arenas[q][0].reached
+        assert torch.equal(union_bits, want), f"rank {r}: the union bitmap apply leaves for the next backward (zero_outside)"
         for name in ("means3D", "scales", "rotations", "opacities"):
             assert torch.equal(a.views[name], ref.views[name]), f"rank {r}: {name}"
         assert torch.equal(a.views["shs"][:, :nb, :], ref.views["shs"][:, :nb, :]), f"rank {r}: active SH columns"
@@ -176,11 +181,12 @@ def test_row_messages_give_the_rank_ordered_sum(built_lib, P, K, D, W, frac):
             allm[r * nbytes:(r + 1) * nbytes].copy_(msg)
         a = arenas[0][0]
         own = a.flat.clone()
-        msgs.apply(ex[0]._arena_rowset(), W, small)
+        union_bits = torch.full_like(a.reached, -1)
+        msgs.apply(ex[0]._arena_rowset(), W, small, touched=union_bits)
         ok, worst = msgs.result()
         assert not ok and worst == max(counts)
         torch.cuda.synchronize()
-        assert torch.equal(a.flat, own)
+        assert torch.equal(a.flat, own) and bool((union_bits == -1).all())         # nothing applied: nothing stored
 
 
 @pytest.mark.parametrize("P,K,D,W,frac", [(1000, 16, 3, 3, 0.3), (64 * 37 + 5, 16, 1, 8, 0.4), (4099, 4, 1, 2, 0.05),
@@ -224,11 +230,17 @@ def test_slice_messages_give_the_sparse_reduce_scatter(built_lib, P, K, D, W, fr
             for o in range(W):
                 ms[r].all2[o * n2:(o + 1) * n2].copy_(ms[o].own2)
         res = []
+        want = torch.zeros_like(arenas[0][0].reached)
+        for q in range(W):
+            want |= arenas[q][0].reached
         for r in range(W):
-            ms[r].apply_slices(ex[r]._arena_rowset(), W, per, cap2)
+            union_bits = torch.full_like(want, -1)
+            ms[r].apply_slices(ex[r]._arena_rowset(), W, per, cap2, touched=union_bits)
             ok, worst = ms[r].result()
             res.append((ok, worst, ms[r].worst_in))
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            # the owners' bitmaps side by side = the union over the ranks (stored only if the messages were applied)
+            assert torch.equal(union_bits, want) if ok else bool((union_bits == -1).all()), f"rank {r}: union bitmap"
         return res
 
     own = [a.flat.clone() for a, _ in arenas]

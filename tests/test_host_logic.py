@@ -294,3 +294,28 @@ def test_exchange_slice_capacities(monkeypatch):
     lim = (ex._slice_rows(8) + 1023) // 1024 * 1024
     ex._grow_rs_caps(10 ** 8, 10 ** 8)
     assert ex._rs_caps == [lim, lim]
+
+
+def test_arena_knows_when_its_rows_outside_the_bitmap_are_zero():
+    """GradArena.zero_outside_ok (what lets K8 clear only the rows the reached bitmap names, GsrGrads.zero_outside): true of a fresh
+    arena and behind a HIP backward that overwrote it; a torch op on the arena or a view of it (version counter), touch(), or an
+    accumulate on top of a torch write end it; the next overwriting backward restores it."""
+    import torch
+    from dreamscene_amd import multiview, rasterizer as R
+    a = multiview.GradArena(100, 4, "cpu")
+    assert a.zero_outside_ok() and R._arena_zero_outside(a, False) == 1 and R._arena_zero_outside(a, True) == 0
+    a.views["shs"].mul_(2.0)
+    assert not a.zero_outside_ok() and R._arena_zero_outside(a, False) == 0
+    tok = object()
+    R._arena_written(a, False, tok)                 # (K8 writes through raw pointers: the counter stays)
+    assert a.zero_outside_ok() and a.reached_valid and a._mask_owner is tok
+    R._arena_written(a, True, None)                 # an accumulating view: the bitmap is OR-ed, its owner keeps it
+    assert a.zero_outside_ok() and a._mask_owner is tok
+    a.flat.add_(1.0)
+    R._arena_written(a, True, None)                 # ... on top of a torch write: nothing is known any more
+    assert not a.zero_outside_ok()
+    R._arena_written(a, False, None)
+    assert a.zero_outside_ok() and a._mask_owner is None
+    a.touch()
+    assert not a.zero_outside_ok() and not a.reached_valid
+    assert R._arena_zero_outside(None, False) == 0

@@ -90,3 +90,112 @@ def test_sparse_and_dense_workgroups_vs_oracle(built_lib, c_oracle):
     for j in range(4):
         a, r = grads[0][j].cpu().numpy().reshape(-1), ref_m2[j].reshape(-1)
         assert err(a, r) <= TOL * rel_scale(r), ("batched dL_dmeans2D", j)
+
+
+def _step_sets(n_sets=3):
+    """Camera sets whose reached rows differ (the previous set's rows must be cleared, not all of them)."""
+    from dreamscene_amd import synth
+    cams = synth.object_cameras(4 * n_sets + 1, H, W, radius=3.0)[1:]
+    return [cams[4 * s:4 * s + 4] for s in range(n_sets)]
+
+
+def _eager_step(rastmod, R, sets, t, ups, dev, arena):
+    """One 4-view step through GaussianRasterizerViews into `arena` (None: plain gradients) -> (param grads, means2D grads)."""
+    tt = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    rast = rastmod(sets, context=R.RasterContext(grad_arena=arena))
+    m2d = torch.zeros((4, P, 3), device=dev, requires_grad=True)
+    outs = rast(means3D=tt["means3D"], means2D=m2d, shs=tt["shs"], opacities=tt["opacities"], scales=tt["scales"],
+                rotations=tt["rotations"])
+    leaves = [m2d] if arena is not None else [m2d] + [tt[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    gr = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], leaves,
+                             [torch.tensor(y, device=dev) for k in range(4) for y in ups[k]])
+    torch.cuda.synchronize()
+    return gr
+
+
+def test_rows_known_to_be_zero_are_not_written_again(built_lib):
+    """GsrGrads.zero_outside: a backward that overwrites an arena whose rows outside the reached bitmap are known to be zero clears
+    only the rows the bitmap names. Same bits as the backward into a fresh arena, step after step with CHANGING cameras; a torch op
+    on the arena (version counter) or touch() brings the full clear back."""
+    from dreamscene_amd import multiview, rasterizer as R
+    from dreamscene_amd.views import GaussianRasterizerViews
+    from dreamscene_amd import synth
+    g = _scene()
+    bg = np.array([0.1, 0.3, 0.9], np.float32)
+    dev = torch.device(DEV)
+    ups = [synth.upstream_grads(H, W, seed=k) for k in range(4)]
+    t = {k: torch.tensor(v, device=DEV) for k, v in g.items()}
+    camsets = _step_sets(3)
+    arena = multiview.GradArena(P, K, dev)
+    masks = []
+    for step, cs in enumerate(camsets + camsets[:1]):
+        sets = [settings_for(c, bg, D, dev) for c in cs]
+        assert arena.zero_outside_ok() == (step != 2), step
+        m2 = _eager_step(GaussianRasterizerViews, R, sets, t, ups, dev, arena)
+        fresh = multiview.GradArena(P, K, dev)
+        fresh.flat.fill_(5.0)                    # (a torch write: the reference run clears everything)
+        assert not fresh.zero_outside_ok()
+        m2_ref = _eager_step(GaussianRasterizerViews, R, sets, t, ups, dev, fresh)
+        assert torch.equal(arena.flat, fresh.flat), f"step {step}: arena differs from the fully cleared one"
+        assert torch.equal(arena.reached, fresh.reached), step
+        assert torch.equal(m2[0], m2_ref[0]), step
+        masks.append(arena.reached.clone())
+        if step == 1:
+            arena.views["shs"].mul_(2.0)         # a torch op on a view of the arena: the next backward must not trust the bitmap
+    assert not torch.equal(masks[0], masks[1]), "the camera sets were meant to reach different rows"
+    arena.touch()
+    assert not arena.zero_outside_ok()
+
+
+@pytest.mark.parametrize("with_arena", [True, False])
+def test_captured_backward_keeps_its_results_sparse(built_lib, with_arena):
+    """graph.CapturedViews owns its gradient tensors: graph C's K8 is captured with zero_outside and every replay is checked
+    against the eager module on a fresh arena -- with changing cameras, a foreign write into the arena between two replays, an
+    in-place edit of a returned gradient, and another module writing the same arena in between."""
+    from dreamscene_amd import graph, multiview, rasterizer as R, synth
+    from dreamscene_amd.views import GaussianRasterizerViews
+    g = _scene()
+    bg = np.array([0.1, 0.3, 0.9], np.float32)
+    dev = torch.device(DEV)
+    ups = [synth.upstream_grads(H, W, seed=k) for k in range(4)]
+    up_t = [torch.tensor(y, device=dev) for k in range(4) for y in ups[k]]
+    t = {k: torch.tensor(v, device=DEV) for k, v in g.items()}
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    leaves = {k: t[k].clone().requires_grad_(True) for k in names}
+    arena = multiview.GradArena(P, K, dev) if with_arena else None
+    rast = graph.CapturedViews(context=R.RasterContext(grad_arena=arena))
+    camsets = _step_sets(3)
+    order = [0, 0, 0, 1, 2, 0, 1, 1, 2, 0]        # (the first calls are eager warm-ups, then the capture)
+    for it, si in enumerate(order):
+        sets = [settings_for(c, bg, D, dev) for c in camsets[si]]
+        m2d = torch.zeros((4, P, 3), device=dev, requires_grad=True)
+        outs = rast(sets, means3D=leaves["means3D"], means2D=m2d, shs=leaves["shs"], opacities=leaves["opacities"],
+                    scales=leaves["scales"], rotations=leaves["rotations"])
+        flat = [x for (img, _, da) in outs for x in (img, da)]
+        if with_arena:
+            got = torch.autograd.grad(flat, [m2d], up_t)
+            got_params = arena.flat.clone()
+        else:
+            got = torch.autograd.grad(flat, [m2d] + [leaves[k] for k in names], up_t)
+        torch.cuda.synchronize()
+        fresh = multiview.GradArena(P, K, dev)
+        fresh.flat.fill_(-1.0)
+        ref_m2 = _eager_step(GaussianRasterizerViews, R, sets, t, ups, dev, fresh)
+        assert torch.equal(got[0], ref_m2[0]), f"call {it}: dL_dmeans2D"
+        if with_arena:
+            assert torch.equal(got_params, fresh.flat), f"call {it}: arena"
+        else:
+            for k, gk in zip(names, got[1:]):
+                assert torch.equal(gk.reshape(-1), fresh.views[k].reshape(-1)), f"call {it}: dL_d{k}"
+        # what a caller may do between two steps
+        if it == 5:
+            if with_arena:
+                arena.flat.add_(3.0)                         # a torch write into the arena
+            else:
+                got[1].add_(3.0)                             # an in-place edit of a returned gradient (the capture's own tensor)
+        if it == 6:
+            got[0].mul_(2.0)                                 # ... of the per-view rows
+        if it == 7 and with_arena:
+            _eager_step(GaussianRasterizerViews, R, [settings_for(c, bg, D, dev) for c in camsets[0]], t, ups, dev, arena)
+    st = rast.stats
+    assert st["replays"] >= 5, st

@@ -77,6 +77,13 @@ def _worker(rank, world, port, mode, out_dir):
     for step in range(3 if lazy else 2):   # (the second one runs the batched launches; lazy sparse_rs learns two capacities)
         outs, g2d = _render_into_arena(params, cams, ups, mine, arena, dev)
         own = arena.flat.clone()
+        if step > 0:
+            # the arena went through an exchange: K8 may only skip the rows the union bitmap does not name (GsrGrads.zero_outside
+            # behind the message forms), and must have cleared everything after the others -- same bits as into a fresh arena
+            fresh = multiview.GradArena(P, K, dev)
+            fresh.flat.fill_(3.0)
+            _render_into_arena(params, cams, ups, mine, fresh, dev)
+            assert torch.equal(own, fresh.flat), f"step {step}: this rank's gradients differ from a backward into a fresh arena"
         if lazy:
             # the statistics all-reduce on the caller's stream beside the exchange on its own (multiview.reduce_step)
             radii = outs[-1][1]
