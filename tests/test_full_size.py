@@ -403,6 +403,64 @@ def test_c2_vs_the_independent_float64_autograd_oracle(built_lib):
         assert n_over <= 4 and float(e.max()) <= 1e-4 * sc, f"{hk}: {n_over} entries beyond 1e-5, max {e.max() / sc:.2e}"
 
 
+def _window_vs_float64(P, res, win, init_opacity, radii_allow, min_depth, label, threads, flips_allow=4, beside_fp32=False):
+    """The HIP path against the independent float64 autograd oracle on a crop: the full scene and camera, the loss restricted to the
+    pixels of the tile window `win` (upstream gradients zero elsewhere), the oracle compositing only those tiles."""
+    from dreamscene_amd import rasterizer as R, synth
+    from tests.test_oracle_consistency import _torch_run
+    K, D = 16, 3
+    y0, y1, x0, x1 = win[0] * 16, win[1] * 16, win[2] * 16, win[3] * 16
+    g = synth.g_object(P, seed=0, K=K, init_opacity=init_opacity)
+    cam = synth.object_cameras(1, res, res)[0]
+    bg = np.ones(3, np.float32)
+    gi, gda = synth.upstream_grads(res, res, 0)
+    mask = np.zeros((res, res), np.float32)
+    mask[y0:y1, x0:x1] = 1.0
+    gi, gda = gi * mask, gda * mask
+    torch.set_num_threads(min(threads, max(1, (os.cpu_count() or 2) // 2)))
+    r = _torch_run(g, cam, bg, D, gi=gi, gda=gda, cam_grad=False, tile_window=win)
+    # beside_fp32: the same independent restatement evaluated in float32 -- how far ANY fp32 evaluation of the algorithm is from
+    # float64 in this state (hard gates taken the other way: everything behind them on that pixel moves)
+    r32 = _torch_run(g, cam, bg, D, dt=torch.float32, gi=gi, gda=gda, cam_grad=False, tile_window=win) if beside_fp32 else None
+    t = {k: torch.tensor(v, device=DEV) for k, v in g.items()}
+    out, st = _forward(t, cam, bg, D, want_keys=False)
+    o = R.rasterize_backward_raw(st, torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV))
+    torch.cuda.synchronize()
+    dr = np.abs(out["radii"].cpu().numpy().astype(np.int64) - r["radii"].astype(np.int64))
+    assert dr.max() <= 1 and int((dr > 0).sum()) <= radii_allow, (int(dr.max()), int((dr > 0).sum()))
+    nc = out["n_contrib"].cpu().numpy().view(np.uint32)[y0:y1, x0:x1]
+    assert int(nc.max()) > min_depth, int(nc.max())                                # the window IS deep
+    assert int((nc != r["aux"]["n_contrib"][y0:y1, x0:x1]).sum()) <= 8
+    d_img = np.abs(out["color"].cpu().numpy().astype(np.float64) - r["img"]).max(axis=0)[y0:y1, x0:x1]
+    n_img = int((d_img > 1e-5).sum())
+    print(f"[{label} vs float64 autograd] image: {n_img} pixels beyond 1e-5 (max {d_img.max():.1e}), "
+          f"{float(nc.mean()):.0f} splats blended per pixel")
+    assert n_img <= flips_allow and float(d_img.max()) <= 4e-3, (n_img, float(d_img.max()))
+    d_da = np.abs(out["depth_alpha"].cpu().numpy().astype(np.float64) - r["da"]).max(axis=0)[y0:y1, x0:x1]
+    sc_da = rel_scale(r["da"])
+    assert int((d_da > 1e-5 * sc_da).sum()) <= flips_allow and float(d_da.max()) <= 4e-3 * sc_da
+    for tk, hk in (("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                   ("opacities", "dL_dopacities"), ("shs", "dL_dshs"), ("means2D", "dL_dmeans2D")):
+        ref = np.asarray(r["grads"][tk], dtype=np.float64)
+        e = np.abs(o[hk].cpu().numpy().astype(np.float64).reshape(ref.shape) - ref)
+        sc = rel_scale(ref)
+        n_over = int((e > 1e-5 * sc).sum())
+        if r32 is None:
+            print(f"[{label} vs float64 autograd] {hk}: max {e.max() / sc:.1e}, {n_over} entries beyond 1e-5 (scale {sc:.2e})")
+            assert n_over <= flips_allow and float(e.max()) <= 1e-4 * sc, f"{hk}: {n_over} entries beyond 1e-5, max {e.max() / sc:.2e}"
+            continue
+        e32 = np.abs(np.asarray(r32["grads"][tk], dtype=np.float64).reshape(ref.shape) - ref)
+        n32 = int((e32 > 1e-5 * sc).sum())
+        n_nz = int((ref != 0).sum())
+        print(f"[{label} vs float64 autograd] {hk}: max {e.max() / sc:.1e}, {n_over} of {n_nz} non-zero entries beyond 1e-5 (scale "
+              f"{sc:.2e}); the float32 evaluation of the independent restatement: max {e32.max() / sc:.1e}, {n32} entries")
+        # no further from float64 than an independent float32 evaluation of the same algorithm is, and nowhere by more than the
+        # alpha_min step of a gate taken the other way
+        assert n_over <= 1.5 * n32 + 8 and float(e.max()) <= max(2.0 * float(e32.max()), 1e-4 * sc) and float(e.max()) <= 4e-3 * sc, \
+            f"{hk}: {n_over} entries beyond 1e-5 (float32 restatement: {n32}), max {e.max() / sc:.2e} ({e32.max() / sc:.2e})"
+        assert n_over <= 0.005 * n_nz, f"{hk}: {n_over} of {n_nz} non-zero entries beyond 1e-5"
+
+
 def test_c3_window_vs_the_independent_float64_autograd_oracle(built_lib):
     """BASELINE.json configs[2] -- the metric's own configuration, 500 k Gaussians @1024^2 -- against the INDEPENDENT float64
     restatement (oracle/torch_oracle.py: libm exp, autograd backward; nothing in common with the kernels but the algorithm), on a
@@ -412,39 +470,22 @@ def test_c3_window_vs_the_independent_float64_autograd_oracle(built_lib):
     blended per pixel -- instead of C2's. (the independent evidence stopped at 100 k @512^2.) Same allowance
     as at C2: float64 takes a hard gate the other way on about one pixel per 10^5; <= 4 pixels / entries per tensor beyond 1e-5,
     none beyond 1e-4 (gradients) / 4e-3 (the alpha_min T step of a flipped gate)."""
-    from dreamscene_amd import rasterizer as R, synth
-    from tests.test_oracle_consistency import _torch_run
-    P, K, D, res = 500_000, 16, 3, 1024
-    win = (28, 36, 28, 36)                       # ty0, ty1, tx0, tx1
-    y0, y1, x0, x1 = win[0] * 16, win[1] * 16, win[2] * 16, win[3] * 16
-    g = synth.g_object(P, seed=0, K=K)
-    cam = synth.object_cameras(1, res, res)[0]
-    bg = np.ones(3, np.float32)
-    gi, gda = synth.upstream_grads(res, res, 0)
-    mask = np.zeros((res, res), np.float32)
-    mask[y0:y1, x0:x1] = 1.0
-    gi, gda = gi * mask, gda * mask
-    torch.set_num_threads(min(32, max(1, (os.cpu_count() or 2) // 2)))
-    r = _torch_run(g, cam, bg, D, gi=gi, gda=gda, cam_grad=False, tile_window=win)
-    t = {k: torch.tensor(v, device=DEV) for k, v in g.items()}
-    out, st = _forward(t, cam, bg, D, want_keys=False)
-    o = R.rasterize_backward_raw(st, torch.tensor(gi, device=DEV), torch.tensor(gda, device=DEV))
-    torch.cuda.synchronize()
-    dr = np.abs(out["radii"].cpu().numpy().astype(np.int64) - r["radii"].astype(np.int64))
-    assert dr.max() <= 1 and int((dr > 0).sum()) <= 40, (int(dr.max()), int((dr > 0).sum()))     # (500 k radii; C2 allows 8 of 100 k)
-    nc = out["n_contrib"].cpu().numpy().view(np.uint32)[y0:y1, x0:x1]
-    assert int(nc.max()) > 300                                                     # the window IS deep
-    assert int((nc != r["aux"]["n_contrib"][y0:y1, x0:x1]).sum()) <= 8
-    d_img = np.abs(out["color"].cpu().numpy().astype(np.float64) - r["img"]).max(axis=0)[y0:y1, x0:x1]
-    assert int((d_img > 1e-5).sum()) <= 4 and float(d_img.max()) <= 4e-3, (int((d_img > 1e-5).sum()), float(d_img.max()))
-    d_da = np.abs(out["depth_alpha"].cpu().numpy().astype(np.float64) - r["da"]).max(axis=0)[y0:y1, x0:x1]
-    sc_da = rel_scale(r["da"])
-    assert int((d_da > 1e-5 * sc_da).sum()) <= 4 and float(d_da.max()) <= 4e-3 * sc_da
-    for tk, hk in (("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
-                   ("opacities", "dL_dopacities"), ("shs", "dL_dshs"), ("means2D", "dL_dmeans2D")):
-        ref = np.asarray(r["grads"][tk], dtype=np.float64)
-        e = np.abs(o[hk].cpu().numpy().astype(np.float64).reshape(ref.shape) - ref)
-        sc = rel_scale(ref)
-        n_over = int((e > 1e-5 * sc).sum())
-        print(f"[C3 window vs float64 autograd] {hk}: max {e.max() / sc:.1e}, {n_over} entries beyond 1e-5 (scale {sc:.2e})")
-        assert n_over <= 4 and float(e.max()) <= 1e-4 * sc, f"{hk}: {n_over} entries beyond 1e-5, max {e.max() / sc:.2e}"
+    _window_vs_float64(500_000, 1024, (28, 36, 28, 36), False, radii_allow=40, min_depth=300, label="C3 window", threads=32)
+
+
+def test_initial_state_window_vs_the_independent_float64_autograd_oracle(built_lib):
+    """The state the reference's training STARTS in -- every opacity 0.1 (gs_renderer.py:598) -- at C2's size, same crop and same
+    allowances: nothing saturates early there, a pixel of the window blends ~2 200 splats (up to ~3 000) where the trained state
+    blends a few hundred, so fp32 compositing and K7's sums are at their longest. (the init state is where the kernels
+    spend their time -- K7 0.13 of the roofline -- and had been checked against the co-defined C oracle only.) The window takes
+    3.6e7 hard gate decisions (16 384 pixels x ~2 200 splats) where C3's takes ~1e7: float64 takes 7 of them the other way in
+    the IMAGE (measured; each shows as one pixel with a T step of up to 2e-3; <= 16 allowed) -- and behind every such gate ~2 000
+    splats of that pixel see a different T, so the count of gradient entries beyond 1e-5 of their tensor's scale is no longer a
+    handful: 43 ... 544 per tensor for the scalar C oracle (whose arithmetic the kernels share), 57 ... 725 for the SAME independent
+    restatement evaluated in float32 by torch, max 5e-4 ... 3e-3 for both (CPU run, round 6). A property of the algorithm's hard
+    gates in fp32 at this depth, not of a kernel. What is asserted for the gradients here: the HIP path is no further from float64
+    than that independent float32 evaluation is (entries beyond 1e-5: <= 1.5 x its count + 8; max: <= 2 x its max), nowhere beyond
+    the 4e-3 of a flipped gate, and at most 0.5 % of a tensor's non-zero entries are affected at all (measured on the GPU: 0.03 ...
+    0.24 %; 189 / 212 / 65 / 43 / 544 / 180 entries against 235 / 260 / 82 / 56 / 716 / 226 for the float32 restatement)."""
+    _window_vs_float64(100_000, 512, (12, 20, 12, 20), True, radii_allow=8, min_depth=1500, label="C2 init-state window", threads=32,
+                       flips_allow=16, beside_fp32=True)
