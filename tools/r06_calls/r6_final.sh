@@ -14,3 +14,11 @@ try:
 except Exception as e: print("bench failed", e)
 PY
 bash tools/sweep.sh r06 > $O/sweep.log 2>&1; tail -12 $O/sweep.log
+# exchange kernels of the final tree (device side + kernel trace)
+cd $ROOT
+timeout 600 python tools/bench_exchange_device.py > $O/exchange_device_c3.json 2> $O/ex.err; echo "exchange c3 rc=$?"
+timeout 600 python tools/bench_exchange_device.py --res 800 --views 1 > $O/exchange_device_c4.json 2>> $O/ex.err; echo "exchange c4 rc=$?"
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python $ROOT/tools/bench_exchange_device.py > $O/trace.log 2>&1
+python $ROOT/tools/kstats.py $O/trace 2>/dev/null | grep -E "k_msg|k_rows|k_sum|kernel " | head -12 | tee $O/exchange_kernel_stats.txt
+rm -rf $O/trace
