@@ -1202,6 +1202,16 @@ def cpu_baseline_leg(g, cam, D, K, H, W, gi_np, gda_np, hip_out, extra_cams=(), 
            "what": "view 0 through the plain per-view module (the drop-in path) against the scalar C oracle"}
     if timed_path is not None:
         err["batched_sum"] = timed_path_check(timed_path, (f, b), g, D, K, H, W, gi_np, gda_np)
+    # one word for the reader of the line: is every checked tensor inside the bar? (round 6: a stale-rows bug in the arena path showed
+    # in `batched_sum` as 4e-2 on ONE tensor while `value` looked fine -- and went unnoticed until the numbers were read)
+    bs = err.get("batched_sum") or {}
+    worst_all = max([worst_rel] + [v["max_err_over_max_ref"] for v in (bs.get("per_tensor") or {}).values()] +
+                    [bs.get(k, 0.0) for k in ("depth_alpha_max_err_over_max_ref", "means2D_grad_max_err_over_max_ref")])
+    err["within_1e-5_of_own_scale"] = bool(worst_all <= 1e-5 and err["bit_exact_radii"] and err["image_max_abs"] <= 1e-5 and
+                                           bs.get("bit_exact_radii_all_views", True) and bs.get("image_max_abs_all_views", 0.0) <= 1e-5)
+    if not err["within_1e-5_of_own_scale"]:
+        print(f"bench.py: PARITY CHECK FAILED on the line (worst {worst_all:.3e} of a tensor's own scale): max_grad_err_vs_oracle",
+              file=sys.stderr, flush=True)
     return base, err
 
 

@@ -393,7 +393,7 @@ class CapturedViews(torch.nn.Module):
         if self._result_versions(cap, rc) != cap.bwd_versions:
             return False
         if arena is not None:
-            if (zo & 1) and not arena.zero_outside_ok():
+            if (zo & 1) and not arena.zero_outside_ok(cap.bwd["_regions"]):
                 return False
             if (zo & 2) and getattr(arena, "_mask_owner", None) is not cap.bwd["_token"]:
                 return False
@@ -415,7 +415,7 @@ class CapturedViews(torch.nn.Module):
         """Bookkeeping behind a replay of graph C (the launches ran without rasterize_backward_views_raw): the arena holds K8's
         rows and bitmap again, and the result tensors what K8 wrote."""
         if rc.grad_arena is not None:
-            R._arena_written(rc.grad_arena, bool(rc.accumulate), cap.bwd["_token"])
+            R._arena_written(rc.grad_arena, bool(rc.accumulate), cap.bwd["_token"], cap.bwd["_regions"])
         cap.bwd_versions = self._result_versions(cap, rc)
 
     def _direct_graph(self, cap: _Captured, gcs, gdas, rc, per_view, trusted: bool):

@@ -45,6 +45,7 @@ class GradArena:
         # nothing reached (84 % of the rows at C3). A torch op that writes `flat` (or a view of it) in place shows in the
         # version counter; anything that writes it through raw pointers calls touch().
         self.zero_outside_reached = True
+        self._maintained = frozenset(n for n, _ in FIELDS)     # the regions the last overwriting backward wrote (all: a fresh arena)
         self._k8_version = self.flat._version
         self._mask_owner = None       # whose per-view rows the bitmap describes as well (rasterize_backward_views_raw, `persistent`)
 
@@ -53,10 +54,13 @@ class GradArena:
         self.reached_valid = False
         self.zero_outside_reached = False
 
-    def zero_outside_ok(self) -> bool:
-        """Are the rows outside the reached bitmap known to be zero? (nothing but the HIP backward wrote the arena since the
-        bitmap was left)"""
-        return self.zero_outside_reached and self.flat._version == self._k8_version
+    def zero_outside_ok(self, regions=None) -> bool:
+        """Are the rows outside the reached bitmap known to be zero -- in `regions` (names of FIELDS; default all)? True when nothing
+        but the HIP backward wrote the arena since the bitmap was left AND that backward wrote those regions: a call with per-view
+        scales leaves the arena's `scales` region as it was, under a NEW bitmap (its scale gradients go to a [V,P,3] tensor of their
+        own), so the next call that writes `scales` must clear all of it."""
+        need = frozenset(n for n, _ in FIELDS) if regions is None else frozenset(regions)
+        return self.zero_outside_reached and self.flat._version == self._k8_version and need <= self._maintained
 
     def reached_rows(self) -> Optional[torch.Tensor]:
         """Ascending indices of the Gaussians whose row MAY be non-zero (a superset of the non-zero rows), from the bitmap

@@ -738,24 +738,38 @@ def _backward_scene(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bool, mod
     return o
 
 
-def _arena_zero_outside(arena, accumulate: bool) -> int:
-    """GsrGrads.zero_outside bit 0 for a backward that OVERWRITES the arena: its rows outside the reached bitmap are known to be
-    zero (GradArena.zero_outside_reached) -- K8 clears what the bitmap names and nothing else."""
+def _arena_regions(g, per_view_scales: bool = False):
+    """The regions of a GradArena a backward over the Gaussians `g` (GsrGaussians) writes."""
+    r = {"means3D", "opacities"}
+    if g.shs:
+        r.add("shs")
+    if g.scales and not per_view_scales:
+        r.add("scales")
+    if g.rotations:
+        r.add("rotations")
+    return frozenset(r)
+
+
+def _arena_zero_outside(arena, accumulate: bool, regions=None) -> int:
+    """GsrGrads.zero_outside bit 0 for a backward that OVERWRITES `regions` of the arena (default all): their rows outside the
+    reached bitmap are known to be zero (GradArena.zero_outside_ok) -- K8 clears what the bitmap names and nothing else."""
     if arena is None or accumulate or getattr(arena, "reached", None) is None:
         return 0
     ok = getattr(arena, "zero_outside_ok", None)
-    return 1 if (ok is not None and ok()) else 0
+    return 1 if (ok is not None and ok(regions)) else 0
 
 
-def _arena_written(arena, accumulate: bool, token=None) -> None:
+def _arena_written(arena, accumulate: bool, token=None, regions=None) -> None:
     """Bookkeeping behind a HIP backward into the arena: K8 left the bitmap of the rows it reached (OR-ed into it when
-    accumulating) and, when it overwrote, zeros everywhere else. token: the persistent result dict whose per-view rows the new
-    bitmap describes as well (an OR-ed bitmap stays a superset of whatever it described)."""
+    accumulating) and, when it overwrote, zeros everywhere else IN THE REGIONS IT WRITES (default all; the others now sit under a
+    bitmap that does not describe them). token: the persistent result dict whose per-view rows the new bitmap describes as well
+    (an OR-ed bitmap stays a superset of whatever it described)."""
     if arena is None or getattr(arena, "reached", None) is None:
         return
     arena.reached_valid = True
     if not accumulate:
         arena.zero_outside_reached = True
+        arena._maintained = frozenset(arena.views) if regions is None else frozenset(regions)
         arena._k8_version = arena.flat._version
         arena._mask_owner = token
     elif arena.flat._version != getattr(arena, "_k8_version", None):
@@ -800,7 +814,7 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
     gr.accumulate = int(bool(accumulate and arena is not None))
     if arena is not None and getattr(arena, "reached", None) is not None:
         gr.reached_mask = arena.reached.data_ptr()      # K8 marks the rows an exchange has to move (GradArena.reached_rows)
-        gr.zero_outside = _arena_zero_outside(arena, gr.accumulate != 0)
+        gr.zero_outside = _arena_zero_outside(arena, gr.accumulate != 0, _arena_regions(g))
     _bind_stats(gr, stats, P, dev)
     ig = L.GsrImageGrads()
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
@@ -817,7 +831,7 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
         scratch.end(ok)
         if not ok and arena is not None:
             arena.touch()
-    _arena_written(arena, gr.accumulate != 0)
+    _arena_written(arena, gr.accumulate != 0, None, _arena_regions(g))
     return o
 
 
@@ -939,7 +953,8 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
     # (with an arena the bitmap is the ARENA's: it describes this dict's per-view rows only if this dict's call wrote it last)
     keeps = reuse is not None and token is not None and not acc and has_mask and \
         (arena is None or getattr(arena, "_mask_owner", None) is token)
-    zo = (_arena_zero_outside(arena, acc) if arena is not None else (1 if keeps else 0)) | (2 if keeps else 0)
+    regions = _arena_regions(g, per_view_scales)
+    zo = (_arena_zero_outside(arena, acc, regions) if arena is not None else (1 if keeps else 0)) | (2 if keeps else 0)
     if not trust_zeros:
         zo = 0
     views = (L.GsrView * V)(*[st.view for st in states])
@@ -985,10 +1000,10 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         scratch.end(ok)
         if not ok and arena is not None:
             arena.touch()
-    _arena_written(arena, acc, token)
+    _arena_written(arena, acc, token, regions)
     o["dL_dmeans2D"] = m2d[:, :P]
     o["_m2d"], o["_scratch"] = m2d, scratch
-    o["_reached"], o["_token"], o["_zero_outside"] = own_mask, token, zo
+    o["_reached"], o["_token"], o["_zero_outside"], o["_regions"] = own_mask, token, zo, regions
     return o
 
 

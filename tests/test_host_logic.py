@@ -319,3 +319,11 @@ def test_arena_knows_when_its_rows_outside_the_bitmap_are_zero():
     a.touch()
     assert not a.zero_outside_ok() and not a.reached_valid
     assert R._arena_zero_outside(None, False) == 0
+    # a backward with per-view scales replaces the bitmap without writing the `scales` region: only the regions it wrote are known
+    b = multiview.GradArena(100, 4, "cpu")
+    R._arena_written(b, False, None, ("means3D", "opacities", "shs", "rotations"))
+    assert not b.zero_outside_ok() and b.zero_outside_ok(("means3D", "shs")) and not b.zero_outside_ok(("scales",))
+    assert R._arena_zero_outside(b, False, ("means3D", "opacities", "shs", "rotations")) == 1
+    assert R._arena_zero_outside(b, False, ("means3D", "opacities", "shs", "rotations", "scales")) == 0
+    R._arena_written(b, False, None, None)
+    assert b.zero_outside_ok()

@@ -99,9 +99,13 @@ def _step_sets(n_sets=3):
     return [cams[4 * s:4 * s + 4] for s in range(n_sets)]
 
 
-def _eager_step(rastmod, R, sets, t, ups, dev, arena):
-    """One 4-view step through GaussianRasterizerViews into `arena` (None: plain gradients) -> (param grads, means2D grads)."""
+def _eager_step(rastmod, R, sets, t, ups, dev, arena, per_view_scales=False):
+    """One 4-view step through GaussianRasterizerViews into `arena` (None: plain gradients) -> (param grads, means2D grads).
+    per_view_scales: scales [V,P,3] (the trainers' scale noise): the scale gradients then go to a [V,P,3] tensor of their own and
+    the arena's `scales` region is NOT written."""
     tt = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    if per_view_scales:
+        tt["scales"] = (t["scales"].unsqueeze(0) * torch.tensor([1.0, 1.01, 0.99, 1.02], device=dev).view(4, 1, 1)).requires_grad_(True)
     rast = rastmod(sets, context=R.RasterContext(grad_arena=arena))
     m2d = torch.zeros((4, P, 3), device=dev, requires_grad=True)
     outs = rast(means3D=tt["means3D"], means2D=m2d, shs=tt["shs"], opacities=tt["opacities"], scales=tt["scales"],
@@ -145,6 +149,29 @@ def test_rows_known_to_be_zero_are_not_written_again(built_lib):
     assert not torch.equal(masks[0], masks[1]), "the camera sets were meant to reach different rows"
     arena.touch()
     assert not arena.zero_outside_ok()
+
+
+def test_a_step_with_per_view_scales_leaves_the_scales_region_alone(built_lib):
+    """bench.py's parity block caught this one (round 6): a step with per-view scales replaces the arena's bitmap WITHOUT writing
+    its `scales` region; the next ordinary step must not trust the bitmap for that region -- GradArena.zero_outside_ok(regions)."""
+    from dreamscene_amd import multiview, rasterizer as R, synth
+    from dreamscene_amd.views import GaussianRasterizerViews
+    g = _scene()
+    bg = np.array([0.1, 0.3, 0.9], np.float32)
+    dev = torch.device(DEV)
+    ups = [synth.upstream_grads(H, W, seed=k) for k in range(4)]
+    t = {k: torch.tensor(v, device=DEV) for k, v in g.items()}
+    camsets = _step_sets(3)
+    arena = multiview.GradArena(P, K, dev)
+    for step, (si, pvs) in enumerate([(0, False), (1, True), (2, False), (0, True), (1, True), (2, False)]):
+        sets = [settings_for(c, bg, D, dev) for c in camsets[si]]
+        _eager_step(GaussianRasterizerViews, R, sets, t, ups, dev, arena, per_view_scales=pvs)
+        fresh = multiview.GradArena(P, K, dev)
+        fresh.flat.fill_(2.0)
+        _eager_step(GaussianRasterizerViews, R, sets, t, ups, dev, fresh, per_view_scales=pvs)
+        for name in ("means3D", "rotations", "opacities", "shs") + (() if pvs else ("scales",)):
+            assert torch.equal(arena.views[name], fresh.views[name]), f"step {step} (per-view scales: {pvs}): {name}"
+        assert arena.zero_outside_ok(("means3D", "shs")) and arena.zero_outside_ok() == (not pvs)
 
 
 @pytest.mark.parametrize("with_arena", [True, False])
