@@ -524,6 +524,13 @@ def main():
         rot_rates = {}
         for path_ in rot_paths:
             rot_captured = path_
+            # (every path starts from the benchmark's parameters with a fresh optimizer: the synthetic upstream gradients make the
+            #  scene drift -- more pairs per view, step after step: 1.05 -> 1.14 ms over 900 steps, tools/rotating_probe.py -- and
+            #  the path that ran second was being timed on a heavier scene)
+            with torch.no_grad():
+                for n_ in names:
+                    params[n_].copy_(saved[n_])
+            opt = FusedAdam([params[n_] for n_ in names], lr=2e-5, eps=1e-15)
             for i in range(6):
                 step_rot(i)
             sync()
@@ -543,7 +550,7 @@ def main():
                     "optimizer": "dreamscene_amd.optim.FusedAdam (one launch over the five parameter "
                     "groups, gradients read from the arena), lr 2e-5",
                     "through": best_, "by_path_views_per_s": {k_: round(v_[0], 1) for k_, v_ in rot_rates.items()},
-                    "capture_stats": rot_rates[best_][3]}
+                    "capture_stats": rot_rates.get("graph.CapturedViews", (None,) * 4)[3]}
         with torch.no_grad():                      # back to the benchmark's parameters for what follows
             for n_ in names:
                 params[n_].copy_(saved[n_])
