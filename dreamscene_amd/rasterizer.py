@@ -955,6 +955,11 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         (arena is None or getattr(arena, "_mask_owner", None) is token)
     regions = _arena_regions(g, per_view_scales)
     zo = (_arena_zero_outside(arena, acc, regions) if arena is not None else (1 if keeps else 0)) | (2 if keeps else 0)
+    if per_view_scales and V == 1 and not keeps:
+        # ONE view with "per-view" scales: the library sees an ordinary single view, for which dL_dscales is one of the summed
+        # outputs bit 0 speaks for -- but the buffer is this call's own fresh [1,P,3] tensor, not the arena's region (found by
+        # tools/fuzz_views.py, seeds 90 / 160: uninitialised rows in dL/dscales)
+        zo &= ~1
     if not trust_zeros:
         zo = 0
     views = (L.GsrView * V)(*[st.view for st in states])

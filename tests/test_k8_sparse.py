@@ -226,3 +226,48 @@ def test_captured_backward_keeps_its_results_sparse(built_lib, with_arena):
             _eager_step(GaussianRasterizerViews, R, [settings_for(c, bg, D, dev) for c in camsets[0]], t, ups, dev, arena)
     st = rast.stats
     assert st["replays"] >= 5, st
+
+
+@pytest.mark.parametrize("captured", [False, True])
+def test_one_view_with_per_view_scales_into_a_trusted_arena(built_lib, captured):
+    """tools/fuzz_views.py seeds 90 / 160 (round 6): ONE view whose scales come as [1,P,3]. The library sees an ordinary single view --
+    dL_dscales is then one of the summed outputs GsrGrads.zero_outside bit 0 speaks for -- while the wrapper hands it a fresh
+    [1,P,3] tensor of its own and trusted the ARENA: rows nothing reached kept whatever the allocator's block held."""
+    from dreamscene_amd import graph, multiview, rasterizer as R, synth
+    from dreamscene_amd.views import GaussianRasterizerViews
+    g = _scene()
+    bg = np.array([0.1, 0.3, 0.9], np.float32)
+    dev = torch.device(DEV)
+    gi, gda = (torch.tensor(x, device=dev) for x in synth.upstream_grads(H, W, seed=0))
+    t = {k: torch.tensor(v, device=DEV) for k, v in g.items()}
+    cams = [cs[0] for cs in _step_sets(3)]
+    names = ("means3D", "shs", "opacities", "rotations")
+    leaves = {k: t[k].clone().requires_grad_(True) for k in names}
+    arena = multiview.GradArena(P, K, dev)
+    rast_c = graph.CapturedViews(context=R.RasterContext(grad_arena=arena)) if captured else None
+    for it, ci in enumerate([0, 0, 0, 1, 2, 0, 1]):
+        sets = [settings_for(cams[ci], bg, D, dev)]
+        sc = (t["scales"].unsqueeze(0) * 1.01).requires_grad_(True)
+        poison = torch.full((4 * P * 3 + 64,), float("nan"), device=dev)      # what the next torch.empty of that size will hold
+        del poison
+        m2d = torch.zeros((1, P, 3), device=dev, requires_grad=True)
+        if captured:
+            outs = rast_c(sets, means3D=leaves["means3D"], means2D=m2d, shs=leaves["shs"], opacities=leaves["opacities"], scales=sc,
+                          rotations=leaves["rotations"])
+        else:
+            outs = GaussianRasterizerViews(sets, context=R.RasterContext(grad_arena=arena))(
+                means3D=leaves["means3D"], means2D=m2d, shs=leaves["shs"], opacities=leaves["opacities"], scales=sc,
+                rotations=leaves["rotations"])
+        g_m2d, g_sc = torch.autograd.grad([outs[0][0], outs[0][2]], [m2d, sc], [gi, gda])
+        got_sc, got_m2d, got_arena = g_sc.clone(), g_m2d.clone(), arena.flat.clone()
+        # the same view with nothing to trust: no arena, fresh tensors
+        ref_leaves = {k: t[k].clone().requires_grad_(True) for k in names}
+        sc2 = (t["scales"].unsqueeze(0) * 1.01).requires_grad_(True)
+        m2 = torch.zeros((1, P, 3), device=dev, requires_grad=True)
+        o2 = GaussianRasterizerViews(sets)(means3D=ref_leaves["means3D"], means2D=m2, shs=ref_leaves["shs"],
+                                           opacities=ref_leaves["opacities"], scales=sc2, rotations=ref_leaves["rotations"])
+        r_m2, r_sc, r_mean = torch.autograd.grad([o2[0][0], o2[0][2]], [m2, sc2, ref_leaves["means3D"]], [gi, gda])
+        torch.cuda.synchronize()
+        assert torch.isfinite(got_sc).all(), f"call {it}: uninitialised rows in dL/dscales"
+        assert torch.equal(got_sc, r_sc) and torch.equal(got_m2d, r_m2), f"call {it}"
+        assert torch.equal(arena.views["means3D"], r_mean), f"call {it}: arena"
