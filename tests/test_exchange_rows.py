@@ -263,3 +263,40 @@ def test_slice_messages_give_the_sparse_reduce_scatter(built_lib, P, K, D, W, fr
         res = run(big1, 512)
         assert not any(ok for ok, _, _ in res) and all(w == c2 and wi == c1 for _, w, wi in res), res
         assert all(torch.equal(arenas[r][0].flat, own[r]) for r in range(W))
+
+
+@pytest.mark.parametrize("F", [1, 3, 4, 5, 61, 255, 300, 1024])
+def test_row_messages_of_any_width(built_lib, F):
+    """The message kernels on a plain row-major set: one float per lane for rows of fewer than 4 floats, one dwordx4 per lane from 4
+    on (the last chunk of a row overlapping its neighbour when F is no multiple of 4), rows of more than 256 floats walked in groups of
+    64 chunks -- against the rank-ordered torch adds (tools/fuzz_rowmsg.py is the wide version of this test)."""
+    from dreamscene_amd import multiview
+    dev = torch.device(DEV)
+    P, W, frac = 64 * 3 + 17, 3, 0.4
+    g = torch.Generator().manual_seed(F)
+    dr = multiview._DeviceRows(dev)
+    ranks, ref, first = [], torch.zeros((P, F)), torch.ones(P, dtype=torch.bool)
+    for r in range(W):
+        mask = torch.rand(P, generator=g) < frac
+        dense = torch.randn((P, F), generator=g)
+        dense[~mask] = 0
+        a = dense.to(dev)
+        bits = torch.zeros(((P + 63) // 64) * 64, dtype=torch.int64)
+        bits[:P] = mask.to(torch.int64)
+        words = (bits.view(-1, 64) << torch.arange(64, dtype=torch.int64)).sum(1).to(dev)
+        ranks.append((dr.rowset([(a, F, F)], P), words, a))
+        new, old = mask & first, mask & ~first
+        ref[new] = dense[new]
+        ref[old] = ref[old] + dense[old]
+        first &= ~mask
+    cap = 1024
+    ms = multiview._RowMessages(dev)
+    msg, allm, nbytes = ms.buffers(P, F, W, cap)
+    for r, (rs, words, _) in enumerate(ranks):
+        ms.pack(rs, words, cap)
+        allm[r * nbytes:(r + 1) * nbytes].copy_(msg)
+    rs, _, a = ranks[0]
+    ms.apply(rs, W, cap)
+    ok, _ = ms.result()
+    torch.cuda.synchronize()
+    assert ok and torch.equal(a.cpu(), ref)

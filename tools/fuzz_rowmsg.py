@@ -1,5 +1,5 @@
 """One-off widening of tests/test_exchange_rows.py on the GPU box: the row-message kernels (gsr_rowmsg_pack / _pack_slices / _reduce /
-_apply / _apply_slices) on random ROW-MAJOR and split row sets -- row widths 1 ... 200 (the F <= 64 several-rows-per-instruction map
+_apply / _apply_slices) on random ROW-MAJOR and split row sets -- row widths 1 ... 1024 (the F <= 64 several-rows-per-instruction map
 and the F > 64 chunked map), 1 ... 16 messages (both template instances), row counts around the 64-row word boundaries, densities 0 ...
 1 -- against the rank-ordered torch adds. usage: python tools/fuzz_rowmsg.py [n_seeds] [first_seed]"""
 import os
@@ -18,7 +18,11 @@ lib = _lib.load()
 def one(seed):
     rng = np.random.default_rng(seed)
     P = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 1000, 4099, 20000, 70001]))
-    F = int(rng.choice([1, 2, 3, 7, 14, 23, 38, 59, 63, 64, 65, 100, 128, 200]))
+    # (4 ... 256: one dwordx4 chunk per lane, 64 / chunks rows per instruction; 257 ... 1024: more than 64 chunks per row, walked in
+    #  groups of 64 lanes; 1 ... 3: the one-float-per-lane instances)
+    F = int(rng.choice([1, 2, 3, 4, 5, 7, 14, 23, 38, 59, 63, 64, 65, 100, 128, 200, 255, 256, 257, 300, 513, 1024]))
+    if F > 256:
+        P = min(P, 4099)
     W = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16]))
     frac = float(rng.choice([0.0, 0.01, 0.1, 0.3, 0.9, 1.0]))
     split = bool(rng.integers(0, 2)) and F >= 3          # the row set as two regions with padding between rows
