@@ -503,8 +503,9 @@ def main():
         saved = {n_: params[n_].detach().clone() for n_ in names}
         opt = FusedAdam([params[n_] for n_ in names], lr=2e-5, eps=1e-15)
         arena_grads = [arena.views[n_].view(params[n_].shape) for n_ in names]
-        # (both paths are timed here, whatever the headline step chose: with NEW cameras and an optimizer step every iteration the
-        #  eager path is paced by the host's ~45 launches per step, the captured one by the GPU)
+        # (both paths are timed here, whatever the headline step chose; at C3 both turn out GPU-bound -- 1 040 us of kernels per
+        #  step with the wider random cameras and 128 us of Adam, tools/rotating_probe.py -- smaller workloads are paced by the
+        #  host's ~45 launches per step on the eager path)
         rot_paths = [None] + ([CapturedViews(context=views_ctx)] if (batched and cap_mode != "off") else [])
         rot_captured = None
 
