@@ -362,7 +362,8 @@ class CapturedViews(torch.nn.Module):
             with torch.cuda.graph(cap.gC, pool=cap.gF.pool(), capture_error_mode="thread_local"):
                 oc = R.rasterize_backward_views_raw(cap.states, list(cap.g_color), list(cap.g_da), arena=rc.grad_arena,
                                                     accumulate=rc.accumulate, stats=rc.densify_stats,
-                                                    stats_views=rc.stats_views, per_view_scales=per_view, reuse=o)
+                                                    stats_views=rc.stats_views, per_view_scales=per_view, reuse=o,
+                                                    trust_zeros=True)
             cap.bwd = o
             cap.bwd_zo = int(oc["_zero_outside"])       # what graph C's K8 takes for granted about the result tensors
             cap.gC0 = None                              # graph C without that premise (captured when first needed)

@@ -812,9 +812,12 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
         setattr(gr, k, _ptr(t))
     _bind_scratch(gr, scratch)
     gr.accumulate = int(bool(accumulate and arena is not None))
+    capturing = False
     if arena is not None and getattr(arena, "reached", None) is not None:
         gr.reached_mask = arena.reached.data_ptr()      # K8 marks the rows an exchange has to move (GradArena.reached_rows)
-        gr.zero_outside = _arena_zero_outside(arena, gr.accumulate != 0, _arena_regions(g))
+        # (not under a capture: what is known now need not hold when the graph replays)
+        capturing = torch.cuda.is_current_stream_capturing()
+        gr.zero_outside = 0 if capturing else _arena_zero_outside(arena, gr.accumulate != 0, _arena_regions(g))
     _bind_stats(gr, stats, P, dev)
     ig = L.GsrImageGrads()
     ig.dL_dcolor, ig.dL_ddepth_alpha = dL_dcolor.data_ptr(), dL_ddepth_alpha.data_ptr()
@@ -831,7 +834,10 @@ def rasterize_backward_raw(st: _State, dL_dcolor, dL_ddepth_alpha, cam_grads: bo
         scratch.end(ok)
         if not ok and arena is not None:
             arena.touch()
-    _arena_written(arena, gr.accumulate != 0, None, _arena_regions(g))
+    if capturing and arena is not None:
+        arena.touch()          # (nothing ran yet; the graph's replays are the capturer's business: nothing is known about the arena)
+    else:
+        _arena_written(arena, gr.accumulate != 0, None, _arena_regions(g))
     return o
 
 
@@ -894,7 +900,7 @@ def rasterize_backward_views_scene_raw(states, dL_dcolors, dL_ddepth_alphas, mod
 def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=None, accumulate: bool = False,
                                  stats=None, stats_views=None, per_view_scales: Optional[bool] = None,
                                  profile=None, reuse: Optional[dict] = None, private_scratch: bool = False,
-                                 persistent: bool = False, trust_zeros: bool = True) -> dict:
+                                 persistent: bool = False, trust_zeros: Optional[bool] = None) -> dict:
     """Backward of several views of the same Gaussians through gsr_backward_views: K7 per view, one K8 pass over all
     views. Returns the SUMMED parameter gradients (written to / added to the arena's views when given) and the per-view
     means2D gradients [V,P,3]. per_view_scales (default: whether the views' scales are different tensors): every view has
@@ -904,7 +910,8 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
     zeroing them all if something did): the dict then carries a reached-row bitmap of its own (without an arena) and calls with
     `reuse` run with GsrGrads.zero_outside -- K8 clears the rows the previous call reached and this one does not, instead of
     everything nothing reached (118 + 24 MB of zeros per 4-view step at C3). trust_zeros=False: never (the call clears every row
-    nothing reached, whatever is known about the tensors)."""
+    nothing reached, whatever is known about the tensors); None (default): unless the stream is being captured -- what is known now
+    need not hold when somebody else's graph replays (graph.py, which checks before every replay, says True explicitly)."""
     lib = L.load()
     V = len(states)
     st0 = states[0]
@@ -960,6 +967,9 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         # outputs bit 0 speaks for -- but the buffer is this call's own fresh [1,P,3] tensor, not the arena's region (found by
         # tools/fuzz_views.py, seeds 90 / 160: uninitialised rows in dL/dscales)
         zo &= ~1
+    foreign_capture = trust_zeros is None and torch.cuda.is_current_stream_capturing()
+    if trust_zeros is None:
+        trust_zeros = not foreign_capture
     if not trust_zeros:
         zo = 0
     views = (L.GsrView * V)(*[st.view for st in states])
@@ -1005,7 +1015,10 @@ def rasterize_backward_views_raw(states, dL_dcolors, dL_ddepth_alphas, arena=Non
         scratch.end(ok)
         if not ok and arena is not None:
             arena.touch()
-    _arena_written(arena, acc, token, regions)
+    if foreign_capture and arena is not None:
+        arena.touch()          # (nothing ran; when and how often the graph will run is the capturer's business: nothing is known)
+    else:
+        _arena_written(arena, acc, token, regions)
     o["dL_dmeans2D"] = m2d[:, :P]
     o["_m2d"], o["_scratch"] = m2d, scratch
     o["_reached"], o["_token"], o["_zero_outside"], o["_regions"] = own_mask, token, zo, regions
