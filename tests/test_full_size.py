@@ -489,3 +489,59 @@ def test_initial_state_window_vs_the_independent_float64_autograd_oracle(built_l
     0.24 %; 189 / 212 / 65 / 43 / 544 / 180 entries against 235 / 260 / 82 / 56 / 716 / 226 for the float32 restatement)."""
     _window_vs_float64(100_000, 512, (12, 20, 12, 20), True, radii_allow=8, min_depth=1500, label="C2 init-state window", threads=32,
                        flips_allow=16, beside_fp32=True)
+
+
+def test_c3_steps_with_changing_cameras_leave_the_same_arena_as_full_clears(built_lib):
+    """GsrGrads.zero_outside at BASELINE.json configs[2]'s size (500 k Gaussians @1024^2: the 1 024-Gaussians-per-workgroup form of
+    K8, sixteen 64-row chunks per workgroup, gridDim.x * 64 apart): six 4-view steps with a DIFFERENT camera set each -- through the
+    eager batched module and through graph.CapturedViews, into one arena each -- against the same step into a poisoned arena that
+    has to be cleared in full. Same bits, bitmap included."""
+    from dreamscene_amd import multiview, synth
+    from dreamscene_amd.graph import CapturedViews
+    from dreamscene_amd.rasterizer import RasterContext
+    from dreamscene_amd.views import GaussianRasterizerViews
+    P, K, D, res, V = 500_000, 16, 3, 1024, 4
+    dev = torch.device(DEV)
+    g = synth.g_object(P, seed=0, K=K)
+    cams = synth.object_cameras(12, res, res)
+    bg = np.ones(3, np.float32)
+    params = {k: torch.tensor(v, device=DEV, requires_grad=True) for k, v in g.items()}
+    gi, gda = (torch.tensor(x, device=DEV) for x in synth.upstream_grads(res, res, 0))
+    arena_e, arena_c = multiview.GradArena(P, K, dev), multiview.GradArena(P, K, dev)
+    cap = CapturedViews(context=RasterContext(grad_arena=arena_c))
+
+    def run(rast_call, arena):
+        m2d = torch.zeros((V, P, 3), device=DEV, requires_grad=True)
+        outs = rast_call(m2d)
+        (g2d,) = torch.autograd.grad([x for (img, _, da) in outs for x in (img, da)], [m2d], [gi, gda] * V)
+        torch.cuda.synchronize()
+        return g2d.clone(), arena.flat.clone(), arena.reached.clone()
+    kw = dict(means3D=params["means3D"], opacities=params["opacities"], shs=params["shs"], scales=params["scales"],
+              rotations=params["rotations"])
+    trusted = 0
+    warm = multiview.GradArena(P, K, dev)      # (the first call at a size learns the pair counts one view at a time: another path)
+    sl0 = [settings_for(cams[j], bg, D, DEV) for j in range(V)]
+    run(lambda m: GaussianRasterizerViews(sl0, context=RasterContext(grad_arena=warm))(means2D=m, **kw), warm)
+
+    def same(got, ref, what, exact):
+        # a stale row shows as a non-zero where the reference has a zero; the captured step may cut K7's work into other segments
+        # than the eager one (last-bit differences in the sums), so only the eager pair is compared bit for bit
+        assert torch.equal(got != 0, ref != 0), f"{what}: zero pattern"
+        if exact:
+            assert torch.equal(got, ref), what
+        else:
+            sc = float(ref.abs().max())
+            assert float((got - ref).abs().max()) <= 1e-6 * sc, what
+    for step, first in enumerate([0, 0, 0, 4, 8, 2, 6, 0]):
+        sl = [settings_for(cams[(first + j) % 12], bg, D, DEV) for j in range(V)]
+        fresh = multiview.GradArena(P, K, dev)
+        fresh.flat.fill_(9.0)
+        ref = run(lambda m: GaussianRasterizerViews(sl, context=RasterContext(grad_arena=fresh))(means2D=m, **kw), fresh)
+        trusted += int(arena_e.zero_outside_ok())
+        got_e = run(lambda m: GaussianRasterizerViews(sl, context=RasterContext(grad_arena=arena_e))(means2D=m, **kw), arena_e)
+        got_c = run(lambda m: cap(sl, means2D=m, **kw), arena_c)
+        for name, got in (("eager", got_e), ("captured", got_c)):
+            same(got[0], ref[0], f"step {step} ({name}): dL_dmeans2D", name == "eager")
+            same(got[1], ref[1], f"step {step} ({name}): arena", name == "eager")
+            assert torch.equal(got[2], ref[2]), f"step {step} ({name}): reached bitmap"
+    assert trusted == 8 and cap.stats["replays"] >= 4 and cap.stats.get("bwd_zero_outside") == 3, (trusted, cap.stats)
