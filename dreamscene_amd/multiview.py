@@ -62,6 +62,15 @@ class GradArena:
         need = frozenset(n for n, _ in FIELDS) if regions is None else frozenset(regions)
         return self.zero_outside_reached and self.flat._version == self._k8_version and need <= self._maintained
 
+    def verify_zero_outside(self, regions=None) -> bool:
+        """The invariant behind GsrGrads.zero_outside, checked the slow way (a scan of the arena; debugging / tests): is every row
+        outside the reached bitmap zero in `regions` (default: the regions the last overwriting backward wrote)? A writer that
+        goes through raw pointers and forgets touch() shows here."""
+        sh = torch.arange(64, device=self.reached.device, dtype=torch.int64)
+        inside = (((self.reached.unsqueeze(1) >> sh) & 1).reshape(-1)[:self.P]).to(torch.bool)
+        names = self._maintained if regions is None else regions
+        return all(bool((self.views[n].reshape(self.P, -1)[~inside] == 0).all()) for n in names)
+
     def reached_rows(self) -> Optional[torch.Tensor]:
         """Ascending indices of the Gaussians whose row MAY be non-zero (a superset of the non-zero rows), from the bitmap
         K8 wrote; None when the bitmap is not valid."""

@@ -544,4 +544,6 @@ def test_c3_steps_with_changing_cameras_leave_the_same_arena_as_full_clears(buil
             same(got[0], ref[0], f"step {step} ({name}): dL_dmeans2D", name == "eager")
             same(got[1], ref[1], f"step {step} ({name}): arena", name == "eager")
             assert torch.equal(got[2], ref[2]), f"step {step} ({name}): reached bitmap"
+        # the invariant itself, the slow way: every row outside the bitmap is zero
+        assert arena_e.verify_zero_outside() and arena_c.verify_zero_outside() and fresh.verify_zero_outside(), step
     assert trusted == 8 and cap.stats["replays"] >= 4 and cap.stats.get("bwd_zero_outside") == 3, (trusted, cap.stats)

@@ -327,3 +327,9 @@ def test_arena_knows_when_its_rows_outside_the_bitmap_are_zero():
     assert R._arena_zero_outside(b, False, ("means3D", "opacities", "shs", "rotations", "scales")) == 0
     R._arena_written(b, False, None, None)
     assert b.zero_outside_ok()
+    # the slow check of the invariant itself
+    assert b.verify_zero_outside()
+    b.views["scales"][7, 1] = 1.0
+    assert not b.verify_zero_outside() and b.verify_zero_outside(("means3D", "shs"))
+    b.reached[0] = 1 << 7
+    assert b.verify_zero_outside()

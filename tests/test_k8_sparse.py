@@ -172,6 +172,7 @@ def test_a_step_with_per_view_scales_leaves_the_scales_region_alone(built_lib):
         for name in ("means3D", "rotations", "opacities", "shs") + (() if pvs else ("scales",)):
             assert torch.equal(arena.views[name], fresh.views[name]), f"step {step} (per-view scales: {pvs}): {name}"
         assert arena.zero_outside_ok(("means3D", "shs")) and arena.zero_outside_ok() == (not pvs)
+        assert arena.verify_zero_outside()              # (the regions the last backward wrote: the slow check of the invariant)
 
 
 @pytest.mark.parametrize("with_arena", [True, False])

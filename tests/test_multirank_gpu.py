@@ -98,6 +98,8 @@ def _worker(rank, world, port, mode, out_dir):
         else:
             ex.reduce()
         torch.cuda.synchronize(dev)
+        if arena.zero_outside_ok():       # (the message forms leave the union bitmap: the invariant must hold for the SUM as well)
+            assert arena.verify_zero_outside(), f"step {step}: rows outside the union bitmap are not zero after the exchange"
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=arena.flat.cpu().numpy(), own=own.cpu().numpy(),
              img0=outs[0][0].detach().cpu().numpy(), last=json.dumps(ex.last))
     dist.barrier()
